@@ -1,0 +1,166 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors captured from the reference.
+
+The goldens come from the reference's own pure-PyTorch restatement of its kernels
+(`torch_version`, utils/gs_cuda/check.py:4-27 and utils/gs_cuda_dmax/check.py:4-31) and autograd
+through it -- see tests/golden/make_golden.py.  These tests run on CPU.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle, host_ref
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RASTER = sorted(glob.glob(os.path.join(GOLDEN, "raster_*.npz")))
+
+
+def _case(path):
+    z = np.load(path)
+    dmax = float(z["dmax"])
+    return z, (None if dmax < 0 else dmax)
+
+
+def _relmax(a, b):
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[7:-4] for p in RASTER])
+def test_forward_f32_matches_reference_torch_version(path):
+    z, dmax = _case(path)
+    h, w = int(z["h"]), int(z["w"])
+    img = gs_oracle.forward_f32(z["sigmas"], z["coords"], z["colors"], h, w, dmax)
+    # both are fp32 evaluations with different association; agreement is at fp32 rounding level
+    # relative to the exponent's conditioning (|rho| -> 1 cases amplify it), checked vs fp64 too
+    tol = 2e-3 if "edge" in path else 2e-5
+    assert np.abs(img - z["img_f32"]).max() <= tol * max(1.0, np.abs(z["img_f32"]).max())
+    assert np.abs(img - z["img_f64"]).max() <= tol * max(1.0, np.abs(z["img_f64"]).max())
+
+
+@pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[7:-4] for p in RASTER])
+def test_forward_f64_matches_reference_fp64(path):
+    z, dmax = _case(path)
+    h, w = int(z["h"]), int(z["w"])
+    img = gs_oracle.forward_f64(z["sigmas"], z["coords"], z["colors"], h, w, dmax)
+    # reference fp64 run stores into an fp32 image buffer (check.py:11)
+    assert np.abs(img - z["img_f64"]).max() <= 1e-6 * max(1.0, np.abs(img).max())
+
+
+@pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[7:-4] for p in RASTER])
+def test_backward_matches_reference_autograd(path):
+    z, dmax = _case(path)
+    wgt = z["weight"]
+    g64 = gs_oracle.backward_f64(z["sigmas"], z["coords"], z["colors"], wgt, dmax)
+    g32 = gs_oracle.backward_f32(z["sigmas"], z["coords"], z["colors"], wgt, dmax)
+    for got64, got32, key in zip(g64, g32, ("g_sigmas", "g_coords", "g_colors")):
+        ref64, ref32 = z[key + "_f64"], z[key + "_f32"]
+        # analytic backward (gs.cu) == autograd of the forward: proves the five partials.  Not tighter
+        # than 2e-5 because the reference's fp64 run keeps pixel coordinates in double
+        # (check.py:15-16) while the kernels -- and this oracle -- round them to float (gs.cu:27-28)
+        assert _relmax(got64, ref64) <= 2e-5, key
+        tol = 5e-3 if "edge" in path else 2e-4
+        assert _relmax(got32, ref64) <= tol, key
+        assert _relmax(got32, ref32) <= tol, key
+
+
+def test_known_answers_survey_8c():
+    """checksums of the reference's own check.py cases."""
+    z, _ = _case(os.path.join(GOLDEN, "raster_unbounded_s40_49x49.npz"))
+    img = gs_oracle.forward_f32(z["sigmas"], z["coords"], z["colors"], 49, 49, None)
+    assert abs(float(img.sum(dtype=np.float64)) - 26040.0957) < 0.05
+    np.testing.assert_allclose(img[0, 0], [2.9283757, 4.0633411, 2.5853238], rtol=2e-6)
+    z, dmax = _case(os.path.join(GOLDEN, "raster_dmax0p5_s4_10x10_sig5.npz"))
+    img = gs_oracle.forward_f32(z["sigmas"], z["coords"], z["colors"], 10, 10, dmax)
+    assert abs(float(img.sum(dtype=np.float64)) - 98.180832) < 1e-3
+    np.testing.assert_allclose(img[0, 0], [0.6789380, 0.9116083, 0.3955441], rtol=2e-6)
+
+
+def test_fma_mode_only_matters_near_rho_one():
+    rng = np.random.default_rng(0)
+    s = 16
+    sig = np.stack([rng.uniform(0.05, 0.3, s), rng.uniform(0.05, 0.3, s), rng.uniform(-0.9, 0.9, s)], 1)
+    xy, col = rng.uniform(-1, 1, (s, 2)), rng.uniform(0, 1, (s, 3))
+    a = gs_oracle.forward_f32(sig, xy, col, 24, 24, 0.5, use_fma=False)
+    b = gs_oracle.forward_f32(sig, xy, col, 24, 24, 0.5, use_fma=True)
+    assert np.abs(a - b).max() < 1e-5
+
+
+def test_accumulate_into_and_row_slab():
+    z, dmax = _case(os.path.join(GOLDEN, "raster_dmax0p25_s24_31x47.npz"))
+    h, w = int(z["h"]), int(z["w"])
+    full = gs_oracle.forward_f32(z["sigmas"], z["coords"], z["colors"], h, w, dmax)
+    # chunked callers rely on `+=` (utils/gaussian_splatting.py:146-151)
+    acc = gs_oracle.forward_f32(z["sigmas"][:10], z["coords"][:10], z["colors"][:10], h, w, dmax)
+    acc = gs_oracle.forward_f32(z["sigmas"][10:], z["coords"][10:], z["colors"][10:], h, w, dmax, img=acc)
+    np.testing.assert_allclose(acc, full, rtol=0, atol=1e-5)
+    # row slabs partition the image exactly; gradients add over slabs
+    slab = gs_oracle.forward_f32(z["sigmas"], z["coords"], z["colors"], h, w, dmax, rows=(7, 19))
+    np.testing.assert_array_equal(slab, full[7:19])
+    g_full = gs_oracle.backward_f64(z["sigmas"], z["coords"], z["colors"], z["weight"], dmax)
+    g_a = gs_oracle.backward_f64(z["sigmas"], z["coords"], z["colors"], z["weight"][:13], dmax, h=h, rows=(0, 13))
+    g_b = gs_oracle.backward_f64(z["sigmas"], z["coords"], z["colors"], z["weight"][13:], dmax, h=h, rows=(13, h))
+    for f, a, b in zip(g_full, g_a, g_b):
+        np.testing.assert_allclose(a + b, f, rtol=1e-12, atol=1e-12)
+
+
+def test_autograd_restatement_agrees_with_c_oracle():
+    torch.manual_seed(3)
+    s, h, w = 20, 17, 23
+    sig = torch.stack([0.05 + 0.4 * torch.rand(s), 0.05 + 0.4 * torch.rand(s), 1.8 * torch.rand(s) - 0.9], 1)
+    xy, col = 2 * torch.rand(s, 2) - 1, torch.rand(s, 3)
+    wgt = torch.rand(h, w, 3)
+    for dmax in (None, 0.3):
+        a, b, c = (t.double().requires_grad_(True) for t in (sig, xy, col))
+        img = host_ref.autograd_render(a, b, c, h, w, dmax)
+        (wgt.double() * img).sum().backward()
+        ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), h, w, dmax)
+        # (the C truth rounds dx,dy to float like the kernels; the torch expression keeps them in double)
+        np.testing.assert_allclose(img.detach().numpy(), ref, rtol=5e-6, atol=1e-9)
+        g = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), dmax)
+        for got, t in zip(g, (a, b, c)):
+            assert _relmax(got, t.grad.numpy()) < 2e-5
+
+
+PROLOGUE = sorted(glob.glob(os.path.join(GOLDEN, "prologue_*.npz")))
+
+
+@pytest.mark.parametrize("path", PROLOGUE, ids=[os.path.basename(p)[9:-4] for p in PROLOGUE])
+def test_prologue_restatement_matches_reference_capture(path):
+    z = np.load(path)
+    sc = float(z["scale"])
+    sig, xy, col, dmax = host_ref.prologue(torch.from_numpy(z["gs_parameters"]), z["sr_size"].tolist(),
+                                           torch.tensor([sc, sc]), dmax=float(z["dmax_in"]),
+                                           dmax_mode=str(z["dmax_mode"]))
+    np.testing.assert_allclose(sig.numpy(), z["sigmas"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(xy.numpy(), z["coords"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(col.numpy(), z["colors"], rtol=1e-6, atol=0)
+    if bool(z["if_dmax"]):
+        assert abs(dmax - float(z["dmax_out"])) < 1e-12
+
+
+def test_prologue_worked_example_survey_2_3():
+    g = torch.zeros(2, 9)
+    g[0, 7:9] = torch.tensor([0.5, 0.5])
+    g[1, 7:9] = torch.tensor([0.25, 0.75])
+    g[1, 0], g[1, 2], g[1, 3] = 1.0, 0.5, 2.0
+    sig, xy, col, dmax = host_ref.prologue(g, (40, 52), torch.tensor([4.0, 4.0]), dmax=0.1)
+    np.testing.assert_allclose(sig.numpy(), [[0.06535895, 0.08546940, 0.0], [0.06535895, 0.12496620, 0.46211669]],
+                               rtol=2e-6)
+    np.testing.assert_allclose(xy.numpy(), [[0, 0], [-0.50980389, 0.51282048]], atol=1e-6)
+    np.testing.assert_allclose(col.numpy(), [[0.25] * 3, [0.44039851] * 3], rtol=1e-6)
+    _, _, _, dyn = host_ref.prologue(g, (40, 52), torch.tensor([4.0, 4.0]), dmax=25, dmax_mode="dynamic")
+    assert abs(dyn - 0.675) < 1e-12
+
+
+RP = sorted(glob.glob(os.path.join(GOLDEN, "rendering_python_n*.npz")))
+
+
+@pytest.mark.parametrize("path", RP, ids=[os.path.basename(p)[17:-4] for p in RP])
+def test_rendering_python_restatement(path):
+    z = np.load(path)
+    sc = float(z["scale"])
+    out = host_ref.rendering_python(torch.from_numpy(z["gs_parameters"]), z["sr_size"].tolist(),
+                                    torch.tensor([sc, sc]))
+    np.testing.assert_allclose(out.numpy(), z["out"], rtol=1e-4, atol=2e-5)
