@@ -1,0 +1,286 @@
+#!/usr/bin/env python
+"""bench.py -- HR Mpixels/s of the rasterizer hot path (forward + backward) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dmax 0.1] [--config c2|c3|c4|profile-log]
+
+A "step" is one pass of the hot path over one batch of synthetic Gaussians already resident in HBM:
+plan (bin) -> forward splat into a zeroed [H,W,3] image -> backward to {sigmas, coords, colors}, exactly
+what `GSCUDA.apply(...)` + `.backward()` enqueue, driven through the C ABI of libgsasr_splat.so.
+
+  N = 1   BASELINE.json config 2: 256x256 LR -> x4 (1024^2 HR), 65 536 Gaussians (1 per LR pixel), fp32.
+  N > 1   weak scaling of the row-band shard: the image grows to (1024*N) x 1024 with
+          65 536*N Gaussians; rank g renders rows [g*1024,(g+1)*1024).  Per step: ONE broadcast of the
+          [N_g,8] Gaussians from rank 0 and ONE reduce_scatter of the per-Gaussian gradients (RCCL).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel, measured
+live with events on the launch stream) and `cpu_baseline` (the oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+CONFIGS = {
+    # name: (h_lr, w_lr, scale, description)
+    "c2": (256, 256, 4.0, "config2: 256x256 LR -> x4 (1024^2 HR), 65536 Gaussians, fwd+bwd"),
+    "c3": (512, 512, 12.0, "config3: 512x512 LR -> x12 (6144^2 HR), 262144 Gaussians, fwd only"),
+    "c4": (1024, 1024, 8.0, "config4: 1024x1024 LR -> x8 (8192^2 HR), 1048576 Gaussians, fwd+bwd, row-band shard"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dmax", type=float, default=0.1, help="box half-size; <0 = unbounded gs_cuda op")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--cutoff", type=float, default=0.0, help="support cutoff tau (0 = library default 32)")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true")
+    return ap.parse_args()
+
+
+class Step:
+    """One hot-path pass with preallocated buffers (nothing is allocated inside the timed region)."""
+
+    def __init__(self, args, dev, rank, world):
+        from gsasr_amd import _cabi, synthetic
+        from gsasr_amd.shard import row_band
+        self.cabi, self.dev, self.rank, self.world = _cabi, dev, rank, world
+        h_lr, w_lr, scale, _ = CONFIGS[args.config]
+        self.strong = args.config == "c4"
+        if world > 1 and not self.strong:
+            h_lr = h_lr * world      # weak scaling: stack `world` config-sized images vertically
+        self.fwd_only = args.fwd_only or args.config == "c3"
+        sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=0, device="cpu")
+        self.H, self.W, self.n = H, W, sig.shape[0]
+        self.rows = row_band(H, rank, world)
+        self.dmax = None if args.dmax < 0 else args.dmax
+        self.cutoff = args.cutoff
+        self.sig, self.xy, self.col = (t.to(dev) for t in (sig, xy, col))
+        nrows = self.rows[1] - self.rows[0]
+        self.grad_img = synthetic.grad_image(H, W, 1)[self.rows[0]:self.rows[1]].contiguous().to(dev)
+        self.img = torch.zeros(nrows, W, 3, device=dev)
+        self.g = [torch.zeros_like(t) for t in (self.sig, self.xy, self.col)]
+        self.plan = _cabi.plan(self.sig, self.xy, self.col, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
+        if world > 1:
+            from gsasr_amd import shard
+            self.shard = shard
+            self.packed = shard.pack(self.sig, self.xy, self.col)
+            per = (self.n + world - 1) // world
+            self.gpad = torch.zeros(per * world, 8, device=dev)
+            self.gmine = torch.zeros(per, 8, device=dev)
+
+    # --- the three stages, callable separately for per-kernel timing -------------------------------------
+    def do_plan(self):
+        import ctypes
+        p = self.plan
+        self.cabi.check(self.cabi.lib().gsasr_splat_plan(self.sig.data_ptr(), self.xy.data_ptr(), self.col.data_ptr(),
+                                                         ctypes.byref(p.dims), p.workspace.data_ptr(),
+                                                         p.workspace.numel(), self.cabi._stream(self.dev)), "plan")
+
+    def do_forward(self):
+        self.img.zero_()
+        self.cabi.forward(self.plan, self.img)
+
+    def do_backward(self):
+        for t in self.g:
+            t.zero_()
+        self.cabi.backward(self.plan, self.sig, self.xy, self.col, self.grad_img, *self.g)
+
+    def __call__(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.broadcast(self.packed, src=0)                       # Gaussians from the decoder rank
+        self.do_plan()
+        self.do_forward()
+        if not self.fwd_only:
+            self.do_backward()
+            if self.world > 1:
+                import torch.distributed as dist
+                self.gpad[: self.n, 0:3] = self.g[0]
+                self.gpad[: self.n, 3:5] = self.g[1]
+                self.gpad[: self.n, 5:8] = self.g[2]
+                dist.reduce_scatter_tensor(self.gmine, self.gpad)    # per-Gaussian grads, summed over bands
+
+    # algorithmic bytes: fwd = 32 N + 24 H W, bwd = 64 N + 12 H W  (per rank: own rows)
+    def bytes_fwd(self):
+        return 32 * self.n + 24 * (self.rows[1] - self.rows[0]) * self.W
+
+    def bytes_bwd(self):
+        return 64 * self.n + 12 * (self.rows[1] - self.rows[0]) * self.W
+
+
+def time_stage(fn, iters, dev):
+    """average device time of one call of `fn`, with events recorded on the stream the kernels run on"""
+    st = torch.cuda.current_stream(dev)
+    fn()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(st)
+        fn()
+        b.record(st)
+    torch.cuda.synchronize(dev)
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def cpu_baseline(args):
+    """The oracle's fp32 restatement of the reference kernels (OpenMP over the host cores) on a bounded
+    sample of the SAME workload: a 192-row band of config 2 with all 65 536 Gaussians, forward + backward."""
+    from gsasr_amd import synthetic
+    from oracle import gs_oracle
+    h_lr, w_lr, scale, _ = CONFIGS["c2"]
+    sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=0)
+    rows = (H // 2 - 96, H // 2 + 96)
+    wgt = synthetic.grad_image(H, W, 1)[rows[0]:rows[1]].contiguous().numpy()
+    dmax = None if args.dmax < 0 else args.dmax
+    s, c, k = sig.numpy(), xy.numpy(), col.numpy()
+    cores = gs_oracle.num_threads()
+    t0 = time.perf_counter()
+    gs_oracle.forward_f32(s, c, k, H, W, dmax, rows=rows)
+    t1 = time.perf_counter()
+    gs_oracle.backward_f32(s, c, k, wgt, dmax, h=H, rows=rows)
+    t2 = time.perf_counter()
+    px = (rows[1] - rows[0]) * W
+    out = {"value": px / (t2 - t0) / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/gs_ref.c fp32 restatement of gs_cuda{'_dmax' if dmax is not None else ''} (OpenMP, {cores} threads), "
+                     f"config-2 inputs (N=65536, 1024^2 grid), HR rows [{rows[0]},{rows[1]}) = {px} px, fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s"}
+    # the reference's pure-PyTorch path (utils/gaussian_splatting.py rendering_python), BASELINE.json config 1
+    try:
+        from oracle import host_ref
+        torch.manual_seed(0)
+        g = torch.randn(4096, 9)
+        g[:, 7:9] = torch.rand(4096, 2)
+        torch.set_num_threads(os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        host_ref.rendering_python(g, (256, 256), torch.tensor([4.0, 4.0]))
+        dt = time.perf_counter() - t0
+        out["pytorch_path"] = {"value": 256 * 256 / dt / 1e6, "unit": "HR Mpixels/s (fwd only)",
+                               "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"rendering_python restatement (reference utils/gaussian_splatting.py:11-84), BASELINE.json "
+                                         f"config 1 in full: 4096 Gaussians -> 256^2 HR, x4, forward only, {dt:.2f}s"}
+    except Exception as e:  # never let the baseline break the bench line
+        out["pytorch_path"] = {"error": repr(e)}
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    step = Step(args, dev, rank, world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # optional hipGraph of the whole step (single GPU): removes host launch gaps from the measurement
+    graph, launch = None, "eager"
+    for _ in range(min(3, args.warmup)):
+        step()
+    torch.cuda.synchronize(dev)
+    if world == 1 and not args.no_graph:
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                step()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph, launch = g, "hipgraph"
+        except Exception as e:
+            print(f"[bench] graph capture unavailable ({e!r}); timing eager launches", file=sys.stderr)
+            graph = None
+    run = (lambda: graph.replay()) if graph is not None else step
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms = dt / args.steps * 1e3
+    mpix = step.H * step.W / (dt / args.steps) / 1e6        # whole-job HR pixels per second (all ranks)
+
+    # per-kernel device time, measured live (not part of the timed region)
+    kern = {}
+    for name, fn, nbytes in (("plan", step.do_plan, None), ("forward", step.do_forward, step.bytes_fwd()),
+                             ("backward", step.do_backward, step.bytes_bwd())):
+        if name == "backward" and step.fwd_only:
+            continue
+        avg, med = time_stage(fn, 30, dev)
+        kern[name] = {"avg_ms": avg, "median_ms": med}
+        if nbytes:
+            kern[name].update({"algorithmic_bytes": nbytes, "GBps": nbytes / (avg * 1e-3) / 1e9})
+    dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get({"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom], {}).get("hbm_bytes")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
+                "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "note": "stage time includes the memset of its outputs (12 B/px image, 32 B/Gaussian grads)"}
+
+    if rank == 0:
+        h_lr, w_lr, scale, desc = CONFIGS[args.config]
+        out = {
+            "metric": "HR Mpixels/sec fwd+bwd (x4, 1 Gaussian/LR px); achieved HBM GB/s vs roofline"
+                      if not step.fwd_only else "HR Mpixels/sec fwd only",
+            "value": mpix, "unit": "HR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if step.strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc + (f"; weak-scaled to {step.H}x{step.W} HR / {step.n} Gaussians over {world} row bands"
+                                           if world > 1 and not step.strong else ""),
+                       "H": step.H, "W": step.W, "gaussians": step.n, "dmax": args.dmax,
+                       "cutoff_tau": step.cabi.get_default_cutoff() if args.cutoff == 0 else args.cutoff,
+                       "launch": launch, "parallelism": f"row-band x{world}" if world > 1 else "single"},
+            "roofline": roofline, "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+"""ctypes binding of libgsasr_splat.so (include/gsasr_splat.h) for torch tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; every call below passes raw
+`data_ptr()`s, sizes and `torch.cuda.current_stream().cuda_stream` through the C ABI.  There is NO
+fallback: if the library is missing or a tensor is not a contiguous fp32 CUDA tensor this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libgsasr_splat.so")
+
+EXPORTS = (
+    "gsasr_abi_version", "gsasr_last_error", "gsasr_splat_workspace_bytes", "gsasr_splat_plan",
+    "gsasr_splat_forward", "gsasr_splat_backward", "gsasr_gs_render", "gsasr_gs_render_backward",
+    "gsasr_gs_render_dmax", "gsasr_gs_render_backward_dmax", "gsasr_set_default_cutoff",
+    "gsasr_get_default_cutoff",
+)
+
+FLAG_DETERMINISTIC = 1
+EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
+NO_CUTOFF = -1.0
+
+
+class Dims(ctypes.Structure):
+    """struct gsasr_dims"""
+    _fields_ = [("s", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("c", ctypes.c_int),
+                ("dmax", ctypes.c_float), ("row0", ctypes.c_int), ("row1", ctypes.c_int),
+                ("cutoff", ctypes.c_float), ("flags", ctypes.c_uint)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once). Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP rasterizer is not built. Run `python -m gsasr_amd.build` "
+                "(or __graft_entry__.build()). gsasr_amd has no CPU/eager fallback by design.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, f, i, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+        dp = ctypes.POINTER(Dims)
+        L.gsasr_abi_version.restype = i
+        L.gsasr_last_error.restype = ctypes.c_char_p
+        L.gsasr_splat_workspace_bytes.restype = sz
+        L.gsasr_splat_workspace_bytes.argtypes = [dp]
+        L.gsasr_splat_plan.restype = i
+        L.gsasr_splat_plan.argtypes = [vp, vp, vp, dp, vp, sz, vp]
+        L.gsasr_splat_forward.restype = i
+        L.gsasr_splat_forward.argtypes = [dp, vp, sz, vp, vp]
+        L.gsasr_splat_backward.restype = i
+        L.gsasr_splat_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, dp, vp, sz, vp]
+        L.gsasr_gs_render.restype = i
+        L.gsasr_gs_render.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
+        L.gsasr_gs_render_backward.restype = i
+        L.gsasr_gs_render_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
+        L.gsasr_gs_render_dmax.restype = i
+        L.gsasr_gs_render_dmax.argtypes = [vp, vp, vp, vp, i, i, i, i, f, vp]
+        L.gsasr_gs_render_backward_dmax.restype = i
+        L.gsasr_gs_render_backward_dmax.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp]
+        L.gsasr_set_default_cutoff.restype = None
+        L.gsasr_set_default_cutoff.argtypes = [f]
+        L.gsasr_get_default_cutoff.restype = f
+        if L.gsasr_abi_version() != 1:
+            raise RuntimeError("libgsasr_splat.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().gsasr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")
+
+
+def _chk(t: torch.Tensor, name: str, shape_tail: Optional[Tuple[int, ...]] = None) -> int:
+    # same failure mode as the reference's CHECK_INPUT (gswrapper.cpp:5-7): RuntimeError
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype}); the kernels read raw fp32")
+    if shape_tail is not None and tuple(t.shape[-len(shape_tail):]) != shape_tail:
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected [..., {shape_tail}]")
+    return t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+@dataclass
+class Plan:
+    """Binning workspace of one (sigmas, coords, colors, dims): shared by forward and backward."""
+    dims: Dims
+    workspace: torch.Tensor
+    device: torch.device
+
+
+def make_dims(s: int, h: int, w: int, dmax: Optional[float], rows: Optional[Tuple[int, int]] = None,
+              cutoff: float = 0.0, flags: int = 0) -> Dims:
+    r0, r1 = (0, h) if rows is None else rows
+    return Dims(int(s), int(h), int(w), 3, -1.0 if dmax is None else float(dmax), int(r0), int(r1),
+                float(cutoff), int(flags))
+
+
+def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: int, w: int,
+         dmax: Optional[float], rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0,
+         flags: int = 0) -> Plan:
+    ps = _chk(sigmas, "sigmas", (3,))
+    pc = _chk(coords, "coords", (2,))
+    pk = _chk(colors, "colors", (3,))
+    s = sigmas.shape[0]
+    if coords.shape[0] != s or colors.shape[0] != s:
+        raise RuntimeError("sigmas, coords, colors disagree on the number of Gaussians")
+    if dmax is not None and not (float(dmax) >= 0.0):
+        raise RuntimeError("dmax must be >= 0")
+    d = make_dims(s, h, w, dmax, rows, cutoff, flags)
+    L = lib()
+    nbytes = L.gsasr_splat_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        check(-1, "gsasr_splat_workspace_bytes")
+    dev = sigmas.device
+    with torch.cuda.device(dev):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(L.gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), ws.data_ptr(), nbytes, _stream(dev)),
+              "gsasr_splat_plan")
+    return Plan(d, ws, dev)
+
+
+def forward(p: Plan, img: torch.Tensor) -> torch.Tensor:
+    pi = _chk(img, "rendered_img", (p.dims.w, 3))
+    if img.shape[0] != p.dims.row1 - p.dims.row0 or img.device != p.device:
+        raise RuntimeError("rendered_img does not match the plan (rows / device)")
+    with torch.cuda.device(p.device):
+        check(lib().gsasr_splat_forward(ctypes.byref(p.dims), p.workspace.data_ptr(), p.workspace.numel(), pi,
+                                        _stream(p.device)), "gsasr_splat_forward")
+    return img
+
+
+def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors) -> None:
+    ptrs = [_chk(sigmas, "sigmas", (3,)), _chk(coords, "coords", (2,)), _chk(colors, "colors", (3,)),
+            _chk(grad_img, "grads", (p.dims.w, 3)), _chk(g_sigmas, "grads_sigmas", (3,)),
+            _chk(g_coords, "grads_coords", (2,)), _chk(g_colors, "grads_colors", (3,))]
+    if grad_img.shape[0] != p.dims.row1 - p.dims.row0:
+        raise RuntimeError("grads does not match the plan's row band")
+    with torch.cuda.device(p.device):
+        check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(p.dims), p.workspace.data_ptr(),
+                                         p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
+
+
+def set_default_cutoff(tau: float) -> None:
+    """tau > 0: skip exponent < -tau; tau < 0: never skip; 0 restores the library default (32)."""
+    lib().gsasr_set_default_cutoff(float(tau))
+
+
+def get_default_cutoff() -> float:
+    return float(lib().gsasr_get_default_cutoff())

@@ -1,0 +1,204 @@
+"""Rasterizer host API -- mirror of the reference's utils/gaussian_splatting.py (same function names,
+arguments, defaults and error behaviour), with the CUDA ops replaced by the HIP rasterizer.
+
+    generate_2D_gaussian_splatting_step(sr_size, gs_parameters, scale, scale_modify, sample_coords=None,
+        default_step_size=1.2, cuda_rendering=True, mode='scale_modify', if_dmax=True,
+        dmax_mode='fix', dmax=25) -> [3,H,W]                      (reference :158-217)
+    generate_2D_gaussian_splatting_step_buffer(..., buffer_size=4000000)   (reference :219-265)
+    rendering_cuda / rendering_cuda_dmax / rendering_cuda_buffer / rendering_cuda_dmax_buffer
+                                                                  (reference :86-155)
+    rendering_python                                               (reference :11-84)
+
+`gs_parameters[N,9]` columns are the decoder's raw `[sigma_x, sigma_y, rho, alpha, r, g, b, mu_x, mu_y]`
+(reference utils/fea2gs.py:632-635).  Everything here is ordinary differentiable torch code on the
+tensors' own device; the only custom op is `GSCUDA.apply` (gsasr_amd/gs_cuda*/gswrapper.py).
+`cuda_rendering=False` selects the reference's pure-PyTorch *approximation* (`rendering_python`); it
+is part of the API surface and is never used as a fallback for the HIP path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _hw(sr_size):
+    # sr_size arrives as list, CPU tensor or GPU int tensor (gsasr_model.py:148,202); make ints once
+    return int(sr_size[0]), int(sr_size[1])
+
+
+def _to_kernel_frame(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size):
+    """sigmas/coords in the kernels' align-corners frame (reference :121-124): note the x/y swap -- the
+    network's sigma_x is the ROW std, the kernel's first sigma pairs with WIDTH."""
+    H, W = _hw(sr_size)
+    sigmas = torch.cat([sigma_y / step_size * 2 / (W - 1), sigma_x / step_size * 2 / (H - 1), rho],
+                       dim=-1).contiguous()
+    cx = (coords[:, 0:1] + 1 - 1 / W) * W / (W - 1) - 1.0
+    cy = (coords[:, 1:2] + 1 - 1 / H) * H / (H - 1) - 1.0
+    return sigmas, torch.cat([cx, cy], dim=-1).contiguous(), colours_with_alpha.contiguous(), H, W
+
+
+def rendering_cuda(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device):
+    from .gs_cuda.gswrapper import GSCUDA
+    sigmas, xy, col, H, W = _to_kernel_frame(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size)
+    rendered_img = torch.zeros(H, W, 3, device=device, dtype=torch.float32)
+    final_image = GSCUDA.apply(sigmas, xy, col, rendered_img)
+    return final_image.permute(2, 0, 1).contiguous()
+
+
+def rendering_cuda_dmax(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device, dmax=1):
+    from .gs_cuda_dmax.gswrapper import GSCUDA
+    sigmas, xy, col, H, W = _to_kernel_frame(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size)
+    rendered_img = torch.zeros(H, W, 3, device=device, dtype=torch.float32)
+    final_image = GSCUDA.apply(sigmas, xy, col, rendered_img, dmax)
+    return final_image.permute(2, 0, 1).contiguous()
+
+
+def _chunks(n, buffer_size):
+    # the reference runs len//buffer_size + 1 slices, the last possibly empty (:146-151)
+    for k in range(n // buffer_size + 1):
+        yield k * buffer_size, (k + 1) * buffer_size
+
+
+def rendering_cuda_buffer(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device,
+                          buffer_size=1000000):
+    from .gs_cuda.gswrapper import GSCUDA
+    sigmas, xy, col, H, W = _to_kernel_frame(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size)
+    final_image = torch.zeros(H, W, 3, device=device, dtype=torch.float32)
+    for a, b in _chunks(len(sigma_x), buffer_size):
+        if sigmas[a:b].shape[0] == 0:
+            continue
+        final_image = GSCUDA.apply(sigmas[a:b], xy[a:b], col[a:b], final_image)  # kernels accumulate (+=)
+    return final_image.permute(2, 0, 1).contiguous()
+
+
+def rendering_cuda_dmax_buffer(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device,
+                               dmax=1, buffer_size=1000000):
+    from .gs_cuda_dmax.gswrapper import GSCUDA
+    sigmas, xy, col, H, W = _to_kernel_frame(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size)
+    final_image = torch.zeros(H, W, 3, device=device, dtype=torch.float32)
+    for a, b in _chunks(len(sigma_x), buffer_size):
+        if sigmas[a:b].shape[0] == 0:
+            continue
+        final_image = GSCUDA.apply(sigmas[a:b], xy[a:b], col[a:b], final_image, dmax)
+    return final_image.permute(2, 0, 1).contiguous()
+
+
+def rendering_python(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device):
+    """The reference's `cuda_rendering=False` path (:11-84): every Gaussian is sampled on a
+    `num_step x num_step` grid in sigma units, normalised by its sampled peak (+1e-4) and bilinearly
+    resampled onto the HR grid centred at its mean.  An approximation of the kernels, kept for API
+    completeness (BASELINE.json config 1); plain torch ops on `device`."""
+    H, W = _hw(sr_size)
+    step = float(step_size)
+    n = sigma_x.shape[0]
+    cxy = rho * sigma_x * sigma_y
+    if ((sigma_x ** 2) * (sigma_y ** 2) - cxy ** 2 < 0).any():
+        raise ValueError("Covariance matrix must be positive semi-definite")
+    cov = torch.stack([torch.cat([sigma_x ** 2, cxy], -1), torch.cat([cxy, sigma_y ** 2], -1)], dim=-2)
+    inv = torch.inverse(cov)
+    num_step = int(10 * 2 / step)
+    ax = torch.tensor([k * step for k in range(num_step)], device=device)
+    ax = ax - ax.mean()
+    xy = torch.stack([ax[:, None].expand(num_step, num_step), ax[None, :].expand(num_step, num_step)], dim=-1)
+    final_image = torch.zeros((3, H, W), device=device)
+    max_buffer = 2000
+    for s0 in range(0, n, max_buffer):
+        s1 = min(s0 + max_buffer, n)
+        b = s1 - s0
+        z = torch.einsum("xyi,bij,xyj->bxy", xy, -0.5 * inv[s0:s1], xy)
+        kernel = torch.exp(z) / (2 * math.pi * torch.sqrt(torch.det(cov[s0:s1])).view(b, 1, 1))
+        kernel = kernel / (kernel.amax(dim=(-1, -2), keepdim=True) + 1e-4)
+        kernel = kernel[:, None].expand(b, 3, num_step, num_step)
+        theta = torch.zeros(b, 2, 3, dtype=torch.float32, device=device)
+        theta[:, 0, 0] = W / num_step
+        theta[:, 1, 1] = H / num_step
+        theta[:, 0, 2] = -coords[s0:s1, 0] * W / num_step
+        theta[:, 1, 2] = -coords[s0:s1, 1] * H / num_step
+        grid = F.affine_grid(theta, size=(b, 3, H, W), align_corners=False)
+        moved = F.grid_sample(kernel, grid, align_corners=False)
+        final_image = final_image + (colours_with_alpha[s0:s1, :, None, None] * moved).sum(0)
+    return final_image
+
+
+def _step_size(scale, scale_modify, default_step_size, mode):
+    if mode == 'scale':
+        final_scale = scale
+    elif mode == 'scale_modify':
+        assert scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify}"
+        final_scale = scale_modify[0]
+    else:  # the reference leaves final_scale unbound here (UnboundLocalError, a NameError subclass)
+        raise UnboundLocalError(f"mode-{mode} must be scale or scale_modify")
+    return default_step_size / final_scale
+
+
+def _activate(gs_parameters):
+    # reference :174-180
+    sigma_x = 0.99999 * torch.sigmoid(gs_parameters[:, 0:1]) + 1e-6
+    sigma_y = 0.99999 * torch.sigmoid(gs_parameters[:, 1:2]) + 1e-6
+    rho = 0.999999 * torch.tanh(gs_parameters[:, 2:3])
+    alpha = torch.sigmoid(gs_parameters[:, 3:4])
+    colours = torch.sigmoid(gs_parameters[:, 4:7])
+    coords = gs_parameters[:, 7:9] * 2 - 1
+    return sigma_x, sigma_y, rho, coords, colours * alpha
+
+
+def _resolve_dmax(dmax, dmax_mode, sr_size):
+    if dmax_mode == 'dynamic':
+        H, W = _hw(sr_size)
+        return (dmax + 2) / min(H, W)
+    if dmax_mode == 'fix':
+        return dmax
+    raise ValueError(f"dmax_mode-{dmax_mode} must be fix or dynamic")
+
+
+def _sample(final_image, sample_coords):
+    if sample_coords is None:
+        return final_image
+    return torch.stack([final_image[:, c[0], c[1]] for c in sample_coords], dim=1)
+
+
+def generate_2D_gaussian_splatting_step(sr_size, gs_parameters, scale, scale_modify, sample_coords=None,
+                                        default_step_size=1.2, cuda_rendering=True, mode='scale_modify',
+                                        if_dmax=True, dmax_mode='fix', dmax=25):
+    step_size = _step_size(scale, scale_modify, default_step_size, mode)
+    if gs_parameters.dtype != torch.float32:
+        # under bf16 autocast the decoder happens to emit fp32; make that explicit
+        gs_parameters = gs_parameters.float()
+    sigma_x, sigma_y, rho, coords, colours_with_alpha = _activate(gs_parameters)
+    dev = sigma_x.device
+    if cuda_rendering:
+        if if_dmax:
+            dmax = _resolve_dmax(dmax, dmax_mode, sr_size)
+            final_image = rendering_cuda_dmax(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size,
+                                              step_size, dmax=dmax, device=dev)
+        else:
+            final_image = rendering_cuda(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size,
+                                         device=dev)
+    else:
+        final_image = rendering_python(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size,
+                                       device=dev)
+    return _sample(final_image, sample_coords)
+
+
+def generate_2D_gaussian_splatting_step_buffer(sr_size, gs_parameters, scale, scale_modify, sample_coords=None,
+                                               default_step_size=1.2, cuda_rendering=True, mode='scale_modify',
+                                               if_dmax=True, dmax_mode='fix', dmax=25, buffer_size=4000000):
+    step_size = _step_size(scale, scale_modify, default_step_size, mode)
+    if gs_parameters.dtype != torch.float32:
+        gs_parameters = gs_parameters.float()
+    sigma_x, sigma_y, rho, coords, colours_with_alpha = _activate(gs_parameters)
+    dev = sigma_x.device
+    if cuda_rendering:
+        if if_dmax:
+            dmax = _resolve_dmax(dmax, dmax_mode, sr_size)
+            final_image = rendering_cuda_dmax_buffer(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size,
+                                                     step_size, dmax=dmax, device=dev, buffer_size=buffer_size)
+        else:
+            final_image = rendering_cuda_buffer(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size,
+                                                step_size, device=dev, buffer_size=buffer_size)
+    else:
+        final_image = rendering_python(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size,
+                                       device=dev)
+    return _sample(final_image, sample_coords)

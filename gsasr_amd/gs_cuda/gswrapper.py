@@ -1,0 +1,51 @@
+"""Mirror of the reference's utils/gs_cuda/gswrapper.py (unbounded op): same names, same signatures.
+
+    GSCUDA.apply(sigmas[N,3], coords[N,2], colors[N,3], rendered_img[H,W,3]) -> rendered_img
+    gaussiansplatting_render(sigmas, coords, colors, image_size) -> [H,W,3]
+
+Differences from the reference are internal only: the kernels are the HIP ones behind
+libgsasr_splat.so, launched on the current stream, and the binning plan built in forward is kept on
+`ctx` so backward does not re-bin.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _cabi
+
+
+class GSCUDA(Function):
+    """reference: utils/gs_cuda/gswrapper.py:19-39"""
+
+    @staticmethod
+    def forward(ctx, sigmas, coords, colors, rendered_img):
+        ctx.save_for_backward(sigmas, coords, colors)
+        h, w, c = rendered_img.shape
+        if c != 3:
+            raise RuntimeError("rendered_img must be [H,W,3]")
+        plan = _cabi.plan(sigmas, coords, colors, h, w, None)
+        _cabi.forward(plan, rendered_img)
+        ctx.plan = plan
+        return rendered_img
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        sigmas, coords, colors = ctx.saved_tensors
+        grads_sigmas = torch.zeros_like(sigmas)
+        grads_coords = torch.zeros_like(coords)
+        grads_colors = torch.zeros_like(colors)
+        _cabi.backward(ctx.plan, sigmas, coords, colors, grad_output.contiguous(), grads_sigmas, grads_coords,
+                       grads_colors)
+        return (grads_sigmas, grads_coords, grads_colors, None)
+
+
+def gaussiansplatting_render(sigmas, coords, colors, image_size):
+    """reference: utils/gs_cuda/gswrapper.py:41-48"""
+    sigmas = sigmas.contiguous()  # (gs num, 3)
+    coords = coords.contiguous()  # (gs num, 2)
+    colors = colors.contiguous()  # (gs num, c)
+    h, w = image_size[:2]
+    c = colors.shape[-1]
+    rendered_img = torch.zeros(int(h), int(w), c, device=colors.device, dtype=torch.float32)
+    return GSCUDA.apply(sigmas, coords, colors, rendered_img)

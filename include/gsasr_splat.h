@@ -1,0 +1,116 @@
+/*
+ * gsasr_splat.h -- C ABI of the MI355X-native 2D Gaussian-splatting rasterizer (libgsasr_splat.so).
+ *
+ * This is the drop-in boundary for GSASR's rasterizer path.  Every entry point takes plain device
+ * pointers, sizes and a HIP stream; there are no torch types.  What each one replaces in the
+ * reference (paths relative to the reference tree):
+ *
+ *   gsasr_gs_render            <- _gs_render            utils/gs_cuda/gs.h:1-10       (gs.cu:64-79)
+ *   gsasr_gs_render_backward   <- _gs_render_backward   utils/gs_cuda/gs.h:12-24      (gs.cu:180-198)
+ *   gsasr_gs_render_dmax       <- _gs_render            utils/gs_cuda_dmax/gs.h:1-11  (gs.cu:67-83)
+ *   gsasr_gs_render_backward_dmax <- _gs_render_backward utils/gs_cuda_dmax/gs.h:13-26 (gs.cu:167-186)
+ *
+ * i.e. exactly what utils/gs_cuda{,_dmax}/gswrapper.cpp:9-71 binds through pybind11 (`gs_render`,
+ * `gs_render_backward`).  The four functions keep the reference argument order and meaning
+ * (fp32, contiguous, `rendered_img` accumulated into, dmax-backward `+=` into caller-zeroed
+ * outputs, unbounded backward overwrites) and add: the stream to launch on (the reference uses the
+ * null stream) and an int status instead of void.
+ *
+ * The plan API below them is what the PyTorch host code actually uses: it exposes the binning
+ * workspace so that forward and backward of one autograd node share it, and the [row0,row1) row
+ * band for the multi-GPU HR-tile shard.  INTEGRATION.md shows the reference-side
+ * binding.
+ *
+ * Conventions: all pointers are device pointers valid on the current HIP device; `stream` is a
+ * hipStream_t passed as void* (NULL = default stream); calls only enqueue work (no host sync);
+ * return 0 on success or a negative gsasr_status / positive hipError_t, with a thread-local message
+ * available from gsasr_last_error().  c must be 3 (the reference forward hard-codes stride 3,
+ * gs_cuda/gs.cu:58, gs_cuda_dmax/gs.cu:29-31).  h, w >= 2 (the grid is 2*i/(n-1)-1).
+ */
+#ifndef GSASR_SPLAT_H
+#define GSASR_SPLAT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSASR_SPLAT_ABI_VERSION 1
+
+enum gsasr_status {
+    GSASR_OK = 0,
+    GSASR_ERR_ARG = -1,        /* bad dims / null pointer / c != 3 */
+    GSASR_ERR_WORKSPACE = -2,  /* workspace too small or misaligned */
+    GSASR_ERR_PLAN = -3        /* workspace does not hold a plan for these dims */
+};
+
+/* flags */
+#define GSASR_FLAG_DETERMINISTIC 1u /* bin in Gaussian-index order: bit-reproducible sums */
+
+typedef struct gsasr_dims {
+    int s;        /* number of Gaussians                                              */
+    int h, w;     /* FULL HR grid (pixel centres at 2*i/(n-1)-1, gs.cu:27-28)          */
+    int c;        /* channels, must be 3                                              */
+    float dmax;   /* < 0: unbounded (gs_cuda);  >= 0: |dx|,|dy| <= dmax box (gs_cuda_dmax) */
+    int row0, row1; /* HR rows [row0,row1) owned by this call; 0,h for a single GPU   */
+    float cutoff; /* support cutoff tau: a Gaussian is skipped for an 8x8 pixel tile when its
+                     exponent is < -tau everywhere on it (|d| > sigma*sqrt(2 tau)).
+                     0 -> library default (GSASR_SPLAT_DEFAULT_CUTOFF); < 0 -> never skip
+                     (every in-box term is summed, as the reference does).                */
+    unsigned flags;
+} gsasr_dims;
+
+/* Default tau = 32: every skipped term is < exp(-32) = 1.3e-14 times its colour (<= 1), so even
+ * 10^6 skipped terms on one pixel add up to < 1.3e-8 -- four orders below the 1e-4 parity tolerance
+ * and below one fp32 ulp of an O(1) pixel.  tau = 104 (GSASR_SPLAT_EXACT_CUTOFF) skips only terms for
+ * which fp32 expf() in the reference returns exactly +0 (exp(-104) < 2^-150), i.e. it sums the same
+ * set of non-zero terms as the reference; tau < 0 never skips. */
+#define GSASR_SPLAT_DEFAULT_CUTOFF 32.0f
+#define GSASR_SPLAT_EXACT_CUTOFF 104.0f
+
+int gsasr_abi_version(void);
+const char *gsasr_last_error(void);
+
+/* Bytes of scratch the plan needs for these dims (0 on bad dims). 256-byte aligned base required. */
+size_t gsasr_splat_workspace_bytes(const gsasr_dims *dims);
+
+/* Bin the Gaussians for [row0,row1) into `workspace` (classify -> scan -> scatter -> pack). */
+int gsasr_splat_plan(const float *sigmas /*[s,3]*/, const float *coords /*[s,2]*/,
+                     const float *colors /*[s,3]*/, const gsasr_dims *dims, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+/* img[row1-row0, w, 3] += splat.  `workspace` must hold the plan of the same inputs and dims. */
+int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes,
+                        float *img, void *stream);
+
+/* g_* += d(sum(grad_img*img))/d{sigmas,coords,colors} over rows [row0,row1).  Outputs must be
+ * zero-initialised by the caller when a plain gradient is wanted (the reference wrapper does
+ * torch.zeros_like, gs_cuda_dmax/gswrapper.py:40-42). */
+int gsasr_splat_backward(const float *sigmas, const float *coords, const float *colors,
+                         const float *grad_img /*[row1-row0, w, 3]*/, float *g_sigmas,
+                         float *g_coords, float *g_colors, const gsasr_dims *dims,
+                         const void *workspace, size_t workspace_bytes, void *stream);
+
+/* Reference-shaped launchers (allocate their scratch stream-ordered, plan, run, free). */
+int gsasr_gs_render(const float *sigmas, const float *coords, const float *colors,
+                    float *rendered_img, int s, int h, int w, int c, void *stream);
+int gsasr_gs_render_backward(const float *sigmas, const float *coords, const float *colors,
+                             const float *grads, float *grads_sigmas, float *grads_coords,
+                             float *grads_colors, int s, int h, int w, int c, void *stream);
+int gsasr_gs_render_dmax(const float *sigmas, const float *coords, const float *colors,
+                         float *rendered_img, int s, int h, int w, int c, float dmax, void *stream);
+int gsasr_gs_render_backward_dmax(const float *sigmas, const float *coords, const float *colors,
+                                  const float *grads, float *grads_sigmas, float *grads_coords,
+                                  float *grads_colors, int s, int h, int w, int c, float dmax,
+                                  void *stream);
+
+/* Process-wide default used when dims.cutoff == 0 (initially GSASR_SPLAT_DEFAULT_CUTOFF, or the
+ * value of the environment variable GSASR_SPLAT_CUTOFF if set). */
+void gsasr_set_default_cutoff(float tau);
+float gsasr_get_default_cutoff(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSASR_SPLAT_H */

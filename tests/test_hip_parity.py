@@ -1,0 +1,331 @@
+"""GPU parity: the HIP rasterizer (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (north_star): image within 1e-4 ABSOLUTE fp32 per pixel of the reference maths; gradients
+within 2e-4 of the tensor's max-abs (hard part 2: |d sigma| reaches 1e3, so gradient
+parity is relative).  The comparison target is the oracle's double-precision truth, which takes every
+box decision exactly as the kernels do (oracle/gs_ref.c).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RASTER = sorted(glob.glob(os.path.join(GOLDEN, "raster_*.npz")))
+IMG_ATOL = 1e-4
+GRAD_RTOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the MI355X box)"
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def _relmax(got, want):
+    return float(np.abs(got - want).max() / max(1e-12, np.abs(want).max()))
+
+
+def _render(sig, xy, col, h, w, dmax, dev, wgt=None, cutoff=None):
+    """forward (+ backward of sum(wgt*img)) through the autograd Functions; returns numpy arrays."""
+    from gsasr_amd import _cabi
+    from gsasr_amd.gs_cuda.gswrapper import GSCUDA as G0
+    from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA as G1
+    old = _cabi.get_default_cutoff()
+    if cutoff is not None:
+        _cabi.set_default_cutoff(cutoff)
+    try:
+        a, b, c = (_t(x, dev).requires_grad_(wgt is not None) for x in (sig, xy, col))
+        img0 = torch.zeros(h, w, 3, device=dev)
+        img = G0.apply(a, b, c, img0) if dmax is None else G1.apply(a, b, c, img0, dmax)
+        grads = None
+        if wgt is not None:
+            (img * _t(wgt, dev)).sum().backward()
+            grads = tuple(t.grad.cpu().numpy() for t in (a, b, c))
+        torch.cuda.synchronize()
+        return img.detach().cpu().numpy(), grads
+    finally:
+        _cabi.set_default_cutoff(old)
+
+
+def _check(sig, xy, col, h, w, dmax, dev, wgt, cutoff=None, img_atol=IMG_ATOL, grad_rtol=GRAD_RTOL):
+    from oracle import gs_oracle
+    img, grads = _render(sig, xy, col, h, w, dmax, dev, wgt, cutoff)
+    ref = gs_oracle.forward_f64(sig, xy, col, h, w, dmax)
+    assert np.isfinite(img).all()
+    err = np.abs(img - ref).max()
+    assert err <= img_atol, f"image max|err| {err:.3e}"
+    gref = gs_oracle.backward_f64(sig, xy, col, wgt, dmax)
+    for got, want, name in zip(grads, gref, ("sigmas", "coords", "colors")):
+        assert np.isfinite(got).all(), name
+        rel = _relmax(got, want)
+        assert rel <= grad_rtol, f"grad {name} rel err {rel:.3e}"
+    return err
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors captured from the reference's torch_version (tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cutoff", [None, 104.0, -1.0], ids=["tau32", "tau104", "nocut"])
+@pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[7:-4] for p in RASTER])
+def test_golden_forward_backward(path, cutoff, dev):
+    z = np.load(path)
+    dmax = None if float(z["dmax"]) < 0 else float(z["dmax"])
+    h, w = int(z["h"]), int(z["w"])
+    img, grads = _render(z["sigmas"], z["coords"], z["colors"], h, w, dmax, dev, z["weight"], cutoff)
+    # reference fp64-input run (image buffer fp32); sums of up to 40 O(1) terms
+    assert np.abs(img - z["img_f64"]).max() <= IMG_ATOL
+    for got, key in zip(grads, ("g_sigmas", "g_coords", "g_colors")):
+        # the reference's fp64 run keeps pixel coordinates in double, the kernels round them to float
+        # (gs.cu:27-28): 2e-5 of that is inherent, see tests/test_oracle.py
+        assert _relmax(got, z[key + "_f64"]) <= GRAD_RTOL, key
+    # and against the oracle truth, which shares the kernels' float pixel grid
+    _check(z["sigmas"], z["coords"], z["colors"], h, w, dmax, dev, z["weight"], cutoff)
+
+
+# ---------------------------------------------------------------------------------------------------
+# seeded GSASR-shaped inputs at oracle-friendly sizes
+# ---------------------------------------------------------------------------------------------------
+def _synth(h_lr, w_lr, scale, seed, gpp=1):
+    from gsasr_amd import synthetic
+    sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=seed, gpp=gpp)
+    wgt = synthetic.grad_image(H, W, seed + 1)
+    return sig.numpy(), xy.numpy(), col.numpy(), H, W, wgt.numpy()
+
+
+@pytest.mark.parametrize("cutoff", [None, 104.0, -1.0], ids=["tau32", "tau104", "nocut"])
+@pytest.mark.parametrize("dmax", [None, 0.5, 0.1], ids=["unbounded", "dmax0.5", "dmax0.1"])
+def test_synthetic_x4_256(dmax, cutoff, dev):
+    sig, xy, col, H, W, wgt = _synth(64, 64, 4.0, seed=10)
+    _check(sig, xy, col, H, W, dmax, dev, wgt, cutoff)
+
+
+@pytest.mark.parametrize("case", [(37, 29, 3.0, 1), (24, 40, 2.5, 1), (12, 12, 4.0, 16), (20, 16, 12.0, 1),
+                                  (31, 17, 6.5, 2)], ids=lambda c: "lr%dx%d_s%g_gpp%d" % c)
+def test_synthetic_ragged_sizes(case, dev):
+    """non-square, H/W not multiples of the 8-px sub-tile or 16-px cell, fractional scale, 16 Gaussians/px"""
+    h_lr, w_lr, scale, gpp = case
+    sig, xy, col, H, W, wgt = _synth(h_lr, w_lr, scale, seed=20, gpp=gpp)
+    for dmax in (None, 0.25):
+        _check(sig, xy, col, H, W, dmax, dev, wgt)
+
+
+def test_training_shape_c5(dev):
+    """BASELINE.json config 5 per-sample shape: 48x48 LR x4, 16 Gaussians / LR px, dmax 0.5"""
+    sig, xy, col, H, W, wgt = _synth(48, 48, 4.0, seed=30, gpp=16)
+    assert (H, W, sig.shape[0]) == (192, 192, 36864)
+    _check(sig, xy, col, H, W, 0.5, dev, wgt)
+
+
+def test_large_class_random_sigmas(dev):
+    """check.py-style inputs: sigma ~ U(0,1) in normalised units -> every Gaussian spans the image
+    (the 'large' class: brute-force forward, row-chunked atomically-combined backward)."""
+    rng = np.random.default_rng(5)
+    s, h, w = 300, 150, 170
+    sig = np.stack([rng.uniform(0.02, 1.0, s), rng.uniform(0.02, 1.0, s), rng.uniform(-0.95, 0.95, s)], 1)
+    xy, col = rng.uniform(-1.2, 1.2, (s, 2)), rng.uniform(0, 1, (s, 3))
+    wgt = rng.uniform(0, 1, (h, w, 3))
+    sig, xy, col, wgt = (a.astype(np.float32) for a in (sig, xy, col, wgt))
+    for dmax in (None, 0.6):
+        # pixel values reach ~1e2 here: allow the fp32 accumulation its relative share
+        _check(sig, xy, col, h, w, dmax, dev, wgt, img_atol=2e-4)
+
+
+def test_mixed_classes_and_degenerate_gaussians(dev):
+    """normal + large + dead (off-image) Gaussians in one call; tiny sigma; |rho| near the activation limit"""
+    sig, xy, col, H, W, wgt = _synth(32, 32, 4.0, seed=40)
+    sig, xy, col = sig.copy(), xy.copy(), col.copy()
+    sig[5, :2] = [0.8, 0.6]            # large
+    sig[77, :2] = [1.5, 0.01]          # large in x only
+    xy[9] = [3.0, -2.5]                # far outside, small -> dead
+    xy[10] = [-1.02, 0.3]              # just outside the left edge
+    sig[11, :2] = 2e-6                 # sigma at the activation floor (scaled)
+    xy[11] = [2 * 37 / (W - 1) - 1, 2 * 90 / (H - 1) - 1]   # ... sitting exactly on a pixel
+    sig[12, 2] = 0.999                 # rho near 1 (0.999999*tanh saturates around here for |p|>4)
+    sig[13, 2] = -0.9990234375
+    for dmax in (None, 0.2):
+        _check(sig, xy, col, H, W, dmax, dev, wgt, img_atol=2e-4, grad_rtol=5e-4)
+
+
+@pytest.mark.parametrize("hw", [(2, 2), (3, 5), (8, 8), (9, 17), (64, 7)])
+def test_tiny_images(hw, dev):
+    rng = np.random.default_rng(hw[0] * 100 + hw[1])
+    s = 7
+    sig = np.stack([rng.uniform(0.1, 0.8, s), rng.uniform(0.1, 0.8, s), rng.uniform(-0.8, 0.8, s)], 1).astype(np.float32)
+    xy, col = rng.uniform(-1, 1, (s, 2)).astype(np.float32), rng.uniform(0, 1, (s, 3)).astype(np.float32)
+    wgt = rng.uniform(0, 1, (*hw, 3)).astype(np.float32)
+    for dmax in (None, 0.7):
+        _check(sig, xy, col, hw[0], hw[1], dmax, dev, wgt)
+
+
+def test_empty_and_single(dev):
+    from gsasr_amd.gs_cuda_dmax.gswrapper import gaussiansplatting_render
+    z = torch.zeros(0, 3, device=dev)
+    img = gaussiansplatting_render(z, torch.zeros(0, 2, device=dev), z, (16, 24), 0.5)
+    assert img.shape == (16, 24, 3) and float(img.abs().max()) == 0.0
+    one = torch.tensor([[0.2, 0.1, 0.3]], device=dev)
+    img = gaussiansplatting_render(one, torch.tensor([[0.0, 0.0]], device=dev), torch.ones(1, 3, device=dev), (17, 17), 100)
+    assert abs(float(img[8, 8, 0]) - 1.0) < 1e-6      # centre pixel of an odd grid sits at (0,0): v = exp(0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# contracts of the boundary
+# ---------------------------------------------------------------------------------------------------
+def test_accumulate_into_and_buffer_variant(dev):
+    """`rendered_img` is in/out (+=): chunked callers chain GSCUDA.apply (utils/gaussian_splatting.py:146-151)"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    p = synthetic.gs_parameters(40, 40, seed=50).to(dev)
+    sm = torch.tensor([4.0, 4.0], device=dev)
+    full = gsp.generate_2D_gaussian_splatting_step((160, 160), p, 4.0, sm, dmax=0.3)
+    buf = gsp.generate_2D_gaussian_splatting_step_buffer((160, 160), p, 4.0, sm, dmax=0.3, buffer_size=300)
+    assert full.shape == (3, 160, 160)
+    assert float((full - buf).abs().max()) <= 1e-5
+    full_u = gsp.generate_2D_gaussian_splatting_step((160, 160), p, 4.0, sm, if_dmax=False)
+    buf_u = gsp.generate_2D_gaussian_splatting_step_buffer((160, 160), p, 4.0, sm, if_dmax=False, buffer_size=999)
+    assert float((full_u - buf_u).abs().max()) <= 1e-5
+    # pre-filled image is added to, not overwritten
+    from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA
+    sig, xy, col, H, W = synthetic.kernel_inputs(16, 16, 4.0, seed=51, device=dev)
+    base = torch.rand(H, W, 3, device=dev)
+    out = GSCUDA.apply(sig, xy, col, base.clone(), 0.5)
+    ref = GSCUDA.apply(sig, xy, col, torch.zeros(H, W, 3, device=dev), 0.5)
+    assert float((out - (base + ref)).abs().max()) <= 1e-5
+
+
+def test_host_api_end_to_end_matches_oracle(dev):
+    """generate_2D_gaussian_splatting_step on the GPU == oracle(prologue(gs_parameters)), with autograd to
+    the raw decoder parameters flowing through the HIP backward."""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    from oracle import gs_oracle, host_ref
+    p = synthetic.gs_parameters(24, 32, seed=60)
+    H, W = 96, 128
+    sm = torch.tensor([4.0, 4.0])
+    for kw, dm in ((dict(if_dmax=True, dmax_mode="fix", dmax=0.2), 0.2),
+                   (dict(if_dmax=True, dmax_mode="dynamic", dmax=25), None),
+                   (dict(if_dmax=False), None)):
+        pg = p.clone().to(dev).requires_grad_(True)
+        out = gsp.generate_2D_gaussian_splatting_step(torch.tensor([H, W], device=dev), pg, 4.0, sm.to(dev), **kw)
+        sig, xy, col, dmax = host_ref.prologue(p, (H, W), sm, dmax=kw.get("dmax", 25),
+                                               dmax_mode=kw.get("dmax_mode", "fix"))
+        if not kw["if_dmax"]:
+            dmax = None
+        ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax)
+        assert np.abs(out.detach().permute(1, 2, 0).cpu().numpy() - ref).max() <= IMG_ATOL
+        wgt = synthetic.grad_image(H, W, 61)
+        (out * wgt.permute(2, 0, 1).to(dev)).sum().backward()
+        # reference chain rule through the prologue, with the oracle's analytic backward in the middle
+        pr = p.clone().double().requires_grad_(True)
+        s2, x2, c2, _ = host_ref.prologue(pr, (H, W), sm.double(), dmax=kw.get("dmax", 25),
+                                          dmax_mode=kw.get("dmax_mode", "fix"))
+        g = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), dmax)
+        torch.autograd.backward([s2, x2, c2], [torch.from_numpy(a) for a in g])
+        assert _relmax(pg.grad.cpu().numpy(), pr.grad.numpy()) <= GRAD_RTOL
+
+
+def test_gscuda_module_reference_shaped_entry_points(dev):
+    """`gscuda.gs_render / gs_render_backward` (pybind surface, gswrapper.cpp:9-71): stateless launchers,
+    dmax backward adds into caller-zeroed outputs, unbounded backward overwrites."""
+    from gsasr_amd import gscuda, synthetic
+    from oracle import gs_oracle
+    sig, xy, col, H, W = synthetic.kernel_inputs(20, 20, 4.0, seed=70)
+    wgt = synthetic.grad_image(H, W, 71)
+    a, b, c, g = (t.to(dev) for t in (sig, xy, col, wgt))
+    n = a.shape[0]
+    for dmax in (0.3, None):
+        extra = () if dmax is None else (dmax,)
+        img = torch.zeros(H, W, 3, device=dev)
+        gscuda.gs_render(a, b, c, img, n, H, W, 3, *extra)
+        ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax)
+        assert np.abs(img.cpu().numpy() - ref).max() <= IMG_ATOL
+        fill = 0.0 if dmax is not None else 7.0   # unbounded variant must overwrite garbage
+        gs, gc, gk = (torch.full_like(t, fill) for t in (a, b, c))
+        gscuda.gs_render_backward(a, b, c, g, gs, gc, gk, n, H, W, 3, *extra)
+        want = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), dmax)
+        for got, w_ in zip((gs, gc, gk), want):
+            assert _relmax(got.cpu().numpy(), w_) <= GRAD_RTOL
+
+
+def test_errors_are_runtimeerrors(dev):
+    from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA
+    sig = torch.rand(8, 3, device=dev)
+    xy, col, img = torch.rand(8, 2, device=dev), torch.rand(8, 3, device=dev), torch.zeros(16, 16, 3, device=dev)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        GSCUDA.apply(torch.rand(3, 8, device=dev).t(), xy, col, img, 0.5)
+    with pytest.raises(RuntimeError, match="float32"):
+        GSCUDA.apply(sig.double(), xy, col, img, 0.5)
+    with pytest.raises(RuntimeError):
+        GSCUDA.apply(sig, xy[:4], col, img, 0.5)
+    with pytest.raises(RuntimeError):
+        GSCUDA.apply(sig, xy, col, torch.zeros(16, 16, 4, device=dev), 0.5)
+
+
+def test_row_band_slabs_partition_the_image_and_gradients(dev):
+    """the multi-GPU shard on one GPU: bands [r0,r1) reproduce the full render and their gradients add up"""
+    from gsasr_amd import synthetic
+    from gsasr_amd.shard import HipBackend, row_band
+    sig, xy, col, H, W = synthetic.kernel_inputs(32, 24, 4.0, seed=80, device=dev)
+    wgt = synthetic.grad_image(H, W, 81, device=dev)
+    full, st = HipBackend.forward(sig, xy, col, H, W, 0.3, (0, H))
+    gfull = HipBackend.backward(st, sig, xy, col, wgt)
+    for world in (2, 3, 8):
+        parts, gsum = [], None
+        for r in range(world):
+            rows = row_band(H, r, world)
+            slab, st = HipBackend.forward(sig, xy, col, H, W, 0.3, rows)
+            parts.append(slab)
+            g = HipBackend.backward(st, sig, xy, col, wgt[rows[0]:rows[1]].contiguous())
+            gsum = g if gsum is None else tuple(x + y for x, y in zip(gsum, g))
+        assert float((torch.cat(parts, 0) - full).abs().max()) <= 1e-5
+        for a, b in zip(gsum, gfull):
+            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties + one full-size oracle comparison
+# ---------------------------------------------------------------------------------------------------
+def test_config2_full_size_against_oracle_dmax0p1(dev):
+    """config 2: 256x256 LR -> x4 (1024^2), 65 536 Gaussians, fp32 fwd+bwd, per-pixel check (dmax 0.1)"""
+    sig, xy, col, H, W, wgt = _synth(256, 256, 4.0, seed=0)
+    assert (H, W, sig.shape[0]) == (1024, 1024, 65536)
+    _check(sig, xy, col, H, W, 0.1, dev, wgt)
+
+
+def test_config2_properties_all_variants(dev):
+    """linearity in colours, additivity over Gaussian subsets, and cutoff-independence at full size"""
+    from gsasr_amd import synthetic
+    from gsasr_amd.shard import HipBackend
+    sig, xy, col, H, W = synthetic.kernel_inputs(256, 256, 4.0, seed=0, device=dev)
+    for dmax in (None, 0.5, 0.1):
+        full, _ = HipBackend.forward(sig, xy, col, H, W, dmax, (0, H))
+        twice, _ = HipBackend.forward(sig, xy, 2 * col, H, W, dmax, (0, H))
+        assert float((twice - 2 * full).abs().max()) <= 1e-5
+        a, _ = HipBackend.forward(sig[:30000].contiguous(), xy[:30000].contiguous(), col[:30000].contiguous(), H, W, dmax, (0, H))
+        b, _ = HipBackend.forward(sig[30000:].contiguous(), xy[30000:].contiguous(), col[30000:].contiguous(), H, W, dmax, (0, H))
+        assert float((a + b - full).abs().max()) <= 2e-5
+    from gsasr_amd import _cabi
+    plan_exact = _cabi.plan(sig, xy, col, H, W, 0.1, cutoff=104.0)
+    exact = _cabi.forward(plan_exact, torch.zeros(H, W, 3, device=dev))
+    dflt, _ = HipBackend.forward(sig, xy, col, H, W, 0.1, (0, H))
+    assert float((exact - dflt).abs().max()) <= 1e-6     # tau=32 drops < 1.3e-14 per term
+
+
+def test_config3_inference_shape_properties(dev):
+    """config 3: 512x512 LR -> x12 (6144^2), dmax 0.1, forward only: band/chunk consistency + spot oracle"""
+    from gsasr_amd import synthetic
+    from gsasr_amd.shard import HipBackend
+    from oracle import gs_oracle
+    sig, xy, col, H, W = synthetic.kernel_inputs(512, 512, 12.0, seed=3, device=dev)
+    assert (H, W) == (6144, 6144)
+    full, _ = HipBackend.forward(sig, xy, col, H, W, 0.1, (0, H))
+    band, _ = HipBackend.forward(sig, xy, col, H, W, 0.1, (3000, 3100))
+    assert float((band - full[3000:3100]).abs().max()) <= 1e-5
+    ref = gs_oracle.forward_f64(sig.cpu().numpy(), xy.cpu().numpy(), col.cpu().numpy(), H, W, 0.1, rows=(3000, 3016))
+    assert np.abs(full[3000:3016].cpu().numpy() - ref).max() <= IMG_ATOL

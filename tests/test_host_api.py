@@ -1,0 +1,121 @@
+"""CPU tests of the host side: L2 prologue vs reference captures, C-ABI exports, error behaviour."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from gsasr_amd import _cabi, gaussian_splatting as gsp, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PROLOGUE = sorted(glob.glob(os.path.join(GOLDEN, "prologue_*.npz")))
+
+
+@pytest.mark.parametrize("path", PROLOGUE, ids=[os.path.basename(p)[9:-4] for p in PROLOGUE])
+def test_prologue_matches_reference_capture(path):
+    """gsasr_amd's activations + kernel-frame conversion == what the reference hands to GSCUDA.apply."""
+    z = np.load(path)
+    sc = float(z["scale"])
+    p = torch.from_numpy(z["gs_parameters"])
+    step = gsp._step_size(sc, torch.tensor([sc, sc]), 1.2, "scale_modify")
+    sx, sy, rho, xy, col = gsp._activate(p)
+    sig, coords, colors, H, W = gsp._to_kernel_frame(sx, sy, rho, xy, col, z["sr_size"].tolist(), step)
+    assert (H, W, 3) == tuple(z["img_shape"])
+    np.testing.assert_allclose(sig.numpy(), z["sigmas"], rtol=1e-6)
+    np.testing.assert_allclose(coords.numpy(), z["coords"], atol=1e-6)
+    np.testing.assert_allclose(colors.numpy(), z["colors"], rtol=1e-6)
+    if bool(z["if_dmax"]):
+        got = gsp._resolve_dmax(float(z["dmax_in"]), str(z["dmax_mode"]), z["sr_size"].tolist())
+        assert abs(got - float(z["dmax_out"])) < 1e-12
+
+
+def test_prologue_accepts_tensor_sr_size_and_bad_modes():
+    assert gsp._hw(torch.tensor([40, 52])) == (40, 52)
+    with pytest.raises(ValueError):
+        gsp._resolve_dmax(0.1, "bogus", (8, 8))
+    with pytest.raises(AssertionError):
+        gsp._step_size(4.0, torch.tensor([4.0, 3.0]), 1.2, "scale_modify")
+    assert gsp._step_size(3.0, None, 1.2, "scale") == pytest.approx(0.4)
+
+
+RP = sorted(glob.glob(os.path.join(GOLDEN, "rendering_python_n*.npz")))
+
+
+@pytest.mark.parametrize("path", RP, ids=[os.path.basename(p)[17:-4] for p in RP])
+def test_rendering_python_branch_matches_reference(path):
+    z = np.load(path)
+    sc = float(z["scale"])
+    out = gsp.generate_2D_gaussian_splatting_step(z["sr_size"].tolist(), torch.from_numpy(z["gs_parameters"]), sc,
+                                                  torch.tensor([sc, sc]), cuda_rendering=False)
+    np.testing.assert_allclose(out.numpy(), z["out"], rtol=1e-4, atol=2e-5)
+
+
+def test_sample_coords_gather():
+    z = np.load(RP[0])
+    sc = float(z["scale"])
+    pts = [(0, 0), (3, 7), (35, 43)]
+    out = gsp.generate_2D_gaussian_splatting_step(z["sr_size"].tolist(), torch.from_numpy(z["gs_parameters"]), sc,
+                                                  torch.tensor([sc, sc]), sample_coords=pts, cuda_rendering=False)
+    assert out.shape == (3, 3)
+    np.testing.assert_allclose(out[:, 1].numpy(), z["out"][:, 3, 7], rtol=1e-4, atol=2e-5)
+
+
+def test_cabi_exports_every_declared_symbol():
+    """The shared library loads on a CPU-only box and exports exactly what include/*.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "gsasr_splat.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gsasr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_cabi.EXPORTS), declared ^ set(_cabi.EXPORTS)
+    L = ctypes.CDLL(_cabi.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _cabi.lib().gsasr_abi_version() == 1
+
+
+def test_workspace_bytes_and_bad_dims_no_gpu():
+    d = _cabi.make_dims(65536, 1024, 1024, 0.1)
+    n = _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(d))
+    assert 65536 * 48 <= n <= 65536 * 80        # ~48 B/Gaussian of scratch + per-cell tables
+    bad = _cabi.make_dims(10, 1, 8, 0.1)        # h < 2: the grid 2*i/(h-1)-1 is undefined
+    assert _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(bad)) == 0
+    bad = _cabi.make_dims(10, 8, 8, 0.1, rows=(4, 2))
+    assert _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(bad)) == 0
+    assert abs(_cabi.get_default_cutoff() - 32.0) < 1e-6
+
+
+def test_tensor_checks_raise_runtimeerror_like_reference():
+    s = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="CUDA"):       # reference: CHECK_CUDA (gswrapper.cpp:5)
+        _cabi.plan(s, torch.zeros(4, 2), torch.zeros(4, 3), 8, 8, 0.1)
+    from gsasr_amd import gscuda
+    with pytest.raises(RuntimeError, match="CUDA"):
+        gscuda.gs_render(s, torch.zeros(4, 2), torch.zeros(4, 3), torch.zeros(8, 8, 3), 4, 8, 8, 3, 0.1)
+
+
+def test_synthetic_inputs_shape_and_determinism():
+    a = synthetic.kernel_inputs(16, 16, 4.0, seed=3)
+    b = synthetic.kernel_inputs(16, 16, 4.0, seed=3)
+    assert a[3:] == (64, 64) and a[0].shape == (256, 3)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    # means follow the LR raster: Gaussian k sits in LR pixel (k // 16, k % 16)
+    xy = (a[1] + 1) / 2 * 64
+    assert ((xy[:, 0] / 4).floor().clamp(0, 15).long() == torch.arange(256) % 16).float().mean() > 0.9
+
+
+def test_compat_install_registers_reference_module_names():
+    import sys
+    from gsasr_amd import compat
+    compat.install()
+    from utils.gs_cuda_dmax.gswrapper import GSCUDA as A  # noqa: E402
+    from basicsr.utils.gs_cuda.gswrapper import GSCUDA as B  # noqa: E402
+    import gscuda  # noqa: E402
+    from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA as A0
+    from gsasr_amd.gs_cuda.gswrapper import GSCUDA as B0
+    assert A is A0 and B is B0 and hasattr(gscuda, "gs_render") and hasattr(gscuda, "gs_render_backward")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "basicsr", "gscuda")]:
+        del sys.modules[k]
