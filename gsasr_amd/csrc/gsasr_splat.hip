@@ -7,15 +7,16 @@
 //
 // Pipeline (all on the caller's stream, no host sync):
 //   plan     k_classify  per Gaussian: pixel bounding box of (dmax box  ∩  sigma*sqrt(2 tau) support box),
-//                        class {normal -> 16x16-px cell of its centre | large | dead}, cell histogram,
+//                        class {normal -> 16x16-px cell of its centre | large | dead}, rank in its cell
+//                        (one returning atomic per wave and distinct cell),
 //                        max extent of the normal class; also the px/py pixel-coordinate tables
 //                        (double expression rounded to float, as gs.cu:27-28 does per pixel).
-//            k_scan      exclusive scan of the cell histogram (one workgroup).
-//            k_scatter   counting-sort scatter of Gaussian indices into cell order.
-//            k_pack      cell-ordered 32-byte records {x, y, A, B, C, r, g, b} (A,B,C = exponent
-//                        coefficients with log2(e) folded, computed in double) + 8-byte pixel bboxes.
-//   forward  k_render_fwd  PIXEL-stationary: one wave64 = one 8x8 pixel sub-tile, RGB accumulators in
-//                        registers.  The wave walks the cell rows within the class' max extent; 64
+//            k_scan      exclusive scan of the cell histogram + max-extent reduction (one workgroup).
+//            k_bin       counting-sort scatter into cell order fused with packing: 32-byte records
+//                        {x, y, A, B, C, r, g, b} (A,B,C = exponent coefficients with log2(e) folded,
+//                        computed in double), backward-epilogue constants, 8-byte pixel bboxes.
+//   forward  k_render_fwd  PIXEL-stationary: one wave64 = one 8x16 pixel sub-tile (2 px per lane, packed
+//                        fp32), RGB accumulators in registers.  The wave walks the cell rows within the class' max extent; 64
 //                        candidates are box-tested at once (one per lane, 8-byte bbox), the hit mask is
 //                        a ballot in SGPRs, and each hit's record is fetched with SCALAR loads (wave-
 //                        uniform data belongs in SGPRs on CDNA) -- no LDS, no atomics, one coalesced
@@ -41,7 +42,8 @@ namespace {
 
 constexpr int CELL = 16;        // binning cell side in pixels
 constexpr int CELL_SHIFT = 4;
-constexpr int SUB = 8;          // forward sub-tile side: 8x8 pixels = one wave64
+constexpr int SUBX = 8;         // forward sub-tile: 8 px wide x 16 px tall per wave64 (2 px per lane)
+constexpr int SUBY = 16;
 constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is binned as "large"
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y
@@ -58,20 +60,21 @@ struct Params {
 struct PlanView {
     unsigned *hdr;          // [HDR_WORDS]
     unsigned *cell_count;   // [ncells+2]   (ncells = "large" class, ncells+1 = "dead" class)
-    unsigned *cell_cursor;  // [ncells+2]
     unsigned *cell_start;   // [ncells+3]   exclusive scan of cell_count, last = s
     float *px, *py;         // [w], [h]
     unsigned *key;          // [s] class/cell of Gaussian i
-    unsigned *perm;         // [s] cell-ordered position -> Gaussian index
-    float4 *rec;            // [2*s]
-    short4 *bbox;           // [s]
+    unsigned *rank;         // [s] position of Gaussian i inside its cell
+    unsigned *blockmax;     // [2*nblk] per-classify-block max half-extents
+    float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
+    float4 *fin;            // [2*s] backward epilogue constants + original index
+    uint2 *bbox;            // [s] {c0 | test<<15 | c1<<16, r0 | r1<<16}
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-    size_t off_hdr, off_count, off_cursor, off_start, off_px, off_py, off_key, off_perm, off_rec, off_bbox;
-    size_t zero_bytes;  // header + count + cursor are zeroed by one memset at the start of plan
+    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_rec, off_fin, off_bbox;
+    size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
     size_t total;
     int ncx, ncy, ncells;
 };
@@ -80,6 +83,12 @@ bool dims_ok(const gsasr_dims *d)
 {
     return d && d->s >= 0 && d->h >= 2 && d->w >= 2 && d->h <= 32767 && d->w <= 32767 && d->c == 3 &&
            d->row0 >= 0 && d->row0 <= d->row1 && d->row1 <= d->h && !(d->dmax != d->dmax);
+}
+
+int classify_blocks(const gsasr_dims *d)
+{
+    const int n = d->s > d->w ? (d->s > d->h ? d->s : d->h) : (d->w > d->h ? d->w : d->h);
+    return (n + 255) / 256;
 }
 
 Layout make_layout(const gsasr_dims *d)
@@ -92,14 +101,15 @@ Layout make_layout(const gsasr_dims *d)
     size_t o = 0;
     L.off_hdr = o;    o += HDR_WORDS * 4;
     L.off_count = o;  o += align_up(ncls * 4, 256);
-    L.off_cursor = o; o += align_up(ncls * 4, 256);
     L.zero_bytes = o;
     L.off_start = o;  o += align_up((ncls + 1) * 4, 256);
     L.off_px = o;     o += align_up((size_t)d->w * 4, 256);
     L.off_py = o;     o += align_up((size_t)d->h * 4, 256);
     L.off_key = o;    o += align_up(s * 4, 256);
-    L.off_perm = o;   o += align_up(s * 4, 256);
+    L.off_rank = o;   o += align_up(s * 4, 256);
+    L.off_bmax = o;   o += align_up((size_t)classify_blocks(d) * 8, 256);
     L.off_rec = o;    o += align_up(s * 32, 256);
+    L.off_fin = o;    o += align_up(s * 32, 256);
     L.off_bbox = o;   o += align_up(s * 8, 256);
     L.total = o;
     return L;
@@ -111,14 +121,15 @@ PlanView make_view(const Layout &L, void *ws)
     PlanView V;
     V.hdr = (unsigned *)(b + L.off_hdr);
     V.cell_count = (unsigned *)(b + L.off_count);
-    V.cell_cursor = (unsigned *)(b + L.off_cursor);
     V.cell_start = (unsigned *)(b + L.off_start);
     V.px = (float *)(b + L.off_px);
     V.py = (float *)(b + L.off_py);
     V.key = (unsigned *)(b + L.off_key);
-    V.perm = (unsigned *)(b + L.off_perm);
+    V.rank = (unsigned *)(b + L.off_rank);
+    V.blockmax = (unsigned *)(b + L.off_bmax);
     V.rec = (float4 *)(b + L.off_rec);
-    V.bbox = (short4 *)(b + L.off_bbox);
+    V.fin = (float4 *)(b + L.off_fin);
+    V.bbox = (uint2 *)(b + L.off_bbox);
     return V;
 }
 
@@ -217,16 +228,17 @@ __device__ __forceinline__ float wave_sum(float v)
 __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restrict__ sigmas,
                                                   const float *__restrict__ coords, PlanView V)
 {
+    __shared__ unsigned s_rx[4], s_ry[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
     if (i < P.h) V.py[i] = (float)(2.0 * (double)i / (double)(P.h - 1) - 1.0);
-    unsigned rx = 0, ry = 0;
+    unsigned rx = 0, ry = 0, key = 0xffffffffu;
     if (i < P.s) {
         const float sx = sigmas[i * 3 + 0], sy = sigmas[i * 3 + 1];
         const float x = coords[i * 2 + 0], y = coords[i * 2 + 1];
         const Box b = gaussian_box(sx, sy, x, y, P);
-        unsigned key;
         if (b.cls == 2) {
             key = (unsigned)P.ncells + 1u;
         } else if (b.cls == 1) {
@@ -239,28 +251,65 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
             rx = (unsigned)ceilf(b.ex) + 2u;
             ry = (unsigned)ceilf(b.ey) + 2u;
         }
-        V.key[i] = key;
-        atomicAdd(&V.cell_count[key], 1u);
     }
+    // Rank of the Gaussian inside its cell, with ONE returning atomic per (wave, distinct key): decoder
+    // output is in raster order, so the 64 Gaussians of a wave fall into a handful of cells (often one,
+    // at 16 Gaussians per LR pixel) and per-lane atomics on the same word would serialise at ~10 ns each.
+    unsigned rank = 0;
+    unsigned long long todo = __ballot(key != 0xffffffffu);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long same = __ballot(key == k);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&V.cell_count[k], (unsigned)__builtin_popcountll(same));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+        if (key == k) rank = base + (unsigned)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (i < P.s) {
+        V.key[i] = key;
+        V.rank[i] = rank;
+    }
+    // per-block max half-extent of the normal class -> blockmax[] (reduced by k_scan; no contended atomics)
     rx = wave_max_u32(rx);
     ry = wave_max_u32(ry);
-    if ((threadIdx.x & 63) == 0) {
-        if (rx) atomicMax(&V.hdr[0], rx);
-        if (ry) atomicMax(&V.hdr[1], ry);
+    if (lane == 0) { s_rx[threadIdx.x >> 6] = rx; s_ry[threadIdx.x >> 6] = ry; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        V.blockmax[2 * blockIdx.x + 0] = max(max(s_rx[0], s_rx[1]), max(s_rx[2], s_rx[3]));
+        V.blockmax[2 * blockIdx.x + 1] = max(max(s_ry[0], s_ry[1]), max(s_ry[2], s_ry[3]));
     }
 }
 
 __global__ __launch_bounds__(1024) void k_scan(int n, const unsigned *__restrict__ count,
-                                               unsigned *__restrict__ start)
+                                               unsigned *__restrict__ start, int nblk,
+                                               const unsigned *__restrict__ blockmax, unsigned *__restrict__ hdr)
 {
     __shared__ unsigned part[1024];
+    __shared__ unsigned smax[2][16];
     const int t = threadIdx.x;
+    // (a) max half-extents over the classify blocks -> plan header
+    unsigned mx = 0, my = 0;
+    for (int k = t; k < nblk; k += 1024) {
+        mx = max(mx, blockmax[2 * k + 0]);
+        my = max(my, blockmax[2 * k + 1]);
+    }
+    mx = wave_max_u32(mx);
+    my = wave_max_u32(my);
+    if ((t & 63) == 0) { smax[0][t >> 6] = mx; smax[1][t >> 6] = my; }
+    // (b) exclusive scan of the per-cell counts
     const int per = (n + 1023) / 1024;
     const int b = t * per, e = min(n, b + per);
     unsigned sum = 0;
     for (int k = b; k < e; ++k) sum += count[k];
     part[t] = sum;
     __syncthreads();
+    if (t < 2) {
+        unsigned m = 0;
+        for (int k = 0; k < 16; ++k) m = max(m, smax[t][k]);
+        hdr[t] = m;
+    }
     for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partials
         unsigned v = t >= o ? part[t - o] : 0u;
         __syncthreads();
@@ -275,71 +324,105 @@ __global__ __launch_bounds__(1024) void k_scan(int n, const unsigned *__restrict
     if (t == 1023) start[n] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void k_scatter(Params P, PlanView V)
+// counting-sort placement (slot = cell start + rank, no atomics) fused with record packing
+__global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__ sigmas,
+                                             const float *__restrict__ coords,
+                                             const float *__restrict__ colors, PlanView V)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.s) return;
-    const unsigned key = V.key[i];
-    const unsigned pos = V.cell_start[key] + atomicAdd(&V.cell_cursor[key], 1u);
-    V.perm[pos] = (unsigned)i;
-}
-
-__global__ __launch_bounds__(256) void k_pack(Params P, const float *__restrict__ sigmas,
-                                              const float *__restrict__ coords,
-                                              const float *__restrict__ colors, PlanView V)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.s) return;
-    const unsigned i = V.perm[j];
+    const unsigned j = V.cell_start[V.key[i]] + V.rank[i];
     const float sx = sigmas[i * 3 + 0], sy = sigmas[i * 3 + 1], rho = sigmas[i * 3 + 2];
     const float x = coords[i * 2 + 0], y = coords[i * 2 + 1];
     const Box b = gaussian_box(sx, sy, x, y, P);
-    // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56)
+    // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56);
+    // everything per-Gaussian is evaluated ONCE here, in double, and rounded to float
     const double dr = rho, dsx = sx, dsy = sy;
-    const double w1 = -0.5 / (1.0 - dr * dr) * LOG2E;
-    const float A = (float)(w1 / (dsx * dsx));
-    const float B = (float)(-2.0 * dr * w1 / (dsx * dsy));
-    const float C = (float)(w1 / (dsy * dsy));
+    const double w1 = -0.5 / (1.0 - dr * dr);
+    const double w2 = 1.0 / (dsx * dsx), w3 = 1.0 / (dsx * dsy), w4 = 1.0 / (dsy * dsy);
+    const float A = (float)(w1 * LOG2E * w2);
+    const float B = (float)(-2.0 * dr * w1 * LOG2E * w3);
+    const float C = (float)(w1 * LOG2E * w4);
+    // record layout {x, y, A, B | r, g, b, C}: the (r,g) pair is 8-byte aligned for packed-fp32 operands
     V.rec[2 * j + 0] = make_float4(x, y, A, B);
-    V.rec[2 * j + 1] = make_float4(C, colors[i * 3 + 0], colors[i * 3 + 1], colors[i * 3 + 2]);
-    short4 bb;
-    if (b.cls == 2) { bb.x = 1; bb.y = 0; bb.z = 1; bb.w = 0; }
-    else { bb.x = (short)b.c0; bb.y = (short)b.c1; bb.z = (short)b.r0; bb.w = (short)b.r1; }
+    V.rec[2 * j + 1] = make_float4(colors[i * 3 + 0], colors[i * 3 + 1], colors[i * 3 + 2], C);
+    // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
+    V.fin[2 * j + 0] = make_float4((float)(2.0 * w1), (float)w2, (float)w3, (float)w4);
+    V.fin[2 * j + 1] = make_float4(rho, (float)(1.0 / dsx), (float)(1.0 / dsy), __uint_as_float((unsigned)i));
+    // does a pixel of a tile this Gaussian is binned to ever need the dmax test?  Not if its support box
+    // lies inside its dmax box: pixels beyond the support box carry < exp(-tau) whether tested or not.
+    const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
+    const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * sx * hx + 1.f <= P.dmax * hx &&
+                                           P.kcut * sy * hy + 1.f <= P.dmax * hy);
+    uint2 bb;
+    if (b.cls == 2) {
+        bb.x = 1u;  // c0 = 1 > c1 = 0: never hit
+        bb.y = 1u;
+    } else {
+        bb.x = (unsigned)b.c0 | (needs_test ? 0x8000u : 0u) | ((unsigned)b.c1 << 16);
+        bb.y = (unsigned)b.r0 | ((unsigned)b.r1 << 16);
+    }
     V.bbox[j] = bb;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// forward: one wave64 per 8x8 pixel sub-tile, four sub-tiles side by side per workgroup (32x8 px)
+// forward: one wave64 per 8-wide x 16-tall pixel sub-tile (lane = column X, rows Y and Y+8, so the
+// per-pair arithmetic is 2-wide packed fp32); four sub-tiles side by side per workgroup (32x16 px).
+// The kernel is bound by the CU's single scalar unit (hit-mask walk + record fetch are SALU/SMEM),
+// so the per-hit scalar sequence is kept to: ff1, shift, s_load(sbase+soffset), bit-clear, branch.
 // ---------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+
+template <bool TEST>
+__device__ __forceinline__ void fwd_hits(unsigned long long mask, const char *__restrict__ chunk, float px,
+                                         v2f py, float dmax, v2f &ar, v2f &ag, v2f &ab)
+{
+    while (mask) {
+        const unsigned k = (unsigned)__builtin_ctzll(mask);
+        mask &= ~(1ull << k);
+        // wave-uniform 32-byte record: one s_load_dwordx8 at (chunk + k*32)
+        const v8f r = *reinterpret_cast<const v8f *>(chunk + (k << 5));
+        const float dx = px - r[0];
+        const v2f dy = py - r[1];
+        const float adx = r[2] * dx, bdx = r[3] * dx;
+        const float adx2 = adx * dx;
+        const v2f t = r[7] * dy + bdx;
+        const v2f pw = dy * t + adx2;
+        v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+        if (TEST) {
+            const bool inx = fabsf(dx) <= dmax;
+            v.x = (inx && fabsf(dy.x) <= dmax) ? v.x : 0.f;
+            v.y = (inx && fabsf(dy.y) <= dmax) ? v.y : 0.f;
+        }
+        ar += v * r[4];
+        ag += v * r[5];
+        ab += v * r[6];
+    }
+}
+
 template <bool BOUNDED>
 __device__ __forceinline__ void fwd_segment(unsigned beg, unsigned end, int lane, int sx0, int sx1, int sy0,
-                                            int sy1, float px, float py, float dmax,
-                                            const float4 *__restrict__ rec, const short4 *__restrict__ bbox,
-                                            float &ar, float &ag, float &ab)
+                                            int sy1, float px, v2f py, float dmax,
+                                            const float4 *__restrict__ rec, const uint2 *__restrict__ bbox,
+                                            v2f &ar, v2f &ag, v2f &ab)
 {
     for (unsigned base = beg; base < end; base += 64) {
         const unsigned j = base + (unsigned)lane;
-        bool hit = false;
-        if (j < end) {  // one 8-byte load: {c0 | c1<<16, r0 | r1<<16} as signed 16-bit pixel indices
-            const uint2 bb = reinterpret_cast<const uint2 *>(bbox)[j];
-            const int c0 = (int)(short)(bb.x & 0xffffu), c1 = (int)bb.x >> 16;
-            const int r0 = (int)(short)(bb.y & 0xffffu), r1 = (int)bb.y >> 16;
+        bool hit = false, needs = false;
+        if (j < end) {  // one 8-byte load: {c0 | test<<15 | c1<<16, r0 | r1<<16}
+            const uint2 bb = bbox[j];
+            const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+            const int r0 = (int)(bb.y & 0xffffu), r1 = (int)(bb.y >> 16);
             hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
+            needs = (bb.x & 0x8000u) != 0u;
         }
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int k = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float4 *r = rec + 2 * (size_t)(base + (unsigned)k);
-            const float4 r0 = r[0], r1 = r[1];  // wave-uniform address -> s_load_dwordx8
-            const float dx = px - r0.x, dy = py - r0.y;
-            const float t = fmaf(r0.w, dy, r0.z * dx);
-            const float pw = fmaf(dx, t, r1.x * dy * dy);
-            float v = __builtin_amdgcn_exp2f(pw);
-            if (BOUNDED) v = (fabsf(dx) <= dmax && fabsf(dy) <= dmax) ? v : 0.f;
-            ar = fmaf(v, r1.y, ar);
-            ag = fmaf(v, r1.z, ag);
-            ab = fmaf(v, r1.w, ab);
+        const char *chunk = reinterpret_cast<const char *>(rec + 2 * (size_t)base);
+        if (BOUNDED) {
+            fwd_hits<false>(__ballot(hit && !needs), chunk, px, py, dmax, ar, ag, ab);
+            fwd_hits<true>(__ballot(hit && needs), chunk, px, py, dmax, ar, ag, ab);
+        } else {
+            fwd_hits<false>(__ballot(hit), chunk, px, py, dmax, ar, ag, ab);
         }
     }
 }
@@ -357,16 +440,16 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
     (void)tiles_y;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id is uniform: keep it in an SGPR
-    const int sx0 = (bx * 4 + wv) * SUB, sy0 = P.row0 + by * SUB;
+    const int sx0 = (bx * 4 + wv) * SUBX, sy0 = P.row0 + by * SUBY;
     if (sx0 >= P.w) return;  // wave-uniform
-    const int sx1 = min(sx0 + SUB - 1, P.w - 1), sy1 = min(sy0 + SUB - 1, P.row1 - 1);
-    const int X = sx0 + (lane & 7), Y = sy0 + (lane >> 3);
-    const bool live = X < P.w && Y < P.row1;
-    const float px = V.px[min(X, P.w - 1)], py = V.py[min(Y, P.h - 1)];
-    float ar = 0.f, ag = 0.f, ab = 0.f;
+    const int sx1 = min(sx0 + SUBX - 1, P.w - 1), sy1 = min(sy0 + SUBY - 1, P.row1 - 1);
+    const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
+    const float px = V.px[min(X, P.w - 1)];
+    const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y1, P.h - 1)]};
+    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
 
     const float4 *__restrict__ rec = V.rec;
-    const short4 *__restrict__ bbox = V.bbox;
+    const uint2 *__restrict__ bbox = V.bbox;
     const unsigned *__restrict__ cs = V.cell_start;
     // normal class: cells whose Gaussians can reach this sub-tile (max half-extent from the plan header)
     const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
@@ -381,119 +464,177 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
     // large class: every wave tests all of them
     fwd_segment<BOUNDED>(cs[P.ncells], cs[P.ncells + 1], lane, sx0, sx1, sy0, sy1, px, py, P.dmax, rec, bbox,
                          ar, ag, ab);
-    if (live) {
-        float *o = img + ((size_t)(Y - P.row0) * P.w + X) * 3;
-        o[0] += ar;
-        o[1] += ag;
-        o[2] += ab;
+    if (X < P.w) {
+        if (Y0 < P.row1) {
+            float *o = img + ((size_t)(Y0 - P.row0) * P.w + X) * 3;
+            o[0] += ar.x; o[1] += ag.x; o[2] += ab.x;
+        }
+        if (Y1 < P.row1) {
+            float *o = img + ((size_t)(Y1 - P.row0) * P.w + X) * 3;
+            o[0] += ar.y; o[1] += ag.y; o[2] += ab.y;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // backward: one wave64 per Gaussian (cell order, so neighbouring waves read neighbouring pixels)
 // ---------------------------------------------------------------------------------------------------
+// Sweep the pixel window [c0,c0+bw) x [r0,r1] of one Gaussian with a wave: lanes are laid LX = 16/32/64
+// wide (the narrowest that covers bw), 64/LX rows deep, and every lane handles TWO rows per trip so the
+// per-pixel arithmetic is 2-wide packed fp32 (v_pk_fma_f32 ...).  Accumulates the five moment sums
+// S{x,y,xx,xy,yy} = sum q*{dx,dy,dx^2,dx*dy,dy^2}, q = v * <grad, colour>, and the three colour sums.
+template <bool TEST>
+__device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int lane, const Params &P,
+                                          const float *__restrict__ pxt, const float *__restrict__ pyt,
+                                          const float *__restrict__ grad, float x, float y, float A, float B,
+                                          float C, float cr, float cg, float cb, v2f (&acc)[8])
+{
+    const int lxlog = bw <= 16 ? 4 : (bw <= 32 ? 5 : 6);
+    const int LX = 1 << lxlog, rpi = 64 >> lxlog;
+    const int col = lane & (LX - 1), rsub = lane >> lxlog;
+    const size_t rowpitch = (size_t)P.w * 3;
+    for (int strip = 0; strip < bw; strip += 64) {
+        const int cc = strip + col;
+        const int X = c0 + min(cc, bw - 1);
+        const float dx = pxt[X] - x;
+        const bool inx = cc < bw && (!TEST || fabsf(dx) <= P.dmax);
+        const float adx = A * dx;
+        // running pointers: one 64-bit add per trip instead of a 64-bit multiply per row
+        const ptrdiff_t half = (ptrdiff_t)rpi * (ptrdiff_t)rowpitch;
+        const float *ga = grad + (size_t)X * 3 + (size_t)(r0 + rsub - P.row0) * rowpitch;
+        const float *pa = pyt + (r0 + rsub);
+        for (int Y = r0 + rsub; Y <= r1; Y += 2 * rpi, ga += 2 * half, pa += 2 * rpi) {
+            const bool ok2 = Y + rpi <= r1;
+            const float *gb = ok2 ? ga + half : ga;  // second row of the pair (masked off past the window)
+            const v2f dy = {pa[0] - y, (ok2 ? pa[rpi] : pa[0]) - y};
+            const v2f g0 = {ga[0], gb[0]}, g1 = {ga[1], gb[1]}, g2 = {ga[2], gb[2]};
+            const v2f t = B * dy + adx;
+            const v2f pw = dx * t + (C * dy) * dy;
+            v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+            const bool in0 = inx && (!TEST || fabsf(dy.x) <= P.dmax);
+            const bool in1 = inx && ok2 && (!TEST || fabsf(dy.y) <= P.dmax);
+            v.x = in0 ? v.x : 0.f;
+            v.y = in1 ? v.y : 0.f;
+            const v2f gp = g2 * cb + (g1 * cg + g0 * cr);  // dL/dv summed over channels (gs.cu:150)
+            const v2f qv = gp * v, qdx = qv * dx, qdy = qv * dy;
+            acc[0] += qdx;
+            acc[1] += qdy;
+            acc[2] += qdx * dx;
+            acc[3] += qdx * dy;
+            acc[4] += qdy * dy;
+            acc[5] += v * g0;
+            acc[6] += v * g1;
+            acc[7] += v * g2;
+        }
+    }
+}
+
+// Sum eight per-lane values over the wave with 10 cross-lane exchanges instead of 48: at distances
+// 32/16/8 the lanes split the set of values between the two partners (4, 2, 1 exchanges), then three
+// plain butterfly steps.  Afterwards lane 8k holds the total of value k.
+__device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane)
+{
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+    float b[4], c[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = (h5 ? a[k + 4] : a[k]) + __shfl_xor(h5 ? a[k] : a[k + 4], 32);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) c[k] = (h4 ? b[k + 2] : b[k]) + __shfl_xor(h4 ? b[k] : b[k + 2], 16);
+    float d = (h3 ? c[1] : c[0]) + __shfl_xor(h3 ? c[0] : c[1], 8);
+    d += __shfl_xor(d, 4);
+    d += __shfl_xor(d, 2);
+    d += __shfl_xor(d, 1);
+    return d;
+}
+
 template <bool BOUNDED>
 __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int lane, const Params &P,
-                                         const PlanView &V, const float *__restrict__ sigmas,
-                                         const float *__restrict__ coords, const float *__restrict__ colors,
-                                         const float *__restrict__ grad, float *__restrict__ g_sigmas,
-                                         float *__restrict__ g_coords, float *__restrict__ g_colors)
+                                         const PlanView &V, const float *__restrict__ grad,
+                                         float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                         float *__restrict__ g_colors)
 {
-    const unsigned i = V.perm[j];
-    const float sx = sigmas[i * 3 + 0], sy = sigmas[i * 3 + 1], rho = sigmas[i * 3 + 2];
-    const float x = coords[i * 2 + 0], y = coords[i * 2 + 1];
-    const float cr = colors[i * 3 + 0], cg = colors[i * 3 + 1], cb = colors[i * 3 + 2];
-    const Box b = gaussian_box(sx, sy, x, y, P);
-    if (b.cls == 2) return;
-    int r0 = b.r0, r1 = b.r1;
+    const uint2 bb = V.bbox[j];  // wave-uniform: scalar loads
+    const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+    int r0 = (int)(bb.y & 0xffffu), r1 = (int)(bb.y >> 16);
+    if (c0 > c1) return;  // dead
     if (chunk >= 0) {
-        const int rpc = (b.r1 - b.r0 + NCH) / NCH;
-        r0 = b.r0 + chunk * rpc;
-        r1 = min(b.r1, r0 + rpc - 1);
+        const int rpc = (r1 - r0 + NCH) / NCH;
+        r0 = r0 + chunk * rpc;
+        r1 = min(r1, r0 + rpc - 1);
         if (r0 > r1) return;
     }
-    const double dr = rho, dsx = sx, dsy = sy;
-    const double w1d = -0.5 / (1.0 - dr * dr);
-    const double w2d = 1.0 / (dsx * dsx), w3d = 1.0 / (dsx * dsy), w4d = 1.0 / (dsy * dsy);
-    const float A = (float)(w1d * LOG2E * w2d), B = (float)(-2.0 * dr * w1d * LOG2E * w3d),
-                C = (float)(w1d * LOG2E * w4d);
-
-    const int bw = b.c1 - b.c0 + 1;
-    const int npx = bw * (r1 - r0 + 1);
-    const int kstep = 64 / bw, rstep = 64 % bw;
-    int row = lane / bw, col = lane % bw;
-    float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
-    const float *__restrict__ pxt = V.px;
-    const float *__restrict__ pyt = V.py;
-    for (int idx = lane; idx < npx; idx += 64) {
-        const int X = b.c0 + col, Y = r0 + row;
-        const float dx = pxt[X] - x, dy = pyt[Y] - y;
-        const float *g = grad + ((size_t)(Y - P.row0) * P.w + X) * 3;
-        const float g0 = g[0], g1 = g[1], g2 = g[2];
-        const float t = fmaf(B, dy, A * dx);
-        const float pw = fmaf(dx, t, C * dy * dy);
-        float v = __builtin_amdgcn_exp2f(pw);
-        if (BOUNDED) v = (fabsf(dx) <= P.dmax && fabsf(dy) <= P.dmax) ? v : 0.f;
-        const float gp = fmaf(g2, cb, fmaf(g1, cg, g0 * cr));  // dL/dv summed over channels (gs.cu:150)
-        const float qv = gp * v, qdx = qv * dx, qdy = qv * dy;
-        Sx += qdx;
-        Sy += qdy;
-        Sxx = fmaf(qdx, dx, Sxx);
-        Sxy = fmaf(qdx, dy, Sxy);
-        Syy = fmaf(qdy, dy, Syy);
-        Cr = fmaf(v, g0, Cr);
-        Cg = fmaf(v, g1, Cg);
-        Cb = fmaf(v, g2, Cb);
-        col += rstep;
-        row += kstep;
-        if (col >= bw) { col -= bw; ++row; }
-    }
-    Sx = wave_sum(Sx); Sy = wave_sum(Sy); Sxx = wave_sum(Sxx); Sxy = wave_sum(Sxy); Syy = wave_sum(Syy);
-    Cr = wave_sum(Cr); Cg = wave_sum(Cg); Cb = wave_sum(Cb);
+    const float4 ra = V.rec[2 * (size_t)j], rb = V.rec[2 * (size_t)j + 1];
+    const float x = ra.x, y = ra.y, A = ra.z, B = ra.w, cr = rb.x, cg = rb.y, cb = rb.z, C = rb.w;
+    v2f acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = (v2f){0.f, 0.f};
+    const int bw = c1 - c0 + 1;
+    if (BOUNDED && (bb.x & 0x8000u))
+        bwd_sweep<true>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, A, B, C, cr, cg, cb, acc);
+    else
+        bwd_sweep<false>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, A, B, C, cr, cg, cb, acc);
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = acc[k].x + acc[k].y;
+    const float d = wave_sum8(a, lane);
+    const float Sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0));
+    const float Sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 8));
+    const float Sxx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 16));
+    const float Sxy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 24));
+    const float Syy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 32));
+    const float Cr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 40));
+    const float Cg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 48));
+    const float Cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 56));
     if (lane == 0) {
         // the per-pixel partials of gs.cu:139-146 are linear in {q dx, q dy, q dx^2, q dx dy, q dy^2},
-        // so the Gaussian-constant factors are applied once, in double, to the five moment sums
-        const double rw3 = dr * w3d, two_w1 = 2.0 * w1d;
-        const double gx = two_w1 * (-w2d * Sx + rw3 * Sy);
-        const double gy = two_w1 * (-w4d * Sy + rw3 * Sx);
-        const double gsx = two_w1 / dsx * (rw3 * Sxy - w2d * Sxx);
-        const double gsy = two_w1 / dsy * (rw3 * Sxy - w4d * Syy);
-        const double qd = w2d * Sxx - 2.0 * rw3 * Sxy + w4d * Syy;
-        const double grho = -two_w1 * (two_w1 * dr * qd + w3d * Sxy);
+        // so the Gaussian-constant factors are applied once to the five moment sums
+        const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
+        const float two_w1 = fa.x, w2 = fa.y, w3 = fa.z, w4 = fa.w, rho = fb.x, isx = fb.y, isy = fb.z;
+        const unsigned i = __float_as_uint(fb.w);
+        const float rw3 = rho * w3;
+        const float gx = two_w1 * (rw3 * Sy - w2 * Sx);
+        const float gy = two_w1 * (rw3 * Sx - w4 * Sy);
+        const float gsx = two_w1 * isx * (rw3 * Sxy - w2 * Sxx);
+        const float gsy = two_w1 * isy * (rw3 * Sxy - w4 * Syy);
+        const float qd = w2 * Sxx - 2.f * rw3 * Sxy + w4 * Syy;
+        const float grho = -two_w1 * (two_w1 * rho * qd + w3 * Sxy);
         float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
         if (atomic) {
-            atomicAdd(os + 0, (float)gsx); atomicAdd(os + 1, (float)gsy); atomicAdd(os + 2, (float)grho);
-            atomicAdd(op + 0, (float)gx);  atomicAdd(op + 1, (float)gy);
+            atomicAdd(os + 0, gsx); atomicAdd(os + 1, gsy); atomicAdd(os + 2, grho);
+            atomicAdd(op + 0, gx);  atomicAdd(op + 1, gy);
             atomicAdd(oc + 0, Cr); atomicAdd(oc + 1, Cg); atomicAdd(oc + 2, Cb);
         } else {
-            os[0] += (float)gsx; os[1] += (float)gsy; os[2] += (float)grho;
-            op[0] += (float)gx;  op[1] += (float)gy;
+            os[0] += gsx; os[1] += gsy; os[2] += grho;
+            op[0] += gx;  op[1] += gy;
             oc[0] += Cr; oc[1] += Cg; oc[2] += Cb;
         }
     }
 }
 
 template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const float *__restrict__ sigmas,
-                                                    const float *__restrict__ coords,
-                                                    const float *__restrict__ colors,
-                                                    const float *__restrict__ grad, float *__restrict__ g_sigmas,
-                                                    float *__restrict__ g_coords, float *__restrict__ g_colors)
+__global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
+                                                    float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                                    float *__restrict__ g_colors)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned gw = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned nwaves = gridDim.x * 4u;
+    // XCD-aware order (block b runs on XCD b%8): each XCD sweeps a contiguous run of the cell-ordered
+    // Gaussians, i.e. one band of the image, so the grad_img rows it re-reads stay in ITS 4 MiB L2
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
+    const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
+    const unsigned gw = t * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned nwaves = nb * 4u;
     const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
     if (gw < large_beg)
-        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, sigmas, coords, colors, grad, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, g_sigmas, g_coords, g_colors);
     else if (gw < large_end)
-        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, sigmas, coords, colors, grad, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, g_sigmas, g_coords, g_colors);
     // remaining row chunks of the large class, spread over all waves
     const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
     for (unsigned it = gw; it < extra; it += nwaves) {
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
-        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, sigmas, coords, colors, grad, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, g_sigmas, g_coords, g_colors);
     }
 }
 
@@ -546,15 +687,12 @@ int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colo
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, workspace);
     HIP_TRY(hipMemsetAsync(workspace, 0, L.zero_bytes, st));
-    const int nthreads = dims->s > dims->w ? (dims->s > dims->h ? dims->s : dims->h)
-                                           : (dims->w > dims->h ? dims->w : dims->h);
-    hipLaunchKernelGGL(k_classify, dim3((nthreads + 255) / 256), dim3(256), 0, st, P, sigmas, coords, V);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, L.ncells + 2, V.cell_count, V.cell_start);
-    if (dims->s > 0) {
-        const int nb = (dims->s + 255) / 256;
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, P, V);
-        hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, P, sigmas, coords, colors, V);
-    }
+    const int nblk = classify_blocks(dims);
+    hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, L.ncells + 2, V.cell_count, V.cell_start, nblk,
+                       V.blockmax, V.hdr);
+    if (dims->s > 0)
+        hipLaunchKernelGGL(k_bin, dim3((dims->s + 255) / 256), dim3(256), 0, st, P, sigmas, coords, colors, V);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }
@@ -569,7 +707,7 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     if (!img) return fail(GSASR_ERR_ARG, "null image pointer");
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, const_cast<void *>(workspace));
-    const int tiles_x = (dims->w + 4 * SUB - 1) / (4 * SUB), tiles_y = (rows + SUB - 1) / SUB;
+    const int tiles_x = (dims->w + 4 * SUBX - 1) / (4 * SUBX), tiles_y = (rows + SUBY - 1) / SUBY;
     const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (P.bounded)
@@ -594,11 +732,9 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
     const dim3 grid((unsigned)((dims->s + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (P.bounded)
-        hipLaunchKernelGGL(k_render_bwd<true>, grid, block, 0, st, P, V, sigmas, coords, colors, grad_img,
-                           g_sigmas, g_coords, g_colors);
+        hipLaunchKernelGGL(k_render_bwd<true>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
     else
-        hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, sigmas, coords, colors, grad_img,
-                           g_sigmas, g_coords, g_colors);
+        hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }

@@ -1,0 +1,112 @@
+// tools/mb.hip -- standalone micro-benchmark of libgsasr_splat's kernels (development aid, not product).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Iinclude [-DVARIANT...] tools/mb.hip -o /tmp/mb
+//   /tmp/mb [lr_h lr_w scale dmax tau iters gpp]
+//
+// It #includes the library source so that -D switches can select kernel variants, generates
+// GSASR-shaped Gaussians (LR raster + jitter, sigmoid/tanh activations) with its own
+// RNG, and times plan / forward / backward with hipEvents on one stream.
+#include "../gsasr_amd/csrc/gsasr_splat.hip"
+
+#include <algorithm>
+#include <random>
+#include <vector>
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+
+template <class F>
+static float time_us(F &&f, int iters, hipStream_t st)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipStreamSynchronize(st));
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a, st));
+        f();
+        CK(hipEventRecord(b, st));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        ts.push_back(ms * 1e3f);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+int main(int argc, char **argv)
+{
+    int lrh = argc > 1 ? atoi(argv[1]) : 256, lrw = argc > 2 ? atoi(argv[2]) : 256;
+    float scale = argc > 3 ? atof(argv[3]) : 4.f, dmax = argc > 4 ? atof(argv[4]) : 0.1f;
+    float tau = argc > 5 ? atof(argv[5]) : 0.f;
+    int iters = argc > 6 ? atoi(argv[6]) : 30, gpp = argc > 7 ? atoi(argv[7]) : 1;
+    const int H = (int)lroundf(lrh * scale), W = (int)lroundf(lrw * scale), n = lrh * lrw * gpp;
+    std::mt19937 rng(0);
+    std::normal_distribution<float> nd(0.f, 0.5f);
+    std::uniform_real_distribution<float> ud(0.f, 1.f);
+    auto sigm = [](float v) { return 1.f / (1.f + expf(-v)); };
+    std::vector<float> sig(3 * (size_t)n), xy(2 * (size_t)n), col(3 * (size_t)n), grad((size_t)H * W * 3);
+    const float step = 1.2f / scale;
+    for (int k = 0; k < n; ++k) {
+        const int i = k / (lrw * gpp), j = (k / gpp) % lrw;
+        const float sx = 0.99999f * sigm(nd(rng)) + 1e-6f, sy = 0.99999f * sigm(nd(rng)) + 1e-6f;
+        sig[3 * k + 0] = sy / step * 2 / (W - 1);
+        sig[3 * k + 1] = sx / step * 2 / (H - 1);
+        sig[3 * k + 2] = 0.999999f * tanhf(nd(rng));
+        const float a = sigm(nd(rng));
+        for (int c = 0; c < 3; ++c) col[3 * k + c] = sigm(nd(rng)) * a;
+        const float mx = ((j + 0.5f + ud(rng) - 0.5f) / lrw) * 2 - 1, my = ((i + 0.5f + ud(rng) - 0.5f) / lrh) * 2 - 1;
+        xy[2 * k + 0] = (mx + 1 - 1.f / W) * W / (W - 1) - 1.f;
+        xy[2 * k + 1] = (my + 1 - 1.f / H) * H / (H - 1) - 1.f;
+    }
+    for (auto &g : grad) g = ud(rng);
+
+    gsasr_dims d{n, H, W, 3, dmax, 0, H, tau, 0u};
+    const size_t wsb = gsasr_splat_workspace_bytes(&d);
+    float *dsig, *dxy, *dcol, *dgrad, *dimg, *dgs, *dgc, *dgk;
+    void *ws;
+    CK(hipMalloc(&dsig, sig.size() * 4)); CK(hipMalloc(&dxy, xy.size() * 4)); CK(hipMalloc(&dcol, col.size() * 4));
+    CK(hipMalloc(&dgrad, grad.size() * 4)); CK(hipMalloc(&dimg, grad.size() * 4));
+    CK(hipMalloc(&dgs, sig.size() * 4)); CK(hipMalloc(&dgc, xy.size() * 4)); CK(hipMalloc(&dgk, col.size() * 4));
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMemcpy(dsig, sig.data(), sig.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dxy, xy.data(), xy.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dcol, col.data(), col.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dgrad, grad.data(), grad.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dimg, 0, grad.size() * 4));
+    CK(hipMemset(dgs, 0, sig.size() * 4)); CK(hipMemset(dgc, 0, xy.size() * 4)); CK(hipMemset(dgk, 0, col.size() * 4));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    auto chk = [](int rc, const char *w) { if (rc) { fprintf(stderr, "%s: %d %s\n", w, rc, gsasr_last_error()); exit(1); } };
+    chk(gsasr_splat_plan(dsig, dxy, dcol, &d, ws, wsb, st), "plan");
+    const float t_plan = time_us([&] { chk(gsasr_splat_plan(dsig, dxy, dcol, &d, ws, wsb, st), "plan"); }, iters, st);
+    const float t_fwd = time_us([&] { chk(gsasr_splat_forward(&d, ws, wsb, dimg, st), "fwd"); }, iters, st);
+    const float t_bwd = time_us([&] { chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d, ws, wsb, st), "bwd"); }, iters, st);
+    CK(hipStreamSynchronize(st));
+    // checksums so variants can be compared for (approximate) equality
+    std::vector<float> img(grad.size()), gs(sig.size());
+    CK(hipMemset(dimg, 0, grad.size() * 4)); CK(hipMemset(dgs, 0, sig.size() * 4));
+    CK(hipMemset(dgc, 0, xy.size() * 4)); CK(hipMemset(dgk, 0, col.size() * 4));
+    chk(gsasr_splat_forward(&d, ws, wsb, dimg, st), "fwd");
+    chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d, ws, wsb, st), "bwd");
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(img.data(), dimg, img.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gs.data(), dgs, gs.size() * 4, hipMemcpyDeviceToHost));
+    double si = 0, sg = 0;
+    for (float v : img) si += v;
+    for (float v : gs) sg += fabs(v);
+    unsigned hdr[4];
+    CK(hipMemcpy(hdr, ws, 16, hipMemcpyDeviceToHost));
+    printf("N=%d %dx%d dmax=%g tau=%g | plan %.1f us  fwd %.1f us  bwd %.1f us | sum(img)=%.6e sum|gs|=%.6e | rx=%u ry=%u\n", n, H, W,
+           dmax, tau, t_plan, t_fwd, t_bwd, si, sg, hdr[0], hdr[1]);
+    return 0;
+}
