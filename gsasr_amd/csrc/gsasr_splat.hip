@@ -256,16 +256,23 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     // output is in raster order, so the 64 Gaussians of a wave fall into a handful of cells (often one,
     // at 16 Gaussians per LR pixel) and per-lane atomics on the same word would serialise at ~10 ns each.
     unsigned rank = 0;
-    unsigned long long todo = __ballot(key != 0xffffffffu);
-    while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
-        const unsigned long long same = __ballot(key == k);
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&V.cell_count[k], (unsigned)__builtin_popcountll(same));
-        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-        if (key == k) rank = base + (unsigned)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
+    {
+        // match-any without atomics: every lane learns the lane-mask of its key's group ...
+        unsigned long long mine = 0ull, todo = __ballot(key != 0xffffffffu);
+        while (todo) {
+            const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(todo));
+            const unsigned long long same = __ballot(key == k);
+            if (key == k) mine = same;
+            todo &= ~same;
+        }
+        // ... then ALL group leaders issue their returning atomic in one instruction (one round trip)
+        if (mine) {
+            const int leader = __builtin_ctzll(mine);
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&V.cell_count[key], (unsigned)__builtin_popcountll(mine));
+            base = (unsigned)__shfl((int)base, leader);
+            rank = base + (unsigned)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
+        }
     }
     if (i < P.s) {
         V.key[i] = key;
@@ -479,53 +486,97 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
 // ---------------------------------------------------------------------------------------------------
 // backward: one wave64 per Gaussian (cell order, so neighbouring waves read neighbouring pixels)
 // ---------------------------------------------------------------------------------------------------
-// Sweep the pixel window [c0,c0+bw) x [r0,r1] of one Gaussian with a wave: lanes are laid LX = 16/32/64
-// wide (the narrowest that covers bw), 64/LX rows deep, and every lane handles TWO rows per trip so the
-// per-pixel arithmetic is 2-wide packed fp32 (v_pk_fma_f32 ...).  Accumulates the five moment sums
-// S{x,y,xx,xy,yy} = sum q*{dx,dy,dx^2,dx*dy,dy^2}, q = v * <grad, colour>, and the three colour sums.
-template <bool TEST>
+// Sweep the pixel window [c0,c0+bw) x [r0,r1] of one Gaussian with a wave.  Lanes are laid LX = 16/32/64
+// wide (the narrowest that covers bw, a template parameter so all the lane geometry is constant) and
+// 64/LX rows deep; a lane keeps ONE column (dx is a lane constant) and handles TWO rows per trip, so
+// the per-pixel arithmetic is 2-wide packed fp32.  Because dx is constant per lane only three
+// row-moments are accumulated per pixel,
+//     M0 = sum q,  M1 = sum q*dy,  M2 = sum q*dy^2,      q = v * <grad, colour>,
+// and expanded at the end of the column: Sx = dx*M0, Sxx = dx^2*M0, Sy = M1, Sxy = dx*M1, Syy = M2.
+// The py values of a 64-row block are staged in LDS (256 B per wave); full trips carry no masks or
+// address clamps, the ragged last trip is peeled.
+// acc[] = {Sx, Sy, Sxx, Sxy, Syy, Cr, Cg, Cb} (per lane, summed over the wave by the caller).
+struct BwdRow {
+    v2f m0, m1, m2, k01, k20, k12;  // moments; colour sums in the mixed pairing of two HWC pixels
+};
+
+template <bool TEST, bool TAIL>
+__device__ __forceinline__ void bwd_trip(BwdRow &R, const float *ga, const float *gb, v2f dy, bool ok1, bool ok2,
+                                         float adx2, float bdx, float C, float cr, float cg, float cb, float dmax)
+{
+    // six consecutive-in-memory floats per pixel pair are used as they land: no register shuffling
+    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
+    const v2f t = C * dy + bdx;
+    const v2f pw = dy * t + adx2;
+    v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+    if (TEST || TAIL) {
+        v.x = ((!TAIL || ok1) && (!TEST || fabsf(dy.x) <= dmax)) ? v.x : 0.f;
+        v.y = ((!TAIL || ok2) && (!TEST || fabsf(dy.y) <= dmax)) ? v.y : 0.f;
+    }
+    const v2f gp = {fmaf(a2, cb, fmaf(a1, cg, a0 * cr)), fmaf(b2, cb, fmaf(b1, cg, b0 * cr))};  // gs.cu:150
+    const v2f q = gp * v, qdy = q * dy;
+    R.m0 += q;
+    R.m1 += qdy;
+    R.m2 += qdy * dy;
+    R.k01 += (v2f){a0, a1} * v.x;
+    R.k20 += (v2f){a2, b0} * v;
+    R.k12 += (v2f){b1, b2} * v.y;
+}
+
+template <bool TEST, int LXLOG>
 __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int lane, const Params &P,
                                           const float *__restrict__ pxt, const float *__restrict__ pyt,
                                           const float *__restrict__ grad, float x, float y, float A, float B,
-                                          float C, float cr, float cg, float cb, v2f (&acc)[8])
+                                          float C, float cr, float cg, float cb, float *spy, float (&acc)[8])
 {
-    const int lxlog = bw <= 16 ? 4 : (bw <= 32 ? 5 : 6);
-    const int LX = 1 << lxlog, rpi = 64 >> lxlog;
-    const int col = lane & (LX - 1), rsub = lane >> lxlog;
+    constexpr int LX = 1 << LXLOG, RPI = 64 >> LXLOG;
+    const int col = lane & (LX - 1), rsub = lane >> LXLOG;
     const size_t rowpitch = (size_t)P.w * 3;
+    const ptrdiff_t half = (ptrdiff_t)RPI * (ptrdiff_t)rowpitch;
     for (int strip = 0; strip < bw; strip += 64) {
         const int cc = strip + col;
         const int X = c0 + min(cc, bw - 1);
         const float dx = pxt[X] - x;
+        // lanes outside the window (or, with TEST, outside the dmax box in x) are switched off by
+        // poisoning dx: the exponent becomes -inf, v = 0 exactly, and every product with it is 0
         const bool inx = cc < bw && (!TEST || fabsf(dx) <= P.dmax);
-        const float adx = A * dx;
-        // running pointers: one 64-bit add per trip instead of a 64-bit multiply per row
-        const ptrdiff_t half = (ptrdiff_t)rpi * (ptrdiff_t)rowpitch;
-        const float *ga = grad + (size_t)X * 3 + (size_t)(r0 + rsub - P.row0) * rowpitch;
-        const float *pa = pyt + (r0 + rsub);
-        for (int Y = r0 + rsub; Y <= r1; Y += 2 * rpi, ga += 2 * half, pa += 2 * rpi) {
-            const bool ok2 = Y + rpi <= r1;
-            const float *gb = ok2 ? ga + half : ga;  // second row of the pair (masked off past the window)
-            const v2f dy = {pa[0] - y, (ok2 ? pa[rpi] : pa[0]) - y};
-            const v2f g0 = {ga[0], gb[0]}, g1 = {ga[1], gb[1]}, g2 = {ga[2], gb[2]};
-            const v2f t = B * dy + adx;
-            const v2f pw = dx * t + (C * dy) * dy;
-            v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
-            const bool in0 = inx && (!TEST || fabsf(dy.x) <= P.dmax);
-            const bool in1 = inx && ok2 && (!TEST || fabsf(dy.y) <= P.dmax);
-            v.x = in0 ? v.x : 0.f;
-            v.y = in1 ? v.y : 0.f;
-            const v2f gp = g2 * cb + (g1 * cg + g0 * cr);  // dL/dv summed over channels (gs.cu:150)
-            const v2f qv = gp * v, qdx = qv * dx, qdy = qv * dy;
-            acc[0] += qdx;
-            acc[1] += qdy;
-            acc[2] += qdx * dx;
-            acc[3] += qdx * dy;
-            acc[4] += qdy * dy;
-            acc[5] += v * g0;
-            acc[6] += v * g1;
-            acc[7] += v * g2;
+        const float dxe = inx ? dx : 1e18f;
+        const float adx2 = (A * dxe) * dxe, bdx = B * dxe;
+        BwdRow R;
+        R.m0 = R.m1 = R.m2 = R.k01 = R.k20 = R.k12 = (v2f){0.f, 0.f};
+        const float *gbase = grad + (size_t)X * 3;
+        for (int rb = r0; rb <= r1; rb += 64) {
+            const int rend = min(r1, rb + 63);
+            __builtin_amdgcn_wave_barrier();
+            spy[lane] = pyt[min(rb + lane, r1)] - y;  // dy of the block's rows, one LDS word per row
+            __builtin_amdgcn_wave_barrier();
+            const float *sp = spy + rsub;
+            const float *grun = gbase + (size_t)(rb + rsub - P.row0) * rowpitch;
+            int Yb = rb;
+            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, grun += 2 * half, sp += 2 * RPI)
+                bwd_trip<TEST, false>(R, grun, grun + half, (v2f){sp[0], sp[RPI]}, true, true, adx2, bdx, C, cr,
+                                      cg, cb, P.dmax);
+            if (Yb <= rend) {  // ragged last trip: clamp the addresses, mask the rows past the window
+                const int Ya = Yb + rsub, Yc = Ya + RPI;
+                const float *glast = gbase + (size_t)(rend - P.row0) * rowpitch;
+                const bool ok1 = Ya <= rend, ok2 = Yc <= rend;
+                bwd_trip<TEST, true>(R, ok1 ? grun : glast, ok2 ? grun + half : glast,
+                                     (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, ok1, ok2, adx2, bdx, C,
+                                     cr, cg, cb, P.dmax);
+            }
         }
+        const float M0 = R.m0.x + R.m0.y, M1 = R.m1.x + R.m1.y, M2 = R.m2.x + R.m2.y;
+        if (inx) {  // (dx is the true difference here; switched-off lanes have M* == 0 anyway)
+            const float sx = dx * M0;
+            acc[0] += sx;
+            acc[1] += M1;
+            acc[2] += dx * sx;
+            acc[3] += dx * M1;
+            acc[4] += M2;
+        }
+        acc[5] += R.k01.x + R.k20.y;
+        acc[6] += R.k01.y + R.k12.x;
+        acc[7] += R.k20.x + R.k12.y;
     }
 }
 
@@ -551,7 +602,7 @@ template <bool BOUNDED>
 __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int lane, const Params &P,
                                          const PlanView &V, const float *__restrict__ grad,
                                          float *__restrict__ g_sigmas, float *__restrict__ g_coords,
-                                         float *__restrict__ g_colors)
+                                         float *__restrict__ g_colors, float *spy)
 {
     const uint2 bb = V.bbox[j];  // wave-uniform: scalar loads
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
@@ -565,17 +616,14 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
     }
     const float4 ra = V.rec[2 * (size_t)j], rb = V.rec[2 * (size_t)j + 1];
     const float x = ra.x, y = ra.y, A = ra.z, B = ra.w, cr = rb.x, cg = rb.y, cb = rb.z, C = rb.w;
-    v2f acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = (v2f){0.f, 0.f};
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int bw = c1 - c0 + 1;
-    if (BOUNDED && (bb.x & 0x8000u))
-        bwd_sweep<true>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, A, B, C, cr, cg, cb, acc);
-    else
-        bwd_sweep<false>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, A, B, C, cr, cg, cb, acc);
-    float a[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = acc[k].x + acc[k].y;
+    const bool test = BOUNDED && (bb.x & 0x8000u);
+#define GSASR_SWEEP(T, L) bwd_sweep<T, L>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, A, B, C, cr, cg, cb, spy, a)
+    if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
+    else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
+    else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
+#undef GSASR_SWEEP
     const float d = wave_sum8(a, lane);
     const float Sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0));
     const float Sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 8));
@@ -624,17 +672,19 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
     const unsigned gw = t * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned nwaves = nb * 4u;
+    __shared__ float s_py[4][64];
+    float *spy = s_py[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
     if (gw < large_beg)
-        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, g_sigmas, g_coords, g_colors, spy);
     else if (gw < large_end)
-        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, g_sigmas, g_coords, g_colors, spy);
     // remaining row chunks of the large class, spread over all waves
     const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
     for (unsigned it = gw; it < extra; it += nwaves) {
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
-        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, g_sigmas, g_coords, g_colors, spy);
     }
 }
 
