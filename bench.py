@@ -138,21 +138,30 @@ def time_stage(fn, iters, dev):
 
 def cpu_baseline(args):
     """The oracle's fp32 restatement of the reference kernels (OpenMP over the host cores) on a bounded
-    sample of the SAME workload: a 192-row band of config 2 with all 65 536 Gaussians, forward + backward."""
+    sample of the SAME workload: a row band of config 2 (sized for ~10 s on this host) with all 65 536 Gaussians, forward + backward."""
     from gsasr_amd import synthetic
     from oracle import gs_oracle
     h_lr, w_lr, scale, _ = CONFIGS["c2"]
     sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=0)
-    rows = (H // 2 - 96, H // 2 + 96)
-    wgt = synthetic.grad_image(H, W, 1)[rows[0]:rows[1]].contiguous().numpy()
     dmax = None if args.dmax < 0 else args.dmax
     s, c, k = sig.numpy(), xy.numpy(), col.numpy()
     cores = gs_oracle.num_threads()
-    t0 = time.perf_counter()
-    gs_oracle.forward_f32(s, c, k, H, W, dmax, rows=rows)
-    t1 = time.perf_counter()
-    gs_oracle.backward_f32(s, c, k, wgt, dmax, h=H, rows=rows)
-    t2 = time.perf_counter()
+    full_wgt = synthetic.grad_image(H, W, 1)
+
+    def run(rows):
+        wgt = full_wgt[rows[0]:rows[1]].contiguous().numpy()
+        t0 = time.perf_counter()
+        gs_oracle.forward_f32(s, c, k, H, W, dmax, rows=rows)
+        t1 = time.perf_counter()
+        gs_oracle.backward_f32(s, c, k, wgt, dmax, h=H, rows=rows)
+        return t0, t1, time.perf_counter()
+
+    # size the sample for ~10 s of wall time on whatever host this is: calibrate on 2 rows per thread
+    probe = min(H, max(16, 2 * cores))
+    t0, _, t2 = run((H // 2 - probe // 2, H // 2 - probe // 2 + probe))
+    nrows = int(min(H, max(probe, probe * 10.0 / max(t2 - t0, 1e-3))))
+    rows = (H // 2 - nrows // 2, H // 2 - nrows // 2 + nrows)
+    t0, t1, t2 = run(rows)
     px = (rows[1] - rows[0]) * W
     out = {"value": px / (t2 - t0) / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
            "sample": f"oracle/gs_ref.c fp32 restatement of gs_cuda{'_dmax' if dmax is not None else ''} (OpenMP, {cores} threads), "
