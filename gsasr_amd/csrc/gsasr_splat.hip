@@ -44,6 +44,7 @@ constexpr int CELL = 16;        // binning cell side in pixels
 constexpr int CELL_SHIFT = 4;
 constexpr int SUBX = 8;         // forward sub-tile: 8 px wide x 16 px tall per wave64 (2 px per lane)
 constexpr int SUBY = 16;
+constexpr int SUBX_SHIFT = 3, SUBY_SHIFT = 4;
 constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is binned as "large"
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y
@@ -67,7 +68,7 @@ struct PlanView {
     unsigned *blockmax;     // [2*nblk] per-classify-block max half-extents
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
     float4 *fin;            // [2*s] backward epilogue constants + original index
-    uint2 *bbox;            // [s] {c0 | test<<15 | c1<<16, r0 | r1<<16}
+    uint4 *bbox;            // [s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[4], span_hi[4]}
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -110,7 +111,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_bmax = o;   o += align_up((size_t)classify_blocks(d) * 8, 256);
     L.off_rec = o;    o += align_up(s * 32, 256);
     L.off_fin = o;    o += align_up(s * 32, 256);
-    L.off_bbox = o;   o += align_up(s * 8, 256);
+    L.off_bbox = o;   o += align_up(s * 16, 256);
     L.total = o;
     return L;
 }
@@ -129,7 +130,7 @@ PlanView make_view(const Layout &L, void *ws)
     V.blockmax = (unsigned *)(b + L.off_bmax);
     V.rec = (float4 *)(b + L.off_rec);
     V.fin = (float4 *)(b + L.off_fin);
-    V.bbox = (uint2 *)(b + L.off_bbox);
+    V.bbox = (uint4 *)(b + L.off_bbox);
     return V;
 }
 
@@ -180,6 +181,8 @@ struct Box {
     int cls;             // 0 normal, 1 large, 2 dead
 };
 
+constexpr double WINDOW_EPS = 0.02;  // px; covers every rounding between these windows and the kernels' float tests
+
 __device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y, const Params &P)
 {
     Box b;
@@ -188,19 +191,22 @@ __device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y
         ext_x = fminf(ext_x, P.kcut * sx);
         ext_y = fminf(ext_y, P.kcut * sy);
     }
-    const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
-    const float cxp = (x + 1.f) * hx, cyp = (y + 1.f) * hy;
-    b.ex = ext_x * hx;
-    b.ey = ext_y * hy;
-    // +-1 px of slack covers every rounding between this window and the kernels' own float tests
-    const float lox = floorf(cxp - b.ex) - 1.f, hix = ceilf(cxp + b.ex) + 1.f;
-    const float loy = floorf(cyp - b.ey) - 1.f, hiy = ceilf(cyp + b.ey) + 1.f;
+    // Pixel X sits at px = 2X/(w-1)-1, so |px - x| <= ext  <=>  |X - cxp| <= ext*hx with cxp = (x+1)*hx.
+    // Evaluated in double (once per Gaussian); the float pixel table differs from the exact grid by
+    // < 1e-2 px even at w = 32767, which WINDOW_EPS covers, so the window is tight to the pixel.
+    const double hx = 0.5 * (double)(P.w - 1), hy = 0.5 * (double)(P.h - 1);
+    const double cxp = ((double)x + 1.0) * hx, cyp = ((double)y + 1.0) * hy;
+    const double ex = (double)ext_x * hx, ey = (double)ext_y * hy;
+    b.ex = (float)ex;
+    b.ey = (float)ey;
+    const double lox = ceil(cxp - ex - WINDOW_EPS), hix = floor(cxp + ex + WINDOW_EPS);
+    const double loy = ceil(cyp - ey - WINDOW_EPS), hiy = floor(cyp + ey + WINDOW_EPS);
     const bool finite = (sx - sx == 0.f) && (sy - sy == 0.f) && (x - x == 0.f) && (y - y == 0.f);
-    b.c0 = (int)fmaxf(lox, 0.f);
-    b.c1 = (int)fminf(hix, (float)(P.w - 1));
-    b.r0 = (int)fmaxf(loy, (float)P.row0);
-    b.r1 = (int)fminf(hiy, (float)(P.row1 - 1));
-    if (!finite || b.c0 > b.c1 || b.r0 > b.r1 || !(hix >= 0.f) || !(hiy >= 0.f))
+    b.c0 = (int)fmax(lox, 0.0);
+    b.c1 = (int)fmin(hix, (double)(P.w - 1));
+    b.r0 = (int)fmax(loy, (double)P.row0);
+    b.r1 = (int)fmin(hiy, (double)(P.row1 - 1));
+    if (!finite || b.c0 > b.c1 || b.r0 > b.r1 || !(hix >= 0.0) || !(hiy >= 0.0))
         b.cls = 2;
     else if (!(b.ex <= (float)RCAP_PX && b.ey <= (float)RCAP_PX))
         b.cls = 1;
@@ -361,13 +367,51 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
     const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * sx * hx + 1.f <= P.dmax * hx &&
                                            P.kcut * sy * hy + 1.f <= P.dmax * hy);
-    uint2 bb;
+    uint4 bb;
     if (b.cls == 2) {
-        bb.x = 1u;  // c0 = 1 > c1 = 0: never hit
-        bb.y = 1u;
+        bb = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
     } else {
         bb.x = (unsigned)b.c0 | (needs_test ? 0x8000u : 0u) | ((unsigned)b.c1 << 16);
         bb.y = (unsigned)b.r0 | ((unsigned)b.r1 << 16);
+        bb.z = bb.w = 0u;
+        // Row spans: for each 16-row band of forward tiles the window touches (at most 4 are encoded),
+        // the range of 8-px tile columns that the ellipse {exponent >= -tau} actually reaches.  The
+        // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
+        // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
+        const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
+        if (P.kcut > 0.f && ty1 - ty0 < 4) {
+            const double spx = dsx * hx, spy = dsy * hy;                  // sigmas in pixels
+            const double cxp = ((double)x + 1.0) * hx, cyp = ((double)y + 1.0) * hy;
+            const double tau = 0.5 * (double)P.kcut * (double)P.kcut;
+            const double omr = 1.0 - dr * dr;
+            const double qa = 0.5 / (omr * spx * spx), qb = -dr / (omr * spx * spy), qc = 0.5 / (omr * spy * spy);
+            const double umax = spx * (double)P.kcut, vmax = spy * (double)P.kcut;
+            const double vstar = dr * spy / spx * umax;                   // v of the ellipse's rightmost point
+            const int tx0 = b.c0 >> SUBX_SHIFT;
+            for (int t = 0; t <= ty1 - ty0; ++t) {
+                // the band's pixel rows Ya..Ya+15, relative to the centre
+                const double v0 = (double)(P.row0 + ((ty0 + t) << SUBY_SHIFT)) - cyp - WINDOW_EPS,
+                             v1 = v0 + (double)(SUBY - 1) + 2.0 * WINDOW_EPS;
+                unsigned lo = 1u, hi = 0u;  // empty
+                if (v1 >= -vmax && v0 <= vmax) {
+                    const double a0 = fmax(v0, -vmax), a1 = fmin(v1, vmax);
+                    const double vr = fmin(fmax(vstar, a0), a1), vl = fmin(fmax(-vstar, a0), a1);
+                    const double dr_ = 4.0 * qa * tau - (4.0 * qa * qc - qb * qb) * vr * vr;
+                    const double dl_ = 4.0 * qa * tau - (4.0 * qa * qc - qb * qb) * vl * vl;
+                    const double uhi = (-qb * vr + sqrt(fmax(dr_, 0.0))) / (2.0 * qa);
+                    const double ulo = (-qb * vl - sqrt(fmax(dl_, 0.0))) / (2.0 * qa);
+                    const int xl = max(b.c0, (int)fmax(ceil(cxp + ulo - WINDOW_EPS), -1.0));
+                    const int xh = min(b.c1, (int)fmin(floor(cxp + uhi + WINDOW_EPS), 40000.0));
+                    if (xl <= xh && !(umax != umax)) {
+                        lo = (unsigned)min(255, (xl >> SUBX_SHIFT) - tx0);
+                        hi = (unsigned)min(255, (xh >> SUBX_SHIFT) - tx0);
+                    }
+                }
+                bb.z |= lo << (8 * t);
+                bb.w |= hi << (8 * t);
+            }
+            bb.y |= 0x8000u;
+        }
     }
     V.bbox[j] = bb;
 }
@@ -382,56 +426,71 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 
 template <bool TEST>
+__device__ __forceinline__ void fwd_eval(const v8f r, float px, v2f py, float dmax, v2f &ar, v2f &ag, v2f &ab)
+{
+    const float dx = px - r[0];
+    const v2f dy = py - r[1];
+    const float adx = r[2] * dx, bdx = r[3] * dx;
+    const float adx2 = adx * dx;
+    const v2f t = r[7] * dy + bdx;
+    const v2f pw = dy * t + adx2;
+    v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+    if (TEST) {
+        const bool inx = fabsf(dx) <= dmax;
+        v.x = (inx && fabsf(dy.x) <= dmax) ? v.x : 0.f;
+        v.y = (inx && fabsf(dy.y) <= dmax) ? v.y : 0.f;
+    }
+    ar += v * r[4];
+    ag += v * r[5];
+    ab += v * r[6];
+}
+
+// Walk the hit mask FOUR hits at a time: the four wave-uniform 32-byte records are fetched by four
+// independent scalar loads (s_load_dwordx8 sbase+soffset) before the first is consumed, so a wave pays
+// one scalar-cache round trip per four hits instead of one per hit.
+template <bool TEST>
 __device__ __forceinline__ void fwd_hits(unsigned long long mask, const char *__restrict__ chunk, float px,
                                          v2f py, float dmax, v2f &ar, v2f &ag, v2f &ab)
 {
     while (mask) {
-        const unsigned k = (unsigned)__builtin_ctzll(mask);
-        mask &= ~(1ull << k);
-        // wave-uniform 32-byte record: one s_load_dwordx8 at (chunk + k*32)
-        const v8f r = *reinterpret_cast<const v8f *>(chunk + (k << 5));
-        const float dx = px - r[0];
-        const v2f dy = py - r[1];
-        const float adx = r[2] * dx, bdx = r[3] * dx;
-        const float adx2 = adx * dx;
-        const v2f t = r[7] * dy + bdx;
-        const v2f pw = dy * t + adx2;
-        v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
-        if (TEST) {
-            const bool inx = fabsf(dx) <= dmax;
-            v.x = (inx && fabsf(dy.x) <= dmax) ? v.x : 0.f;
-            v.y = (inx && fabsf(dy.y) <= dmax) ? v.y : 0.f;
-        }
-        ar += v * r[4];
-        ag += v * r[5];
-        ab += v * r[6];
+        const unsigned k0 = (unsigned)__builtin_ctzll(mask);
+        mask &= ~(1ull << k0);
+        const bool h1 = mask != 0ull;
+        const unsigned k1 = h1 ? (unsigned)__builtin_ctzll(mask) : k0;
+        mask &= ~(1ull << k1);
+        const bool h2 = mask != 0ull;
+        const unsigned k2 = h2 ? (unsigned)__builtin_ctzll(mask) : k0;
+        mask &= ~(1ull << k2);
+        const bool h3 = mask != 0ull;
+        const unsigned k3 = h3 ? (unsigned)__builtin_ctzll(mask) : k0;
+        mask &= ~(1ull << k3);
+        v8f r0, r1, r2, r3;
+        // hipcc sinks each load next to its use (one round trip per hit); issue the four together
+        asm volatile("s_load_dwordx8 %0, %4, %5\n\t"
+                     "s_load_dwordx8 %1, %4, %6\n\t"
+                     "s_load_dwordx8 %2, %4, %7\n\t"
+                     "s_load_dwordx8 %3, %4, %8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3)
+                     : "s"(chunk), "s"(k0 << 5), "s"(k1 << 5), "s"(k2 << 5), "s"(k3 << 5)
+                     : "memory");
+        fwd_eval<TEST>(r0, px, py, dmax, ar, ag, ab);
+        if (h1) fwd_eval<TEST>(r1, px, py, dmax, ar, ag, ab);
+        if (h2) fwd_eval<TEST>(r2, px, py, dmax, ar, ag, ab);
+        if (h3) fwd_eval<TEST>(r3, px, py, dmax, ar, ag, ab);
     }
 }
 
-template <bool BOUNDED>
-__device__ __forceinline__ void fwd_segment(unsigned beg, unsigned end, int lane, int sx0, int sx1, int sy0,
-                                            int sy1, float px, v2f py, float dmax,
-                                            const float4 *__restrict__ rec, const uint2 *__restrict__ bbox,
-                                            v2f &ar, v2f &ag, v2f &ab)
+// next 64-candidate chunk of the segment table held in lanes (sbeg/send); all arguments wave-uniform
+__device__ __forceinline__ bool fwd_advance(int &sg, unsigned &bs, unsigned &en, int nseg, unsigned sbeg, unsigned send)
 {
-    for (unsigned base = beg; base < end; base += 64) {
-        const unsigned j = base + (unsigned)lane;
-        bool hit = false, needs = false;
-        if (j < end) {  // one 8-byte load: {c0 | test<<15 | c1<<16, r0 | r1<<16}
-            const uint2 bb = bbox[j];
-            const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
-            const int r0 = (int)(bb.y & 0xffffu), r1 = (int)(bb.y >> 16);
-            hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
-            needs = (bb.x & 0x8000u) != 0u;
-        }
-        const char *chunk = reinterpret_cast<const char *>(rec + 2 * (size_t)base);
-        if (BOUNDED) {
-            fwd_hits<false>(__ballot(hit && !needs), chunk, px, py, dmax, ar, ag, ab);
-            fwd_hits<true>(__ballot(hit && needs), chunk, px, py, dmax, ar, ag, ab);
-        } else {
-            fwd_hits<false>(__ballot(hit), chunk, px, py, dmax, ar, ag, ab);
-        }
+    bs += 64;
+    while (bs >= en) {
+        if (++sg >= nseg) return false;
+        bs = (unsigned)__builtin_amdgcn_readlane((int)sbeg, sg);
+        en = (unsigned)__builtin_amdgcn_readlane((int)send, sg);
     }
+    return true;
 }
 
 template <bool BOUNDED>
@@ -456,21 +515,64 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
 
     const float4 *__restrict__ rec = V.rec;
-    const uint2 *__restrict__ bbox = V.bbox;
+    const uint4 *__restrict__ bbox = V.bbox;
     const unsigned *__restrict__ cs = V.cell_start;
-    // normal class: cells whose Gaussians can reach this sub-tile (max half-extent from the plan header)
+    const int wty = (sy0 - P.row0) >> SUBY_SHIFT, wtx = sx0 >> SUBX_SHIFT;
+
+    // Segment table: lane r holds [beg,end) of cell row cy0+r restricted to the columns a normal-class
+    // Gaussian can reach this sub-tile from (max half-extent from the plan header); one more lane holds
+    // the large class.  One vector round trip instead of a dependent scalar load per row.
     const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    int nseg = 0;
+    unsigned sbeg = 0, send = 0;
     if (rx > 0) {
         const int cx0 = max(sx0 - rx, 0) >> CELL_SHIFT, cx1 = min((sx1 + rx) >> CELL_SHIFT, P.ncx - 1);
         const int cy0 = max(sy0 - ry, 0) >> CELL_SHIFT, cy1 = min((sy1 + ry) >> CELL_SHIFT, P.ncy - 1);
-        for (int cy = cy0; cy <= cy1; ++cy) {
-            const unsigned beg = cs[cy * P.ncx + cx0], end = cs[cy * P.ncx + cx1 + 1];
-            fwd_segment<BOUNDED>(beg, end, lane, sx0, sx1, sy0, sy1, px, py, P.dmax, rec, bbox, ar, ag, ab);
+        nseg = cy1 - cy0 + 1;
+        if (lane < nseg) {
+            sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+            send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
         }
     }
-    // large class: every wave tests all of them
-    fwd_segment<BOUNDED>(cs[P.ncells], cs[P.ncells + 1], lane, sx0, sx1, sy0, sy1, px, py, P.dmax, rec, bbox,
-                         ar, ag, ab);
+    if (lane == nseg) {
+        sbeg = cs[P.ncells];
+        send = cs[P.ncells + 1];
+    }
+    ++nseg;
+
+    // Flat walk over 64-candidate chunks of all segments, software-pipelined: the window record of the
+    // NEXT chunk is in flight while the hits of the current one are evaluated.
+    int seg = -1;
+    unsigned base = 0, end = 0;
+    const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
+    bool live = fwd_advance(seg, base, end, nseg, sbeg, send);
+    uint4 bb = dead;
+    if (live && base + (unsigned)lane < end) bb = bbox[base + (unsigned)lane];
+    while (live) {
+        int nseg_i = seg;
+        unsigned nbase = base, nend = end;
+        const bool nlive = fwd_advance(nseg_i, nbase, nend, nseg, sbeg, send);
+        uint4 nbb = dead;
+        if (nlive && nbase + (unsigned)lane < nend) nbb = bbox[nbase + (unsigned)lane];
+
+        const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+        const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+        bool hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
+        if (bb.y & 0x8000u) {  // per-tile-row column spans (k_bin)
+            const unsigned sh = ((unsigned)(wty - ((r0 - P.row0) >> SUBY_SHIFT)) & 3u) * 8u;
+            const int txr = wtx - (c0 >> SUBX_SHIFT);
+            hit &= (txr >= (int)((bb.z >> sh) & 0xffu)) & (txr <= (int)((bb.w >> sh) & 0xffu));
+        }
+        const bool needs = (bb.x & 0x8000u) != 0u;
+        const char *chunk = reinterpret_cast<const char *>(rec + 2 * (size_t)base);
+        if (BOUNDED) {
+            fwd_hits<false>(__ballot(hit && !needs), chunk, px, py, P.dmax, ar, ag, ab);
+            fwd_hits<true>(__ballot(hit && needs), chunk, px, py, P.dmax, ar, ag, ab);
+        } else {
+            fwd_hits<false>(__ballot(hit), chunk, px, py, P.dmax, ar, ag, ab);
+        }
+        seg = nseg_i; base = nbase; end = nend; live = nlive; bb = nbb;
+    }
     if (X < P.w) {
         if (Y0 < P.row1) {
             float *o = img + ((size_t)(Y0 - P.row0) * P.w + X) * 3;
@@ -604,9 +706,9 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
                                          float *__restrict__ g_sigmas, float *__restrict__ g_coords,
                                          float *__restrict__ g_colors, float *spy)
 {
-    const uint2 bb = V.bbox[j];  // wave-uniform: scalar loads
+    const uint4 bb = V.bbox[j];  // wave-uniform: scalar loads
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
-    int r0 = (int)(bb.y & 0xffffu), r1 = (int)(bb.y >> 16);
+    int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
     if (c0 > c1) return;  // dead
     if (chunk >= 0) {
         const int rpc = (r1 - r0 + NCH) / NCH;
