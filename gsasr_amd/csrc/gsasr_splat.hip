@@ -68,13 +68,14 @@ struct PlanView {
     unsigned *blockmax;     // [2*nblk] per-classify-block max half-extents
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
     float4 *fin;            // [2*s] backward epilogue constants + original index
+    float *sums;            // [8*s] raw backward sums {Sx,Sy,Sxx,Sxy,Syy,Cr,Cg,Cb} per (cell-ordered) Gaussian
     uint4 *bbox;            // [s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[4], span_hi[4]}
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_rec, off_fin, off_bbox;
+    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_rec, off_fin, off_sums, off_bbox;
     size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
     size_t total;
     int ncx, ncy, ncells;
@@ -111,6 +112,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_bmax = o;   o += align_up((size_t)classify_blocks(d) * 8, 256);
     L.off_rec = o;    o += align_up(s * 32, 256);
     L.off_fin = o;    o += align_up(s * 32, 256);
+    L.off_sums = o;   o += align_up(s * 32, 256);
     L.off_bbox = o;   o += align_up(s * 16, 256);
     L.total = o;
     return L;
@@ -130,6 +132,7 @@ PlanView make_view(const Layout &L, void *ws)
     V.blockmax = (unsigned *)(b + L.off_bmax);
     V.rec = (float4 *)(b + L.off_rec);
     V.fin = (float4 *)(b + L.off_fin);
+    V.sums = (float *)(b + L.off_sums);
     V.bbox = (uint4 *)(b + L.off_bbox);
     return V;
 }
@@ -414,6 +417,10 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         }
     }
     V.bbox[j] = bb;
+    if (b.cls == 1) {  // large Gaussians accumulate their row chunks atomically: start from zero
+        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -634,7 +641,6 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     constexpr int LX = 1 << LXLOG, RPI = 64 >> LXLOG;
     const int col = lane & (LX - 1), rsub = lane >> LXLOG;
     const size_t rowpitch = (size_t)P.w * 3;
-    const ptrdiff_t half = (ptrdiff_t)RPI * (ptrdiff_t)rowpitch;
     for (int strip = 0; strip < bw; strip += 64) {
         const int cc = strip + col;
         const int X = c0 + min(cc, bw - 1);
@@ -646,25 +652,30 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
         const float adx2 = (A * dxe) * dxe, bdx = B * dxe;
         BwdRow R;
         R.m0 = R.m1 = R.m2 = R.k01 = R.k20 = R.k12 = (v2f){0.f, 0.f};
-        const float *gbase = grad + (size_t)X * 3;
+        // addressing: wave-uniform row pointer (SGPRs, advanced by the scalar unit) + a 32-bit per-lane byte
+        // offset -> global_load with saddr, no per-trip VALU address arithmetic
+        const unsigned voff = (unsigned)(((size_t)X * 3 + (size_t)rsub * rowpitch) * sizeof(float));
         for (int rb = r0; rb <= r1; rb += 64) {
             const int rend = min(r1, rb + 63);
             __builtin_amdgcn_wave_barrier();
             spy[lane] = pyt[min(rb + lane, r1)] - y;  // dy of the block's rows, one LDS word per row
             __builtin_amdgcn_wave_barrier();
             const float *sp = spy + rsub;
-            const float *grun = gbase + (size_t)(rb + rsub - P.row0) * rowpitch;
+            const char *rowp = reinterpret_cast<const char *>(grad + (size_t)(rb - P.row0) * rowpitch);
+            const size_t halfb = (size_t)RPI * rowpitch * sizeof(float);
             int Yb = rb;
-            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, grun += 2 * half, sp += 2 * RPI)
-                bwd_trip<TEST, false>(R, grun, grun + half, (v2f){sp[0], sp[RPI]}, true, true, adx2, bdx, C, cr,
-                                      cg, cb, P.dmax);
+            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, rowp += 2 * halfb, sp += 2 * RPI)
+                bwd_trip<TEST, false>(R, reinterpret_cast<const float *>(rowp + voff),
+                                      reinterpret_cast<const float *>(rowp + halfb + voff), (v2f){sp[0], sp[RPI]}, true,
+                                      true, adx2, bdx, C, cr, cg, cb, P.dmax);
             if (Yb <= rend) {  // ragged last trip: clamp the addresses, mask the rows past the window
                 const int Ya = Yb + rsub, Yc = Ya + RPI;
-                const float *glast = gbase + (size_t)(rend - P.row0) * rowpitch;
                 const bool ok1 = Ya <= rend, ok2 = Yc <= rend;
-                bwd_trip<TEST, true>(R, ok1 ? grun : glast, ok2 ? grun + half : glast,
-                                     (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, ok1, ok2, adx2, bdx, C,
-                                     cr, cg, cb, P.dmax);
+                const float *glast = grad + (size_t)X * 3 + (size_t)(rend - P.row0) * rowpitch;
+                const float *ga = ok1 ? reinterpret_cast<const float *>(rowp + voff) : glast;
+                const float *gb = ok2 ? reinterpret_cast<const float *>(rowp + halfb + voff) : glast;
+                bwd_trip<TEST, true>(R, ga, gb, (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, ok1, ok2,
+                                     adx2, bdx, C, cr, cg, cb, P.dmax);
             }
         }
         const float M0 = R.m0.x + R.m0.y, M1 = R.m1.x + R.m1.y, M2 = R.m2.x + R.m2.y;
@@ -702,14 +713,12 @@ __device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane)
 
 template <bool BOUNDED>
 __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int lane, const Params &P,
-                                         const PlanView &V, const float *__restrict__ grad,
-                                         float *__restrict__ g_sigmas, float *__restrict__ g_coords,
-                                         float *__restrict__ g_colors, float *spy)
+                                         const PlanView &V, const float *__restrict__ grad, float *spy)
 {
     const uint4 bb = V.bbox[j];  // wave-uniform: scalar loads
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
     int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
-    if (c0 > c1) return;  // dead
+    if (c0 > c1) return;  // dead class (not finalized)
     if (chunk >= 0) {
         const int rpc = (r1 - r0 + NCH) / NCH;
         r0 = r0 + chunk * rpc;
@@ -726,45 +735,47 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
     else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
     else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
 #undef GSASR_SWEEP
+    // lane 8k now holds raw sum k: one 32-byte store per Gaussian; the Gaussian-constant factors are applied
+    // by k_bwd_finalize, vectorised over Gaussians (64 per wave instead of one)
     const float d = wave_sum8(a, lane);
-    const float Sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0));
-    const float Sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 8));
-    const float Sxx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 16));
-    const float Sxy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 24));
-    const float Syy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 32));
-    const float Cr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 40));
-    const float Cg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 48));
-    const float Cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 56));
-    if (lane == 0) {
-        // the per-pixel partials of gs.cu:139-146 are linear in {q dx, q dy, q dx^2, q dx dy, q dy^2},
-        // so the Gaussian-constant factors are applied once to the five moment sums
-        const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
-        const float two_w1 = fa.x, w2 = fa.y, w3 = fa.z, w4 = fa.w, rho = fb.x, isx = fb.y, isy = fb.z;
-        const unsigned i = __float_as_uint(fb.w);
-        const float rw3 = rho * w3;
-        const float gx = two_w1 * (rw3 * Sy - w2 * Sx);
-        const float gy = two_w1 * (rw3 * Sx - w4 * Sy);
-        const float gsx = two_w1 * isx * (rw3 * Sxy - w2 * Sxx);
-        const float gsy = two_w1 * isy * (rw3 * Sxy - w4 * Syy);
-        const float qd = w2 * Sxx - 2.f * rw3 * Sxy + w4 * Syy;
-        const float grho = -two_w1 * (two_w1 * rho * qd + w3 * Sxy);
-        float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
-        if (atomic) {
-            atomicAdd(os + 0, gsx); atomicAdd(os + 1, gsy); atomicAdd(os + 2, grho);
-            atomicAdd(op + 0, gx);  atomicAdd(op + 1, gy);
-            atomicAdd(oc + 0, Cr); atomicAdd(oc + 1, Cg); atomicAdd(oc + 2, Cb);
-        } else {
-            os[0] += gsx; os[1] += gsy; os[2] += grho;
-            op[0] += gx;  op[1] += gy;
-            oc[0] += Cr; oc[1] += Cg; oc[2] += Cb;
-        }
+    if ((lane & 7) == 0) {
+        float *o = V.sums + 8 * (size_t)j + (lane >> 3);
+        if (atomic) atomicAdd(o, d); else *o = d;
     }
 }
 
+// The per-pixel partials of gs.cu:139-146 are linear in {q dx, q dy, q dx^2, q dx dy, q dy^2}: the
+// Gaussian-constant factors are applied once to the five moment sums, one thread per Gaussian.
+__global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, float *__restrict__ g_sigmas,
+                                                      float *__restrict__ g_coords, float *__restrict__ g_colors)
+{
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= V.cell_start[P.ncells + 1]) return;  // dead class: never swept, sums undefined
+    const float4 sa = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j];
+    const float4 sb = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j + 1];
+    if (j >= V.cell_start[P.ncells]) {  // large class: leave the atomic accumulators zeroed for the next backward
+        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float Sx = sa.x, Sy = sa.y, Sxx = sa.z, Sxy = sa.w, Syy = sb.x, Cr = sb.y, Cg = sb.z, Cb = sb.w;
+    const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
+    const float two_w1 = fa.x, w2 = fa.y, w3 = fa.z, w4 = fa.w, rho = fb.x, isx = fb.y, isy = fb.z;
+    const unsigned i = __float_as_uint(fb.w);
+    const float rw3 = rho * w3;
+    const float gx = two_w1 * (rw3 * Sy - w2 * Sx);
+    const float gy = two_w1 * (rw3 * Sx - w4 * Sy);
+    const float gsx = two_w1 * isx * (rw3 * Sxy - w2 * Sxx);
+    const float gsy = two_w1 * isy * (rw3 * Sxy - w4 * Syy);
+    const float qd = w2 * Sxx - 2.f * rw3 * Sxy + w4 * Syy;
+    const float grho = -two_w1 * (two_w1 * rho * qd + w3 * Sxy);
+    float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
+    os[0] += gsx; os[1] += gsy; os[2] += grho;
+    op[0] += gx;  op[1] += gy;
+    oc[0] += Cr; oc[1] += Cg; oc[2] += Cb;
+}
+
 template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
-                                                    float *__restrict__ g_sigmas, float *__restrict__ g_coords,
-                                                    float *__restrict__ g_colors)
+__global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad)
 {
     const int lane = threadIdx.x & 63;
     // XCD-aware order (block b runs on XCD b%8): each XCD sweeps a contiguous run of the cell-ordered
@@ -778,15 +789,15 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     float *spy = s_py[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
     if (gw < large_beg)
-        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, g_sigmas, g_coords, g_colors, spy);
+        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, spy);
     else if (gw < large_end)
-        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, g_sigmas, g_coords, g_colors, spy);
+        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, spy);
     // remaining row chunks of the large class, spread over all waves
     const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
     for (unsigned it = gw; it < extra; it += nwaves) {
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
-        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, g_sigmas, g_coords, g_colors, spy);
+        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, spy);
     }
 }
 
@@ -884,9 +895,11 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
     const dim3 grid((unsigned)((dims->s + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (P.bounded)
-        hipLaunchKernelGGL(k_render_bwd<true>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
+        hipLaunchKernelGGL(k_render_bwd<true>, grid, block, 0, st, P, V, grad_img);
     else
-        hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
+        hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, grad_img);
+    hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((dims->s + 255) / 256)), block, 0, st, P, V, g_sigmas, g_coords,
+                       g_colors);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for a round on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh r01
+# Writes text summaries under gpurun_out/profiles_<tag>/ ; copy the ones to keep into profiles/.
+set -u
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph"
+# 1. kernel trace + stats of the bench command (same command as the bench line, eager launches so every
+#    kernel is a separate dispatch)
+rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/kt.err
+python $R/tools/rocpd_summary.py /tmp/kt_$TAG/kt_results.db --skip 2 > $OUT/kernel_stats.txt
+# 2. PMC passes (counters only, no other tracing domains): SQ activity, then HBM bytes in separate passes
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU \
+    --kernel-trace -d /tmp/pmc1_$TAG -o p -- $BENCH > /dev/null 2> $OUT/pmc1.err
+python $R/tools/rocpd_summary.py /tmp/pmc1_$TAG/p_results.db --filter k_ | sed -n '/counters/,$p' > $OUT/pmc_sq.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc2_$TAG -o p -- $BENCH > /dev/null 2> $OUT/pmc2.err
+python $R/tools/rocpd_summary.py /tmp/pmc2_$TAG/p_results.db --filter k_ | sed -n '/counters/,$p' > $OUT/pmc_fetch.txt
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc3_$TAG -o p -- $BENCH > /dev/null 2> $OUT/pmc3.err
+python $R/tools/rocpd_summary.py /tmp/pmc3_$TAG/p_results.db --filter k_ | sed -n '/counters/,$p' > $OUT/pmc_write.txt
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace -d /tmp/pmc4_$TAG -o p -- $BENCH > /dev/null 2> $OUT/pmc4.err
+python $R/tools/rocpd_summary.py /tmp/pmc4_$TAG/p_results.db --filter k_ | sed -n '/counters/,$p' > $OUT/pmc_l2.txt
+# 3. the plain bench line (hipGraph, with cpu_baseline)
+cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
+ls -la $OUT
+cat $OUT/kernel_stats.txt $OUT/pmc_fetch.txt $OUT/pmc_write.txt
+tail -c 2500 $OUT/bench.json
