@@ -4,8 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dmax 0.1] [--config c2|c3|c4|profile-log]
 
 A "step" is one pass of the hot path over one batch of synthetic Gaussians already resident in HBM:
-plan (bin) -> forward splat into a zeroed [H,W,3] image -> backward to {sigmas, coords, colors}, exactly
-what `GSCUDA.apply(...)` + `.backward()` enqueue, driven through the C ABI of libgsasr_splat.so.
+plan (bin) -> forward splat into a fresh [H,W,3] image -> backward to {sigmas, coords, colors}, exactly what
+`rendering_cuda_dmax(...)` + `.backward()` of gsasr_amd.gaussian_splatting enqueue, through the C ABI.
 
   N = 1   BASELINE.json config 2: 256x256 LR -> x4 (1024^2 HR), 65 536 Gaussians (1 per LR pixel), fp32.
   N > 1   weak scaling of the row-band shard: the image grows to (1024*N) x 1024 with
@@ -90,13 +90,10 @@ class Step:
                                                          p.workspace.numel(), self.cabi._stream(self.dev)), "plan")
 
     def do_forward(self):
-        self.img.zero_()
-        self.cabi.forward(self.plan, self.img)
+        self.cabi.forward(self.plan, self.img, overwrite=True)      # what rendering_cuda_dmax enqueues
 
     def do_backward(self):
-        for t in self.g:
-            t.zero_()
-        self.cabi.backward(self.plan, self.sig, self.xy, self.col, self.grad_img, *self.g)
+        self.cabi.backward(self.plan, self.sig, self.xy, self.col, self.grad_img, *self.g, overwrite=True)
 
     def __call__(self):
         if self.world > 1:
@@ -266,7 +263,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
                 "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                "note": "stage time includes the memset of its outputs (12 B/px image, 32 B/Gaussian grads)"}
+                "note": "backward stage = k_render_bwd + k_bwd_finalize; outputs are stored, not accumulated (no memsets)"}
 
     if rank == 0:
         h_lr, w_lr, scale, desc = CONFIGS[args.config]

@@ -23,7 +23,8 @@ EXPORTS = (
     "gsasr_get_default_cutoff",
 )
 
-FLAG_DETERMINISTIC = 1
+FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
+FLAG_OVERWRITE_GRADS = 4   # GSASR_FLAG_OVERWRITE_GRADS
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -140,24 +141,36 @@ def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
     return Plan(d, ws, dev)
 
 
-def forward(p: Plan, img: torch.Tensor) -> torch.Tensor:
+def _dims_with(p: Plan, extra_flags: int) -> Dims:
+    if not extra_flags:
+        return p.dims
+    d = Dims.from_buffer_copy(p.dims)
+    d.flags |= extra_flags
+    return d
+
+
+def forward(p: Plan, img: torch.Tensor, overwrite: bool = False) -> torch.Tensor:
+    """img += splat (reference contract), or img = splat when `overwrite` (img may be torch.empty)."""
     pi = _chk(img, "rendered_img", (p.dims.w, 3))
     if img.shape[0] != p.dims.row1 - p.dims.row0 or img.device != p.device:
         raise RuntimeError("rendered_img does not match the plan (rows / device)")
+    d = _dims_with(p, FLAG_OVERWRITE_IMAGE if overwrite else 0)
     with torch.cuda.device(p.device):
-        check(lib().gsasr_splat_forward(ctypes.byref(p.dims), p.workspace.data_ptr(), p.workspace.numel(), pi,
+        check(lib().gsasr_splat_forward(ctypes.byref(d), p.workspace.data_ptr(), p.workspace.numel(), pi,
                                         _stream(p.device)), "gsasr_splat_forward")
     return img
 
 
-def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors) -> None:
+def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors, overwrite: bool = False) -> None:
+    """g_* += gradients (reference contract: caller zero-fills), or g_* = gradients when `overwrite`."""
     ptrs = [_chk(sigmas, "sigmas", (3,)), _chk(coords, "coords", (2,)), _chk(colors, "colors", (3,)),
             _chk(grad_img, "grads", (p.dims.w, 3)), _chk(g_sigmas, "grads_sigmas", (3,)),
             _chk(g_coords, "grads_coords", (2,)), _chk(g_colors, "grads_colors", (3,))]
     if grad_img.shape[0] != p.dims.row1 - p.dims.row0:
         raise RuntimeError("grads does not match the plan's row band")
+    d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
     with torch.cuda.device(p.device):
-        check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(p.dims), p.workspace.data_ptr(),
+        check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
 
 

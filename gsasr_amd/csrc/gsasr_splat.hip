@@ -56,6 +56,7 @@ struct Params {
     float dmax;      // box half-size (normalised units); +inf when !bounded
     float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled
     int ncx, ncy, ncells;
+    unsigned flags;  // GSASR_FLAG_*
 };
 
 struct PlanView {
@@ -158,6 +159,7 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     float tau = d->cutoff == 0.f ? default_cutoff() : d->cutoff;
     P.kcut = tau > 0.f ? (float)(std::sqrt(2.0 * (double)tau) * (1.0 + 1e-6)) : 0.f;
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
+    P.flags = d->flags;
     return P;
 }
 
@@ -581,13 +583,16 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
         seg = nseg_i; base = nbase; end = nend; live = nlive; bb = nbb;
     }
     if (X < P.w) {
+        const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
         if (Y0 < P.row1) {
             float *o = img + ((size_t)(Y0 - P.row0) * P.w + X) * 3;
-            o[0] += ar.x; o[1] += ag.x; o[2] += ab.x;
+            if (store) { o[0] = ar.x; o[1] = ag.x; o[2] = ab.x; }
+            else { o[0] += ar.x; o[1] += ag.x; o[2] += ab.x; }
         }
         if (Y1 < P.row1) {
             float *o = img + ((size_t)(Y1 - P.row0) * P.w + X) * 3;
-            o[0] += ar.y; o[1] += ag.y; o[2] += ab.y;
+            if (store) { o[0] = ar.y; o[1] = ag.y; o[2] = ab.y; }
+            else { o[0] += ar.y; o[1] += ag.y; o[2] += ab.y; }
         }
     }
 }
@@ -750,12 +755,18 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, floa
                                                       float *__restrict__ g_coords, float *__restrict__ g_colors)
 {
     const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= V.cell_start[P.ncells + 1]) return;  // dead class: never swept, sums undefined
-    const float4 sa = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j];
-    const float4 sb = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j + 1];
-    if (j >= V.cell_start[P.ncells]) {  // large class: leave the atomic accumulators zeroed for the next backward
-        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j >= (unsigned)P.s) return;
+    const bool store = P.flags & GSASR_FLAG_OVERWRITE_GRADS;
+    const bool dead = j >= V.cell_start[P.ncells + 1];  // dead class: never swept, sums undefined
+    if (dead && !store) return;
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    if (!dead) {
+        sa = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j];
+        sb = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j + 1];
+        if (j >= V.cell_start[P.ncells]) {  // large class: leave the atomic accumulators zeroed for the next backward
+            reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     const float Sx = sa.x, Sy = sa.y, Sxx = sa.z, Sxy = sa.w, Syy = sb.x, Cr = sb.y, Cg = sb.z, Cb = sb.w;
     const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
@@ -769,9 +780,15 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, floa
     const float qd = w2 * Sxx - 2.f * rw3 * Sxy + w4 * Syy;
     const float grho = -two_w1 * (two_w1 * rho * qd + w3 * Sxy);
     float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
-    os[0] += gsx; os[1] += gsy; os[2] += grho;
-    op[0] += gx;  op[1] += gy;
-    oc[0] += Cr; oc[1] += Cg; oc[2] += Cb;
+    if (store) {
+        os[0] = gsx; os[1] = gsy; os[2] = grho;
+        op[0] = gx;  op[1] = gy;
+        oc[0] = Cr; oc[1] = Cg; oc[2] = Cb;
+    } else {
+        os[0] += gsx; os[1] += gsy; os[2] += grho;
+        op[0] += gx;  op[1] += gy;
+        oc[0] += Cr; oc[1] += Cg; oc[2] += Cb;
+    }
 }
 
 template <bool BOUNDED>
@@ -887,9 +904,17 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
 {
     Layout L;
     if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
-    if (dims->s == 0 || dims->row1 == dims->row0) return GSASR_OK;
-    if (!sigmas || !coords || !colors || !grad_img || !g_sigmas || !g_coords || !g_colors)
-        return fail(GSASR_ERR_ARG, "null pointer");
+    if (dims->s == 0) return GSASR_OK;
+    if (!sigmas || !coords || !colors || !g_sigmas || !g_coords || !g_colors) return fail(GSASR_ERR_ARG, "null pointer");
+    if (dims->row1 == dims->row0) {  // empty band: the gradient is zero
+        if (dims->flags & GSASR_FLAG_OVERWRITE_GRADS) {
+            HIP_TRY(hipMemsetAsync(g_sigmas, 0, sizeof(float) * 3 * (size_t)dims->s, (hipStream_t)stream));
+            HIP_TRY(hipMemsetAsync(g_coords, 0, sizeof(float) * 2 * (size_t)dims->s, (hipStream_t)stream));
+            HIP_TRY(hipMemsetAsync(g_colors, 0, sizeof(float) * 3 * (size_t)dims->s, (hipStream_t)stream));
+        }
+        return GSASR_OK;
+    }
+    if (!grad_img) return fail(GSASR_ERR_ARG, "null pointer");
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, const_cast<void *>(workspace));
     const dim3 grid((unsigned)((dims->s + 3) / 4)), block(256);
@@ -921,11 +946,7 @@ static int render_common(const float *sigmas, const float *coords, const float *
         if (!backward) {
             rc = gsasr_splat_forward(&d, ws, bytes, img, stream);
         } else {
-            if (dmax < 0.f && s > 0) {  // gs_cuda backward overwrites its outputs (gs.cu:169-176)
-                (void)hipMemsetAsync(gs, 0, sizeof(float) * 3 * (size_t)s, st);
-                (void)hipMemsetAsync(gc, 0, sizeof(float) * 2 * (size_t)s, st);
-                (void)hipMemsetAsync(gk, 0, sizeof(float) * 3 * (size_t)s, st);
-            }
+            if (dmax < 0.f) d.flags |= GSASR_FLAG_OVERWRITE_GRADS;  // gs_cuda backward overwrites (gs.cu:169-176)
             rc = gsasr_splat_backward(sigmas, coords, colors, grads, gs, gc, gk, &d, ws, bytes, stream);
         }
     }

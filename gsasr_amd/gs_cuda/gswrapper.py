@@ -32,11 +32,13 @@ class GSCUDA(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         sigmas, coords, colors = ctx.saved_tensors
-        grads_sigmas = torch.zeros_like(sigmas)
-        grads_coords = torch.zeros_like(coords)
-        grads_colors = torch.zeros_like(colors)
+        # (the reference zero-fills three tensors and lets the kernel add into them; the finalize kernel
+        # stores instead, which saves three memsets per step)
+        grads_sigmas = torch.empty_like(sigmas)
+        grads_coords = torch.empty_like(coords)
+        grads_colors = torch.empty_like(colors)
         _cabi.backward(ctx.plan, sigmas, coords, colors, grad_output.contiguous(), grads_sigmas, grads_coords,
-                       grads_colors)
+                       grads_colors, overwrite=True)
         return (grads_sigmas, grads_coords, grads_colors, None)
 
 

@@ -61,15 +61,15 @@ class HipBackend:
     def forward(sigmas, coords, colors, h, w, dmax, rows):
         from . import _cabi
         plan = _cabi.plan(sigmas, coords, colors, h, w, dmax, rows=rows)
-        slab = torch.zeros(rows[1] - rows[0], w, 3, device=sigmas.device, dtype=torch.float32)
-        _cabi.forward(plan, slab)
+        slab = torch.empty(rows[1] - rows[0], w, 3, device=sigmas.device, dtype=torch.float32)
+        _cabi.forward(plan, slab, overwrite=True)
         return slab, plan
 
     @staticmethod
     def backward(state, sigmas, coords, colors, grad_slab):
         from . import _cabi
-        g = (torch.zeros_like(sigmas), torch.zeros_like(coords), torch.zeros_like(colors))
-        _cabi.backward(state, sigmas, coords, colors, grad_slab.contiguous(), *g)
+        g = (torch.empty_like(sigmas), torch.empty_like(coords), torch.empty_like(colors))
+        _cabi.backward(state, sigmas, coords, colors, grad_slab.contiguous(), *g, overwrite=True)
         return g
 
 

@@ -46,7 +46,10 @@ enum gsasr_status {
 };
 
 /* flags */
-#define GSASR_FLAG_DETERMINISTIC 1u /* bin in Gaussian-index order: bit-reproducible sums */
+#define GSASR_FLAG_OVERWRITE_IMAGE 2u /* forward STORES the splat (img need not be initialised) instead of
+                                         accumulating into it; saves the caller's memset and a 12 B/px read */
+#define GSASR_FLAG_OVERWRITE_GRADS 4u /* backward STORES the gradients (outputs need not be zeroed) instead
+                                         of adding into them */
 
 typedef struct gsasr_dims {
     int s;        /* number of Gaussians                                              */
@@ -80,13 +83,14 @@ int gsasr_splat_plan(const float *sigmas /*[s,3]*/, const float *coords /*[s,2]*
                      const float *colors /*[s,3]*/, const gsasr_dims *dims, void *workspace,
                      size_t workspace_bytes, void *stream);
 
-/* img[row1-row0, w, 3] += splat.  `workspace` must hold the plan of the same inputs and dims. */
+/* img[row1-row0, w, 3] += splat (= splat with GSASR_FLAG_OVERWRITE_IMAGE).  `workspace` must hold the
+ * plan of the same inputs and dims. */
 int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes,
                         float *img, void *stream);
 
 /* g_* += d(sum(grad_img*img))/d{sigmas,coords,colors} over rows [row0,row1).  Outputs must be
  * zero-initialised by the caller when a plain gradient is wanted (the reference wrapper does
- * torch.zeros_like, gs_cuda_dmax/gswrapper.py:40-42). */
+ * torch.zeros_like, gs_cuda_dmax/gswrapper.py:40-42), unless GSASR_FLAG_OVERWRITE_GRADS is set. */
 int gsasr_splat_backward(const float *sigmas, const float *coords, const float *colors,
                          const float *grad_img /*[row1-row0, w, 3]*/, float *g_sigmas,
                          float *g_coords, float *g_colors, const gsasr_dims *dims,

@@ -253,6 +253,55 @@ def test_gscuda_module_reference_shaped_entry_points(dev):
             assert _relmax(got.cpu().numpy(), w_) <= GRAD_RTOL
 
 
+def test_overwrite_flags_store_instead_of_accumulate(dev):
+    """GSASR_FLAG_OVERWRITE_IMAGE / _GRADS: outputs may be uninitialised (the host API renders into
+    torch.empty); results equal the accumulate-into-zeros path, dead Gaussians get exact zeros."""
+    from gsasr_amd import _cabi, synthetic
+    sig, xy, col, H, W = synthetic.kernel_inputs(24, 24, 4.0, seed=90, device=dev)
+    xy = xy.clone()
+    xy[7] = torch.tensor([4.0, 4.0], device=dev)          # a dead (off-image) Gaussian
+    wgt = synthetic.grad_image(H, W, 91, device=dev)
+    for dmax in (0.25, None):
+        plan = _cabi.plan(sig, xy, col, H, W, dmax)
+        ref = _cabi.forward(plan, torch.zeros(H, W, 3, device=dev))
+        out = _cabi.forward(plan, torch.full((H, W, 3), float("nan"), device=dev), overwrite=True)
+        assert torch.equal(out, ref)
+        gz = [torch.zeros_like(t) for t in (sig, xy, col)]
+        _cabi.backward(plan, sig, xy, col, wgt, *gz)
+        gn = [torch.full_like(t, float("nan")) for t in (sig, xy, col)]
+        _cabi.backward(plan, sig, xy, col, wgt, *gn, overwrite=True)
+        for a, b in zip(gz, gn):
+            assert torch.equal(a, b)
+        assert float(gn[0][7].abs().sum() + gn[1][7].abs().sum() + gn[2][7].abs().sum()) == 0.0
+        # backward twice on the same plan gives the same answer (large-class accumulators are re-armed)
+        g2 = [torch.empty_like(t) for t in (sig, xy, col)]
+        _cabi.backward(plan, sig, xy, col, wgt, *g2, overwrite=True)
+        for a, b in zip(gn, g2):
+            assert torch.equal(a, b)
+    # empty row band: zero gradient, stored
+    plan = _cabi.plan(sig, xy, col, H, W, 0.25, rows=(10, 10))
+    gn = [torch.full_like(t, float("nan")) for t in (sig, xy, col)]
+    _cabi.backward(plan, sig, xy, col, wgt[10:10].contiguous(), *gn, overwrite=True)
+    assert all(float(t.abs().max()) == 0.0 for t in gn)
+
+
+def test_large_class_backward_is_repeatable(dev):
+    from gsasr_amd import _cabi
+    g = torch.Generator().manual_seed(3)
+    s = 50
+    sig = torch.stack([0.05 + torch.rand(s, generator=g), 0.05 + torch.rand(s, generator=g), torch.rand(s, generator=g) - 0.5], 1).to(dev)
+    xy, col = (2 * torch.rand(s, 2, generator=g) - 1).to(dev), torch.rand(s, 3, generator=g).to(dev)
+    wgt = torch.rand(300, 280, 3, generator=g).to(dev)
+    plan = _cabi.plan(sig, xy, col, 300, 280, None)
+    outs = []
+    for _ in range(3):
+        gg = [torch.empty_like(t) for t in (sig, xy, col)]
+        _cabi.backward(plan, sig, xy, col, wgt, *gg, overwrite=True)
+        outs.append(gg)
+    for k in range(3):   # atomically combined row chunks: equal up to fp32 summation order
+        assert float((outs[0][k] - outs[2][k]).abs().max()) <= 1e-4 * float(outs[0][k].abs().max())
+
+
 def test_errors_are_runtimeerrors(dev):
     from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA
     sig = torch.rand(8, 3, device=dev)
