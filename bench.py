@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even at world size 1 (self-test)")
     return ap.parse_args()
 
 
@@ -73,7 +74,8 @@ class Step:
         self.img = torch.zeros(nrows, W, 3, device=dev)
         self.g = [torch.zeros_like(t) for t in (self.sig, self.xy, self.col)]
         self.plan = _cabi.plan(self.sig, self.xy, self.col, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
-        if world > 1:
+        self.dist = world > 1 or args.force_dist
+        if self.dist:
             from gsasr_amd import shard
             self.shard = shard
             self.packed = shard.pack(self.sig, self.xy, self.col)
@@ -96,14 +98,17 @@ class Step:
         self.cabi.backward(self.plan, self.sig, self.xy, self.col, self.grad_img, *self.g, overwrite=True)
 
     def __call__(self):
-        if self.world > 1:
+        if self.dist:
             import torch.distributed as dist
-            dist.broadcast(self.packed, src=0)                       # Gaussians from the decoder rank
+            dist.broadcast(self.packed, src=0)                       # Gaussians from the decoder rank ...
+            self.sig.copy_(self.packed[:, 0:3])                      # ... are what this rank bins and renders
+            self.xy.copy_(self.packed[:, 3:5])
+            self.col.copy_(self.packed[:, 5:8])
         self.do_plan()
         self.do_forward()
         if not self.fwd_only:
             self.do_backward()
-            if self.world > 1:
+            if self.dist:
                 import torch.distributed as dist
                 self.gpad[: self.n, 0:3] = self.g[0]
                 self.gpad[: self.n, 3:5] = self.g[1]
@@ -190,16 +195,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     step = Step(args, dev, rank, world)
 
     def barrier():
-        if world > 1:
+        if world > 1 or args.force_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -209,7 +215,7 @@ def main():
     for _ in range(min(3, args.warmup)):
         step()
     torch.cuda.synchronize(dev)
-    if world == 1 and not args.no_graph:
+    if world == 1 and not args.no_graph and not args.force_dist:
         try:
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -255,7 +261,7 @@ def main():
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")   # HBM bytes per launch from rocprofv3 --pmc passes
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.config == "c2" and world == 1:
         try:
             traffic = json.load(open(pmc)).get({"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom], {}).get("hbm_bytes")
         except Exception:
@@ -268,8 +274,8 @@ def main():
     if rank == 0:
         h_lr, w_lr, scale, desc = CONFIGS[args.config]
         out = {
-            "metric": "HR Mpixels/sec fwd+bwd (x4, 1 Gaussian/LR px); achieved HBM GB/s vs roofline"
-                      if not step.fwd_only else "HR Mpixels/sec fwd only",
+            "metric": ("HR Mpixels/sec fwd+bwd (x4, 1 Gaussian/LR px); achieved HBM GB/s vs roofline" if args.config == "c2"
+                       else f"HR Mpixels/sec {'fwd only' if step.fwd_only else 'fwd+bwd'} (x{scale:g}, 1 Gaussian/LR px)"),
             "value": mpix, "unit": "HR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if step.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -283,7 +289,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -67,6 +67,7 @@ struct PlanView {
     unsigned *key;          // [s] class/cell of Gaussian i
     unsigned *rank;         // [s] position of Gaussian i inside its cell
     unsigned *blockmax;     // [2*nblk] per-classify-block max half-extents
+    unsigned *scan_tot;     // [ceil((ncells+2)/4096)] per-chunk totals of the two-pass scan
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
     float4 *fin;            // [2*s] backward epilogue constants + original index
     float *sums;            // [8*s] raw backward sums {Sx,Sy,Sxx,Sxy,Syy,Cr,Cg,Cb} per (cell-ordered) Gaussian
@@ -76,7 +77,7 @@ struct PlanView {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_rec, off_fin, off_sums, off_bbox;
+    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_bbox;
     size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
     size_t total;
     int ncx, ncy, ncells;
@@ -111,6 +112,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_key = o;    o += align_up(s * 4, 256);
     L.off_rank = o;   o += align_up(s * 4, 256);
     L.off_bmax = o;   o += align_up((size_t)classify_blocks(d) * 8, 256);
+    L.off_stot = o;   o += align_up((ncls / 4096 + 2) * 4, 256);
     L.off_rec = o;    o += align_up(s * 32, 256);
     L.off_fin = o;    o += align_up(s * 32, 256);
     L.off_sums = o;   o += align_up(s * 32, 256);
@@ -131,6 +133,7 @@ PlanView make_view(const Layout &L, void *ws)
     V.key = (unsigned *)(b + L.off_key);
     V.rank = (unsigned *)(b + L.off_rank);
     V.blockmax = (unsigned *)(b + L.off_bmax);
+    V.scan_tot = (unsigned *)(b + L.off_stot);
     V.rec = (float4 *)(b + L.off_rec);
     V.fin = (float4 *)(b + L.off_fin);
     V.sums = (float *)(b + L.off_sums);
@@ -340,6 +343,76 @@ __global__ __launch_bounds__(1024) void k_scan(int n, const unsigned *__restrict
         run += count[k];
     }
     if (t == 1023) start[n] = part[1023];
+}
+
+// Large grids (> 8192 cells): two-pass scan.  Pass 1: every block scans 4096 counts (4 per thread,
+// coalesced) and leaves its total in start_tot[b]; block 0 also reduces the max extents.  Pass 2: every
+// block adds the totals of the blocks before it (<= a few hundred values) to its 4096 entries.
+constexpr int SCAN_CHUNK = 4096;
+
+__global__ __launch_bounds__(1024) void k_scan_local(int n, const unsigned *__restrict__ count,
+                                                     unsigned *__restrict__ start, unsigned *__restrict__ tot,
+                                                     int nblk, const unsigned *__restrict__ blockmax,
+                                                     unsigned *__restrict__ hdr)
+{
+    __shared__ unsigned part[1024];
+    __shared__ unsigned smax[2][16];
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0) {
+        unsigned mx = 0, my = 0;
+        for (int k = t; k < nblk; k += 1024) {
+            mx = max(mx, blockmax[2 * k + 0]);
+            my = max(my, blockmax[2 * k + 1]);
+        }
+        mx = wave_max_u32(mx);
+        my = wave_max_u32(my);
+        if ((t & 63) == 0) { smax[0][t >> 6] = mx; smax[1][t >> 6] = my; }
+    }
+    const int base = blockIdx.x * SCAN_CHUNK + t * 4;
+    unsigned c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = base + k < n ? count[base + k] : 0u;
+    const unsigned sum = c[0] + c[1] + c[2] + c[3];
+    part[t] = sum;
+    __syncthreads();
+    if (blockIdx.x == 0 && t < 2) {
+        unsigned m = 0;
+        for (int k = 0; k < 16; ++k) m = max(m, smax[t][k]);
+        hdr[t] = m;
+    }
+    for (int o = 1; o < 1024; o <<= 1) {
+        unsigned v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = part[t] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) start[base + k] = run;
+        run += c[k];
+    }
+    if (t == 1023) tot[blockIdx.x] = part[1023];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_fix(int n, unsigned *__restrict__ start,
+                                                   const unsigned *__restrict__ tot, int nchunks)
+{
+    __shared__ unsigned s_off;
+    const int t = threadIdx.x;
+    if (t < 64) {  // one wave sums the totals of the preceding chunks
+        unsigned v = 0;
+        for (int k = t; k < (int)blockIdx.x; k += 64) v += tot[k];
+        for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o);
+        if (t == 0) s_off = v;
+    }
+    __syncthreads();
+    const unsigned off = s_off;
+    const int base = blockIdx.x * SCAN_CHUNK + t * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < n) start[base + k] += off;
+    if ((int)blockIdx.x == nchunks - 1 && t == 0) start[n] = off + tot[blockIdx.x];
 }
 
 // counting-sort placement (slot = cell start + rank, no atomics) fused with record packing
@@ -869,8 +942,16 @@ int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colo
     HIP_TRY(hipMemsetAsync(workspace, 0, L.zero_bytes, st));
     const int nblk = classify_blocks(dims);
     hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, L.ncells + 2, V.cell_count, V.cell_start, nblk,
-                       V.blockmax, V.hdr);
+    const int ncls = L.ncells + 2;
+    if (ncls <= 2 * SCAN_CHUNK) {
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start, nblk, V.blockmax,
+                           V.hdr);
+    } else {
+        const int nchunks = (ncls + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start,
+                           V.scan_tot, nblk, V.blockmax, V.hdr);
+        hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_start, V.scan_tot, nchunks);
+    }
     if (dims->s > 0)
         hipLaunchKernelGGL(k_bin, dim3((dims->s + 255) / 256), dim3(256), 0, st, P, sigmas, coords, colors, V);
     HIP_TRY(hipGetLastError());
