@@ -687,12 +687,23 @@ struct BwdRow {
     v2f m0, m1, m2, k01, k20, k12;  // moments; colour sums in the mixed pairing of two HWC pixels
 };
 
+struct Grad6 {  // the three gradient channels of the two pixels (rows Y, Y+RPI) a lane owns in one trip
+    float a0, a1, a2, b0, b1, b2;
+};
+
+__device__ __forceinline__ Grad6 bwd_load(const float *ga, const float *gb)
+{
+    Grad6 g;
+    g.a0 = ga[0]; g.a1 = ga[1]; g.a2 = ga[2];
+    g.b0 = gb[0]; g.b1 = gb[1]; g.b2 = gb[2];
+    return g;
+}
+
 template <bool TEST, bool TAIL>
-__device__ __forceinline__ void bwd_trip(BwdRow &R, const float *ga, const float *gb, v2f dy, bool ok1, bool ok2,
-                                         float adx2, float bdx, float C, float cr, float cg, float cb, float dmax)
+__device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dy, bool ok1, bool ok2, float adx2, float bdx,
+                                         float C, float cr, float cg, float cb, float dmax)
 {
     // six consecutive-in-memory floats per pixel pair are used as they land: no register shuffling
-    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
     const v2f t = C * dy + bdx;
     const v2f pw = dy * t + adx2;
     v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
@@ -700,14 +711,14 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const float *ga, const float
         v.x = ((!TAIL || ok1) && (!TEST || fabsf(dy.x) <= dmax)) ? v.x : 0.f;
         v.y = ((!TAIL || ok2) && (!TEST || fabsf(dy.y) <= dmax)) ? v.y : 0.f;
     }
-    const v2f gp = {fmaf(a2, cb, fmaf(a1, cg, a0 * cr)), fmaf(b2, cb, fmaf(b1, cg, b0 * cr))};  // gs.cu:150
+    const v2f gp = {fmaf(g.a2, cb, fmaf(g.a1, cg, g.a0 * cr)), fmaf(g.b2, cb, fmaf(g.b1, cg, g.b0 * cr))};  // gs.cu:150
     const v2f q = gp * v, qdy = q * dy;
     R.m0 += q;
     R.m1 += qdy;
     R.m2 += qdy * dy;
-    R.k01 += (v2f){a0, a1} * v.x;
-    R.k20 += (v2f){a2, b0} * v;
-    R.k12 += (v2f){b1, b2} * v.y;
+    R.k01 += (v2f){g.a0, g.a1} * v.x;
+    R.k20 += (v2f){g.a2, g.b0} * v;
+    R.k12 += (v2f){g.b1, g.b2} * v.y;
 }
 
 template <bool TEST, int LXLOG>
@@ -741,19 +752,21 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             const float *sp = spy + rsub;
             const char *rowp = reinterpret_cast<const char *>(grad + (size_t)(rb - P.row0) * rowpitch);
             const size_t halfb = (size_t)RPI * rowpitch * sizeof(float);
+            // full trips: no masks, no address clamps (manual software pipelining of the loads was measured
+            // 10% slower than letting the 8 resident waves per SIMD hide the latency)
             int Yb = rb;
             for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, rowp += 2 * halfb, sp += 2 * RPI)
-                bwd_trip<TEST, false>(R, reinterpret_cast<const float *>(rowp + voff),
-                                      reinterpret_cast<const float *>(rowp + halfb + voff), (v2f){sp[0], sp[RPI]}, true,
-                                      true, adx2, bdx, C, cr, cg, cb, P.dmax);
+                bwd_trip<TEST, false>(R, bwd_load(reinterpret_cast<const float *>(rowp + voff),
+                                                  reinterpret_cast<const float *>(rowp + halfb + voff)),
+                                      (v2f){sp[0], sp[RPI]}, true, true, adx2, bdx, C, cr, cg, cb, P.dmax);
             if (Yb <= rend) {  // ragged last trip: clamp the addresses, mask the rows past the window
                 const int Ya = Yb + rsub, Yc = Ya + RPI;
                 const bool ok1 = Ya <= rend, ok2 = Yc <= rend;
                 const float *glast = grad + (size_t)X * 3 + (size_t)(rend - P.row0) * rowpitch;
                 const float *ga = ok1 ? reinterpret_cast<const float *>(rowp + voff) : glast;
                 const float *gb = ok2 ? reinterpret_cast<const float *>(rowp + halfb + voff) : glast;
-                bwd_trip<TEST, true>(R, ga, gb, (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, ok1, ok2,
-                                     adx2, bdx, C, cr, cg, cb, P.dmax);
+                bwd_trip<TEST, true>(R, bwd_load(ga, gb), (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, ok1,
+                                     ok2, adx2, bdx, C, cr, cg, cb, P.dmax);
             }
         }
         const float M0 = R.m0.x + R.m0.y, M1 = R.m1.x + R.m1.y, M2 = R.m2.x + R.m2.y;
@@ -771,18 +784,19 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     }
 }
 
-// Sum eight per-lane values over the wave with 10 cross-lane exchanges instead of 48: at distances
-// 32/16/8 the lanes split the set of values between the two partners (4, 2, 1 exchanges), then three
-// plain butterfly steps.  Afterwards lane 8k holds the total of value k.
-__device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane)
+// Sum eight per-lane values over the wave through LDS: lanes park their 8 partials ([8][64] floats per wave),
+// lane l then adds the 8 consecutive partials {l&7} of value {l>>3} (two ds_read_b128) and three butterfly
+// steps finish inside each 8-lane group.  Afterwards lane 8k holds the total of value k.  ~14 VALU
+// instructions instead of ~45 for a register-only exchange network; the LDS pipe is otherwise idle here.
+__device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane, float *red)
 {
-    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-    float b[4], c[2];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] = (h5 ? a[k + 4] : a[k]) + __shfl_xor(h5 ? a[k] : a[k + 4], 32);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) c[k] = (h4 ? b[k + 2] : b[k]) + __shfl_xor(h4 ? b[k] : b[k + 2], 16);
-    float d = (h3 ? c[1] : c[0]) + __shfl_xor(h3 ? c[0] : c[1], 8);
+    for (int k = 0; k < 8; ++k) red[k * 64 + lane] = a[k];
+    __builtin_amdgcn_wave_barrier();
+    const float4 u = *reinterpret_cast<const float4 *>(red + lane * 8);
+    const float4 v = *reinterpret_cast<const float4 *>(red + lane * 8 + 4);
+    float d = ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
     d += __shfl_xor(d, 4);
     d += __shfl_xor(d, 2);
     d += __shfl_xor(d, 1);
@@ -791,7 +805,7 @@ __device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane)
 
 template <bool BOUNDED>
 __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int lane, const Params &P,
-                                         const PlanView &V, const float *__restrict__ grad, float *spy)
+                                         const PlanView &V, const float *__restrict__ grad, float *spy, float *red)
 {
     const uint4 bb = V.bbox[j];  // wave-uniform: scalar loads
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
@@ -807,6 +821,15 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
     const float x = ra.x, y = ra.y, A = ra.z, B = ra.w, cr = rb.x, cg = rb.y, cb = rb.z, C = rb.w;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int bw = c1 - c0 + 1;
+    if (chunk < 0) {  // (row chunks of a large Gaussian must not overlap: they keep their ragged tail)
+        // Round the row count up to a whole number of trips (8/4/2 rows for 16/32/64-lane columns) when the
+        // band has room: the extra rows lie outside the window (their terms are < exp(-tau), or fail the
+        // dmax test), and the ragged, masked last trip disappears.
+        const int rows_per_trip = bw <= 16 ? 8 : (bw <= 32 ? 4 : 2);
+        const int pad = (rows_per_trip - ((r1 - r0 + 1) & (rows_per_trip - 1))) & (rows_per_trip - 1);
+        if (r1 + pad <= P.row1 - 1) r1 += pad;
+        else if (r0 - pad >= P.row0) r0 -= pad;
+    }
     const bool test = BOUNDED && (bb.x & 0x8000u);
 #define GSASR_SWEEP(T, L) bwd_sweep<T, L>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, A, B, C, cr, cg, cb, spy, a)
     if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
@@ -815,7 +838,7 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
 #undef GSASR_SWEEP
     // lane 8k now holds raw sum k: one 32-byte store per Gaussian; the Gaussian-constant factors are applied
     // by k_bwd_finalize, vectorised over Gaussians (64 per wave instead of one)
-    const float d = wave_sum8(a, lane);
+    const float d = wave_sum8(a, lane, red);
     if ((lane & 7) == 0) {
         float *o = V.sums + 8 * (size_t)j + (lane >> 3);
         if (atomic) atomicAdd(o, d); else *o = d;
@@ -873,21 +896,25 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     const unsigned nb = gridDim.x, b = blockIdx.x;
     const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
     const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
-    const unsigned gw = t * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned gw = t * 4u + (unsigned)wv;
     const unsigned nwaves = nb * 4u;
     __shared__ float s_py[4][64];
-    float *spy = s_py[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    __shared__ __attribute__((aligned(16))) float s_red[4][512];
+    float *spy = s_py[wv], *red = s_red[wv];
     const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
+    // one Gaussian per wave, dispatched by the hardware (a persistent-workgroup variant with a static
+    // partition was measured 13% slower at config 2 and 60% slower at config 3: load imbalance)
     if (gw < large_beg)
-        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, spy);
+        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, spy, red);
     else if (gw < large_end)
-        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, spy);
+        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, spy, red);
     // remaining row chunks of the large class, spread over all waves
     const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
     for (unsigned it = gw; it < extra; it += nwaves) {
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
-        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, spy);
+        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, spy, red);
     }
 }
 
