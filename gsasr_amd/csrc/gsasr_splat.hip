@@ -575,26 +575,27 @@ __device__ __forceinline__ bool fwd_advance(int &sg, unsigned &bs, unsigned &en,
     return true;
 }
 
-template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float *__restrict__ img, int tiles_x,
-                                                    int tiles_y)
+// next chunk that belongs to this wave when the chunks of a sub-tile are dealt round-robin to `nparts` waves
+__device__ __forceinline__ bool fwd_advance_own(int &sg, unsigned &bs, unsigned &en, int nseg, unsigned sbeg,
+                                                unsigned send, unsigned &cnt, unsigned part, unsigned nparts)
 {
-    // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b%8), so give
-    // each XCD a contiguous band of tile rows: neighbouring tiles then share records in ONE L2.
-    const unsigned nb = gridDim.x, b = blockIdx.x;
-    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
-    const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
-    const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
-    (void)tiles_y;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id is uniform: keep it in an SGPR
-    const int sx0 = (bx * 4 + wv) * SUBX, sy0 = P.row0 + by * SUBY;
-    if (sx0 >= P.w) return;  // wave-uniform
+    for (;;) {
+        if (!fwd_advance(sg, bs, en, nseg, sbeg, send)) return false;
+        if (cnt++ % nparts == part) return true;
+    }
+}
+
+// One wave, one 8x16 sub-tile at (sx0, sy0): accumulate every Gaussian binned near it into ar/ag/ab
+// (lane = column sx0 + lane%8, rows sy0 + lane/8 and +8).  With nparts > 1 the 64-candidate chunks are
+// dealt round-robin to `nparts` waves and the caller adds their partial sums.
+template <bool BOUNDED>
+__device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int sx0, int sy0, int lane,
+                                         unsigned part, unsigned nparts, v2f &ar, v2f &ag, v2f &ab)
+{
     const int sx1 = min(sx0 + SUBX - 1, P.w - 1), sy1 = min(sy0 + SUBY - 1, P.row1 - 1);
     const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
     const float px = V.px[min(X, P.w - 1)];
     const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y1, P.h - 1)]};
-    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
 
     const float4 *__restrict__ rec = V.rec;
     const uint4 *__restrict__ bbox = V.bbox;
@@ -625,15 +626,15 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
     // Flat walk over 64-candidate chunks of all segments, software-pipelined: the window record of the
     // NEXT chunk is in flight while the hits of the current one are evaluated.
     int seg = -1;
-    unsigned base = 0, end = 0;
+    unsigned base = 0, end = 0, cnt = 0;
     const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
-    bool live = fwd_advance(seg, base, end, nseg, sbeg, send);
+    bool live = fwd_advance_own(seg, base, end, nseg, sbeg, send, cnt, part, nparts);
     uint4 bb = dead;
     if (live && base + (unsigned)lane < end) bb = bbox[base + (unsigned)lane];
     while (live) {
         int nseg_i = seg;
         unsigned nbase = base, nend = end;
-        const bool nlive = fwd_advance(nseg_i, nbase, nend, nseg, sbeg, send);
+        const bool nlive = fwd_advance_own(nseg_i, nbase, nend, nseg, sbeg, send, cnt, part, nparts);
         uint4 nbb = dead;
         if (nlive && nbase + (unsigned)lane < nend) nbb = bbox[nbase + (unsigned)lane];
 
@@ -655,6 +656,12 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
         }
         seg = nseg_i; base = nbase; end = nend; live = nlive; bb = nbb;
     }
+}
+
+__device__ __forceinline__ void fwd_store(const Params &P, float *__restrict__ img, int sx0, int sy0, int lane,
+                                          v2f ar, v2f ag, v2f ab)
+{
+    const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
     if (X < P.w) {
         const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
         if (Y0 < P.row1) {
@@ -667,6 +674,61 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
             if (store) { o[0] = ar.y; o[1] = ag.y; o[2] = ab.y; }
             else { o[0] += ar.y; o[1] += ag.y; o[2] += ab.y; }
         }
+    }
+}
+
+// XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b%8), so give each XCD
+// a contiguous band of tile rows: neighbouring tiles then share records in ONE L2.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nb)
+{
+    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
+    return xcd * q + min(xcd, r) + (b >> 3);
+}
+
+// Large images: a workgroup = four sub-tiles side by side (32x16 px), one wave each.
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float *__restrict__ img, int tiles_x,
+                                                    int tiles_y)
+{
+    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
+    (void)tiles_y;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id is uniform: keep it in an SGPR
+    const int sx0 = (bx * 4 + wv) * SUBX, sy0 = P.row0 + by * SUBY;
+    if (sx0 >= P.w) return;  // wave-uniform
+    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
+    fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, 0u, 1u, ar, ag, ab);
+    fwd_store(P, img, sx0, sy0, lane, ar, ag, ab);
+}
+
+// Small images (fewer sub-tiles than the chip has wave slots, e.g. the 192x192 training crops of
+// BASELINE config 5): a workgroup = ONE sub-tile, its candidate chunks dealt to all `blockDim/64` waves,
+// partial sums combined through LDS.  Parallelism comes from the Gaussian list instead of from pixels.
+template <bool BOUNDED>
+__global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V, float *__restrict__ img, int subs_x)
+{
+    __shared__ float s_part[16][6][64];
+    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int sx0 = (int)(t % (unsigned)subs_x) * SUBX, sy0 = P.row0 + (int)(t / (unsigned)subs_x) * SUBY;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
+    fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, (unsigned)wv, (unsigned)nw, ar, ag, ab);
+    if (wv > 0) {
+        s_part[wv][0][lane] = ar.x; s_part[wv][1][lane] = ar.y;
+        s_part[wv][2][lane] = ag.x; s_part[wv][3][lane] = ag.y;
+        s_part[wv][4][lane] = ab.x; s_part[wv][5][lane] = ab.y;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        for (int k = 1; k < nw; ++k) {
+            ar.x += s_part[k][0][lane]; ar.y += s_part[k][1][lane];
+            ag.x += s_part[k][2][lane]; ag.y += s_part[k][3][lane];
+            ab.x += s_part[k][4][lane]; ab.y += s_part[k][5][lane];
+        }
+        fwd_store(P, img, sx0, sy0, lane, ar, ag, ab);
     }
 }
 
@@ -995,13 +1057,27 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     if (!img) return fail(GSASR_ERR_ARG, "null image pointer");
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, const_cast<void *>(workspace));
-    const int tiles_x = (dims->w + 4 * SUBX - 1) / (4 * SUBX), tiles_y = (rows + SUBY - 1) / SUBY;
-    const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(256);
+    const int subs_x = (dims->w + SUBX - 1) / SUBX, tiles_y = (rows + SUBY - 1) / SUBY;
+    const int tiles_x = (subs_x + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
-    if (P.bounded)
-        hipLaunchKernelGGL(k_render_fwd<true>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
-    else
-        hipLaunchKernelGGL(k_render_fwd<false>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
+    const long nsub = (long)subs_x * tiles_y;
+    if (nsub < 4096) {
+        // fewer sub-tiles than half the chip's 8192 wave slots: split each sub-tile's Gaussian list over
+        // 2..16 waves so that about one full set of waves is in flight
+        int nw = 2;
+        while (nw < 16 && nsub * nw < 8192) nw *= 2;
+        const dim3 grid((unsigned)nsub), block((unsigned)nw * 64u);
+        if (P.bounded)
+            hipLaunchKernelGGL(k_render_fwd_split<true>, grid, block, 0, st, P, V, img, subs_x);
+        else
+            hipLaunchKernelGGL(k_render_fwd_split<false>, grid, block, 0, st, P, V, img, subs_x);
+    } else {
+        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(256);
+        if (P.bounded)
+            hipLaunchKernelGGL(k_render_fwd<true>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL(k_render_fwd<false>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
+    }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }
