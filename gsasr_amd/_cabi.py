@@ -20,7 +20,7 @@ EXPORTS = (
     "gsasr_abi_version", "gsasr_last_error", "gsasr_splat_workspace_bytes", "gsasr_splat_plan",
     "gsasr_splat_forward", "gsasr_splat_backward", "gsasr_gs_render", "gsasr_gs_render_backward",
     "gsasr_gs_render_dmax", "gsasr_gs_render_backward_dmax", "gsasr_set_default_cutoff",
-    "gsasr_get_default_cutoff",
+    "gsasr_get_default_cutoff", "gsasr_prologue_forward", "gsasr_prologue_backward",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -68,6 +68,10 @@ def lib():
         L.gsasr_gs_render_dmax.argtypes = [vp, vp, vp, vp, i, i, i, i, f, vp]
         L.gsasr_gs_render_backward_dmax.restype = i
         L.gsasr_gs_render_backward_dmax.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp]
+        L.gsasr_prologue_forward.restype = i
+        L.gsasr_prologue_forward.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp]
+        L.gsasr_prologue_backward.restype = i
+        L.gsasr_prologue_backward.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp]
         L.gsasr_set_default_cutoff.restype = None
         L.gsasr_set_default_cutoff.argtypes = [f]
         L.gsasr_get_default_cutoff.restype = f
@@ -172,6 +176,30 @@ def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_co
     with torch.cuda.device(p.device):
         check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
+
+
+def prologue_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int):
+    """gs_parameters[N,9] (raw decoder output) -> kernel-frame (sigmas[N,3], coords[N,2], colors[N,3])."""
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(step, "step_size")
+    n, dev = gs_parameters.shape[0], gs_parameters.device
+    out = (torch.empty(n, 3, device=dev), torch.empty(n, 2, device=dev), torch.empty(n, 3, device=dev))
+    with torch.cuda.device(dev):
+        check(lib().gsasr_prologue_forward(pp, ps, n, int(h), int(w), out[0].data_ptr(), out[1].data_ptr(),
+                                           out[2].data_ptr(), _stream(dev)), "gsasr_prologue_forward")
+    return out
+
+
+def prologue_backward(gs_parameters, step, h: int, w: int, g_sigmas, g_coords, g_colors) -> torch.Tensor:
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(step, "step_size")
+    ptrs = [_chk(g_sigmas, "g_sigmas", (3,)), _chk(g_coords, "g_coords", (2,)), _chk(g_colors, "g_colors", (3,))]
+    n, dev = gs_parameters.shape[0], gs_parameters.device
+    gp = torch.empty(n, 9, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().gsasr_prologue_backward(pp, ps, n, int(h), int(w), *ptrs, gp.data_ptr(), _stream(dev)),
+              "gsasr_prologue_backward")
+    return gp
 
 
 def set_default_cutoff(tau: float) -> None:

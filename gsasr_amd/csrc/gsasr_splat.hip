@@ -965,6 +965,60 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// fused host prologue (reference utils/gaussian_splatting.py:174-180 and :121-123) and its backward
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void k_prologue_fwd(const float *__restrict__ p, const float *__restrict__ step_ptr,
+                                                      int n, int h, int w, float *__restrict__ sigmas,
+                                                      float *__restrict__ coords, float *__restrict__ colors)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float step = step_ptr[0];
+    const float *q = p + (size_t)i * 9;
+    const float sx = 0.99999f * sigmoidf_(q[0]) + 1e-6f;  // the network's sigma_x is the ROW std
+    const float sy = 0.99999f * sigmoidf_(q[1]) + 1e-6f;
+    const float rho = 0.999999f * tanhf(q[2]);
+    const float alpha = sigmoidf_(q[3]);
+    const float W = (float)w, H = (float)h;
+    sigmas[i * 3 + 0] = sy / step * 2.f / (W - 1.f);     // kernel's first sigma pairs with WIDTH (:121)
+    sigmas[i * 3 + 1] = sx / step * 2.f / (H - 1.f);
+    sigmas[i * 3 + 2] = rho;
+    const float c0 = q[7] * 2.f - 1.f, c1 = q[8] * 2.f - 1.f;
+    coords[i * 2 + 0] = (c0 + 1.f - 1.f / W) * W / (W - 1.f) - 1.f;   // align_corners=False -> True (:122-123)
+    coords[i * 2 + 1] = (c1 + 1.f - 1.f / H) * H / (H - 1.f) - 1.f;
+    colors[i * 3 + 0] = sigmoidf_(q[4]) * alpha;
+    colors[i * 3 + 1] = sigmoidf_(q[5]) * alpha;
+    colors[i * 3 + 2] = sigmoidf_(q[6]) * alpha;
+}
+
+__global__ __launch_bounds__(256) void k_prologue_bwd(const float *__restrict__ p, const float *__restrict__ step_ptr,
+                                                      int n, int h, int w, const float *__restrict__ gs,
+                                                      const float *__restrict__ gc, const float *__restrict__ gk,
+                                                      float *__restrict__ gp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float step = step_ptr[0];
+    const float *q = p + (size_t)i * 9;
+    const float W = (float)w, H = (float)h;
+    const float s0 = sigmoidf_(q[0]), s1 = sigmoidf_(q[1]), th = tanhf(q[2]), al = sigmoidf_(q[3]);
+    const float r = sigmoidf_(q[4]), g = sigmoidf_(q[5]), b = sigmoidf_(q[6]);
+    float *o = gp + (size_t)i * 9;
+    o[0] = gs[i * 3 + 1] * (2.f / (H - 1.f) / step) * 0.99999f * s0 * (1.f - s0);
+    o[1] = gs[i * 3 + 0] * (2.f / (W - 1.f) / step) * 0.99999f * s1 * (1.f - s1);
+    o[2] = gs[i * 3 + 2] * 0.999999f * (1.f - th * th);
+    const float k0 = gk[i * 3 + 0], k1 = gk[i * 3 + 1], k2 = gk[i * 3 + 2];
+    o[3] = (k0 * r + k1 * g + k2 * b) * al * (1.f - al);
+    o[4] = k0 * al * r * (1.f - r);
+    o[5] = k1 * al * g * (1.f - g);
+    o[6] = k2 * al * b * (1.f - b);
+    o[7] = gc[i * 2 + 0] * 2.f * W / (W - 1.f);
+    o[8] = gc[i * 2 + 1] * 2.f * H / (H - 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 #define HIP_TRY(expr)                                    \
@@ -1093,6 +1147,32 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
         hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, grad_img);
     hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((dims->s + 255) / 256)), block, 0, st, P, V, g_sigmas, g_coords,
                        g_colors);
+    HIP_TRY(hipGetLastError());
+    return GSASR_OK;
+}
+
+int gsasr_prologue_forward(const float *gs_parameters, const float *step_size, int n, int h, int w, float *sigmas,
+                           float *coords, float *colors, void *stream)
+{
+    if (n < 0 || h < 2 || w < 2) return fail(GSASR_ERR_ARG, "bad n/h/w");
+    if (n == 0) return GSASR_OK;
+    if (!gs_parameters || !step_size || !sigmas || !coords || !colors) return fail(GSASR_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_prologue_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       gs_parameters, step_size, n, h, w, sigmas, coords, colors);
+    HIP_TRY(hipGetLastError());
+    return GSASR_OK;
+}
+
+int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, int n, int h, int w,
+                            const float *g_sigmas, const float *g_coords, const float *g_colors, float *g_parameters,
+                            void *stream)
+{
+    if (n < 0 || h < 2 || w < 2) return fail(GSASR_ERR_ARG, "bad n/h/w");
+    if (n == 0) return GSASR_OK;
+    if (!gs_parameters || !step_size || !g_sigmas || !g_coords || !g_colors || !g_parameters)
+        return fail(GSASR_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_prologue_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       gs_parameters, step_size, n, h, w, g_sigmas, g_coords, g_colors, g_parameters);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }

@@ -96,6 +96,19 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
                          float *g_coords, float *g_colors, const gsasr_dims *dims,
                          const void *workspace, size_t workspace_bytes, void *stream);
 
+/* Fused host prologue of the path: raw decoder output gs_parameters[n,9] =
+ * [sigma_x, sigma_y, rho, alpha, r, g, b, mu_x, mu_y] -> the kernel-frame tensors handed to the splat,
+ * i.e. the activations of utils/gaussian_splatting.py:174-180 followed by the conversion of :121-123
+ * (x/y swap of the sigmas, align-corners fix of the means, colour * alpha) in ONE kernel instead of ~15
+ * elementwise launches.  `step_size` points at one float in DEVICE memory (default_step_size / scale, which
+ * the reference holds as a 0-dim tensor), so no host sync is needed.  The backward applies the chain rule
+ * and overwrites g_parameters[n,9]. */
+int gsasr_prologue_forward(const float *gs_parameters, const float *step_size, int n, int h, int w,
+                           float *sigmas, float *coords, float *colors, void *stream);
+int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, int n, int h, int w,
+                            const float *g_sigmas, const float *g_coords, const float *g_colors,
+                            float *g_parameters, void *stream);
+
 /* Reference-shaped launchers (allocate their scratch stream-ordered, plan, run, free). */
 int gsasr_gs_render(const float *sigmas, const float *coords, const float *colors,
                     float *rendered_img, int s, int h, int w, int c, void *stream);

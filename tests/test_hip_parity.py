@@ -230,6 +230,40 @@ def test_host_api_end_to_end_matches_oracle(dev):
         assert _relmax(pg.grad.cpu().numpy(), pr.grad.numpy()) <= GRAD_RTOL
 
 
+def test_fused_prologue_matches_unfused_torch_path(dev):
+    """row f1: `gsasr_prologue_forward/backward` == the torch expression of the reference prologue (and its
+    autograd), and the fused `generate_2D_gaussian_splatting_step` == the unfused renderers."""
+    from gsasr_amd import _cabi, gaussian_splatting as gsp, synthetic
+    p = synthetic.gs_parameters(20, 28, seed=65).to(dev)
+    p[3] = torch.tensor([9.0, -9.0, 6.0, -7.0, 8.0, -8.0, 0.0, 0.3, 0.9], device=dev)   # saturated activations
+    H, W, scale = 60, 84, 3.0
+    step = torch.tensor([1.2 / scale], device=dev)
+    sig, xy, col = _cabi.prologue_forward(p, step, H, W)
+    pr = p.clone().requires_grad_(True)
+    sx, sy, rho, cxy, cwa = gsp._activate(pr)
+    s2, x2, c2, _, _ = gsp._to_kernel_frame(sx, sy, rho, cxy, cwa, (H, W), 1.2 / scale)
+    for a, b in ((sig, s2), (xy, x2), (col, c2)):
+        assert float((a - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(b.detach().abs().max()))
+    g = [torch.rand_like(t) for t in (sig, xy, col)]
+    torch.autograd.backward([s2, x2, c2], g)
+    gp = _cabi.prologue_backward(p, step, H, W, *g)
+    assert float((gp - pr.grad).abs().max()) <= 2e-6 * float(pr.grad.abs().max())
+    # end to end: fused step vs unfused renderer, forward and gradient w.r.t. the raw parameters
+    wgt = synthetic.grad_image(H, W, 66, device=dev).permute(2, 0, 1)
+    sm = torch.tensor([scale, scale], device=dev)
+    for kw in (dict(if_dmax=True, dmax=0.3), dict(if_dmax=False)):
+        pa = p.clone().requires_grad_(True)
+        out = gsp.generate_2D_gaussian_splatting_step((H, W), pa, scale, sm, **kw)
+        (out * wgt).sum().backward()
+        pb = p.clone().requires_grad_(True)
+        a5 = gsp._activate(pb)
+        st = gsp._step_size(scale, sm, 1.2, "scale_modify")
+        ref = gsp.rendering_cuda_dmax(*a5, (H, W), st, dev, dmax=0.3) if kw["if_dmax"] else gsp.rendering_cuda(*a5, (H, W), st, dev)
+        (ref * wgt).sum().backward()
+        assert float((out - ref).abs().max()) <= 1e-5
+        assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * float(pb.grad.abs().max())
+
+
 def test_gscuda_module_reference_shaped_entry_points(dev):
     """`gscuda.gs_render / gs_render_backward` (pybind surface, gswrapper.cpp:9-71): stateless launchers,
     dmax backward adds into caller-zeroed outputs, unbounded backward overwrites."""
