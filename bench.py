@@ -115,9 +115,11 @@ class Step:
                 self.gpad[: self.n, 5:8] = self.g[2]
                 dist.reduce_scatter_tensor(self.gmine, self.gpad)    # per-Gaussian grads, summed over bands
 
-    # algorithmic bytes: fwd = 32 N + 24 H W, bwd = 64 N + 12 H W  (per rank: own rows)
+    # algorithmic bytes: fwd = 32 N + 24 H W with the reference's accumulate-into contract; the
+    # step stores into a fresh image (GSASR_FLAG_OVERWRITE_IMAGE), so the image is written once and never read:
+    # fwd = 32 N + 12 H W.  bwd = 64 N + 12 H W.  (per rank: own rows)
     def bytes_fwd(self):
-        return 32 * self.n + 24 * (self.rows[1] - self.rows[0]) * self.W
+        return 32 * self.n + 12 * (self.rows[1] - self.rows[0]) * self.W
 
     def bytes_bwd(self):
         return 64 * self.n + 12 * (self.rows[1] - self.rows[0]) * self.W
