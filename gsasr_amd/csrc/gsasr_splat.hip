@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
         // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
         const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
-        if (P.kcut > 0.f && ty1 - ty0 < 4) {
+        if (P.kcut > 0.f && ty1 - ty0 < 4 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
             const double spx = dsx * hx, spy = dsy * hy;                  // sigmas in pixels
             const double cxp = ((double)x + 1.0) * hx, cyp = ((double)y + 1.0) * hy;
             const double tau = 0.5 * (double)P.kcut * (double)P.kcut;
@@ -901,8 +901,14 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, floa
     const bool store = P.flags & GSASR_FLAG_OVERWRITE_GRADS;
     const bool dead = j >= V.cell_start[P.ncells + 1];  // dead class: never swept, sums undefined
     if (dead && !store) return;
+    if (dead) {  // zero gradient (the epilogue constants of a non-finite Gaussian are not usable)
+        const unsigned i = __float_as_uint(V.fin[2 * (size_t)j + 1].w);
+        float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
+        os[0] = os[1] = os[2] = op[0] = op[1] = oc[0] = oc[1] = oc[2] = 0.f;
+        return;
+    }
     float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
-    if (!dead) {
+    {
         sa = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j];
         sb = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j + 1];
         if (j >= V.cell_start[P.ncells]) {  // large class: leave the atomic accumulators zeroed for the next backward
@@ -951,6 +957,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
     // one Gaussian per wave, dispatched by the hardware (a persistent-workgroup variant with a static
     // partition was measured 13% slower at config 2 and 60% slower at config 3: load imbalance)
+    // (two or four Gaussians per wave, one after the other, measured the same: wave launch is not the cost)
     if (gw < large_beg)
         bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, spy, red);
     else if (gw < large_end)

@@ -412,3 +412,39 @@ def test_config3_inference_shape_properties(dev):
     assert float((band - full[3000:3100]).abs().max()) <= 1e-5
     ref = gs_oracle.forward_f64(sig.cpu().numpy(), xy.cpu().numpy(), col.cpu().numpy(), H, W, 0.1, rows=(3000, 3016))
     assert np.abs(full[3000:3016].cpu().numpy() - ref).max() <= IMG_ATOL
+
+
+def test_thin_wide_gaussians_beyond_span_encoding(dev):
+    """a Gaussian wider than 255 tile columns (2040 px) but only a few rows tall: the 8-bit tile spans cannot
+    encode it and the kernel must fall back to the plain window test"""
+    from oracle import gs_oracle
+    from gsasr_amd.shard import HipBackend
+    H, W = 40, 4200
+    sig = torch.tensor([[0.6, 0.02, 0.0], [0.9, 0.05, 0.3], [0.01, 0.01, 0.0]], device=dev)
+    xy = torch.tensor([[0.0, 0.0], [0.4, -0.3], [-0.7, 0.5]], device=dev)
+    col = torch.tensor([[1.0, 0.5, 0.25], [0.3, 0.6, 0.9], [0.2, 0.2, 0.2]], device=dev)
+    for dmax in (None, 0.8):
+        img, st = HipBackend.forward(sig, xy, col, H, W, dmax, (0, H))
+        ref = gs_oracle.forward_f64(sig.cpu().numpy(), xy.cpu().numpy(), col.cpu().numpy(), H, W, dmax)
+        assert np.abs(img.cpu().numpy() - ref).max() <= IMG_ATOL
+        wgt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+        g = HipBackend.backward(st, sig, xy, col, wgt)
+        gref = gs_oracle.backward_f64(sig.cpu().numpy(), xy.cpu().numpy(), col.cpu().numpy(), wgt.cpu().numpy(), dmax)
+        for a, b in zip(g, gref):
+            assert _relmax(a.cpu().numpy(), b) <= GRAD_RTOL
+
+
+def test_non_finite_parameters_are_ignored_not_propagated(dev):
+    """NaN/Inf Gaussians are classified dead (documented difference: the reference would smear NaN over the box)"""
+    from gsasr_amd import synthetic
+    from gsasr_amd.shard import HipBackend
+    sig, xy, col, H, W = synthetic.kernel_inputs(16, 16, 4.0, seed=95, device=dev)
+    ref, _ = HipBackend.forward(sig, xy, col, H, W, 0.3, (0, H))
+    sig2, xy2 = sig.clone(), xy.clone()
+    keep = torch.ones(sig.shape[0], dtype=torch.bool, device=dev)
+    sig2[3, 0] = float("nan"); xy2[9, 1] = float("inf"); sig2[20, 1] = float("inf"); keep[[3, 9, 20]] = False
+    out, st = HipBackend.forward(sig2, xy2, col, H, W, 0.3, (0, H))
+    sub, _ = HipBackend.forward(sig[keep].contiguous(), xy[keep].contiguous(), col[keep].contiguous(), H, W, 0.3, (0, H))
+    assert torch.isfinite(out).all() and float((out - sub).abs().max()) <= 1e-5
+    g = HipBackend.backward(st, sig2, xy2, col, torch.ones(H, W, 3, device=dev))
+    assert all(torch.isfinite(t).all() for t in g) and float(g[0][3].abs().sum()) == 0.0
