@@ -5,27 +5,33 @@
 //   forward : img[p,:] += sum_s [|dx|<=dmax & |dy|<=dmax] exp(w1_s * q_s(p)) * colors[s,:]
 //   backward: analytic gradient of sum(grad_img * img) w.r.t. sigmas[s,3], coords[s,2], colors[s,3]
 //
-// Pipeline (all on the caller's stream, no host sync):
-//   plan     k_classify  per Gaussian: pixel bounding box of (dmax box  ∩  sigma*sqrt(2 tau) support box),
-//                        class {normal -> 16x16-px cell of its centre | large | dead}, rank in its cell
-//                        (one returning atomic per wave and distinct cell),
-//                        max extent of the normal class; also the px/py pixel-coordinate tables
+// Pipeline (all on the caller's stream, no host sync; DESIGN.md has the measurements):
+//   plan     k_classify  per Gaussian: pixel window of (dmax box  ∩  sigma*sqrt(2 tau) support box), tight to
+//                        the pixel; class {normal -> 16x16-px cell of its centre | large | dead}; rank in
+//                        its cell (one returning atomic per wave and distinct cell, one round trip);
+//                        per-block max extent of the normal class; the px/py pixel-coordinate tables
 //                        (double expression rounded to float, as gs.cu:27-28 does per pixel).
-//            k_scan      exclusive scan of the cell histogram + max-extent reduction (one workgroup).
-//            k_bin       counting-sort scatter into cell order fused with packing: 32-byte records
-//                        {x, y, A, B, C, r, g, b} (A,B,C = exponent coefficients with log2(e) folded,
-//                        computed in double), backward-epilogue constants, 8-byte pixel bboxes.
+//            k_scan      exclusive scan of the cell histogram + max-extent reduction (one workgroup;
+//                        k_scan_local + k_scan_fix for grids above 8192 cells).
+//            k_bin       counting-sort placement (cell start + rank) fused with packing: 32-byte records
+//                        {x, y, A, B, r, g, b, C} (A,B,C = exponent coefficients with log2(e) folded,
+//                        computed in double), backward-epilogue constants, 16-byte windows with the
+//                        per-tile-band column spans of the ellipse {exponent >= -tau}.
 //   forward  k_render_fwd  PIXEL-stationary: one wave64 = one 8x16 pixel sub-tile (2 px per lane, packed
-//                        fp32), RGB accumulators in registers.  The wave walks the cell rows within the class' max extent; 64
-//                        candidates are box-tested at once (one per lane, 8-byte bbox), the hit mask is
-//                        a ballot in SGPRs, and each hit's record is fetched with SCALAR loads (wave-
-//                        uniform data belongs in SGPRs on CDNA) -- no LDS, no atomics, one coalesced
-//                        read-modify-write of the tile at the end.
-//   backward k_render_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian, lanes sweep the pixels of
-//                        its box reading grad_img (L1/L2 resident), five moment sums + three colour sums
-//                        in registers, ONE DPP wave reduction per Gaussian, plain store of the 8 grads
-//                        (no atomics, deterministic).  Gaussians of the "large" class are split into
-//                        row chunks spread over all waves and combined with fp32 atomics.
+//                        fp32), RGB accumulators in registers.  The wave walks the cell rows within the
+//                        class' max extent in 64-candidate chunks (window + span test, one per lane), compacts
+//                        the hits' records into a per-wave LDS stage and evaluates them from broadcast
+//                        LDS reads; no atomics, one coalesced store / read-modify-write of the tile.
+//            k_render_fwd_split   same per-wave code for small images: one sub-tile per workgroup, its
+//                        chunks dealt to 2..16 waves, partial sums combined through LDS.
+//   backward k_render_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian, lanes laid 16/32/64 wide over its
+//                        window, two rows per trip (packed fp32), grad_img through L1/L2, three row
+//                        moments + three colour sums per lane, one LDS wave reduction, raw sums stored.
+//                        Gaussians of the "large" class are split into row chunks spread over all waves
+//                        and combined with fp32 atomics.
+//            k_bwd_finalize  Gaussian-constant factors applied once per Gaussian (one thread each).
+//   prologue k_prologue_fwd/bwd  the reference's host prologue (activations + kernel frame) and its
+//                        chain rule as one kernel each.
 //
 // No MFMA: this is gather/scatter-accumulate with one transcendental per pair, not a contraction.
 #include <hip/hip_runtime.h>
