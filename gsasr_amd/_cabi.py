@@ -25,6 +25,7 @@ EXPORTS = (
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
 FLAG_OVERWRITE_GRADS = 4   # GSASR_FLAG_OVERWRITE_GRADS
+FLAG_CHW_IMAGE = 8         # GSASR_FLAG_CHW_IMAGE
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -153,12 +154,14 @@ def _dims_with(p: Plan, extra_flags: int) -> Dims:
     return d
 
 
-def forward(p: Plan, img: torch.Tensor, overwrite: bool = False) -> torch.Tensor:
-    """img += splat (reference contract), or img = splat when `overwrite` (img may be torch.empty)."""
-    pi = _chk(img, "rendered_img", (p.dims.w, 3))
-    if img.shape[0] != p.dims.row1 - p.dims.row0 or img.device != p.device:
-        raise RuntimeError("rendered_img does not match the plan (rows / device)")
-    d = _dims_with(p, FLAG_OVERWRITE_IMAGE if overwrite else 0)
+def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = False) -> torch.Tensor:
+    """img += splat (reference contract), or img = splat when `overwrite` (img may be torch.empty).
+    `chw`: img is planar [3, rows, W] instead of [rows, W, 3]."""
+    rows = p.dims.row1 - p.dims.row0
+    pi = _chk(img, "rendered_img", (rows, p.dims.w) if chw else (p.dims.w, 3))
+    if (img.shape[0] != (3 if chw else rows)) or img.dim() != 3 or img.device != p.device:
+        raise RuntimeError("rendered_img does not match the plan (shape / device)")
+    d = _dims_with(p, (FLAG_OVERWRITE_IMAGE if overwrite else 0) | (FLAG_CHW_IMAGE if chw else 0))
     with torch.cuda.device(p.device):
         check(lib().gsasr_splat_forward(ctypes.byref(d), p.workspace.data_ptr(), p.workspace.numel(), pi,
                                         _stream(p.device)), "gsasr_splat_forward")

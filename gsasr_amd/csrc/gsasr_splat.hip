@@ -650,18 +650,31 @@ __device__ __forceinline__ void fwd_store(const Params &P, float *__restrict__ i
                                           v2f ar, v2f ag, v2f ab)
 {
     const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
-    if (X < P.w) {
-        const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
+    if (X >= P.w) return;
+    const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
+    if (P.flags & GSASR_FLAG_CHW_IMAGE) {  // planar [3, rows, w]
+        const size_t plane = (size_t)(P.row1 - P.row0) * P.w;
         if (Y0 < P.row1) {
-            float *o = img + ((size_t)(Y0 - P.row0) * P.w + X) * 3;
-            if (store) { o[0] = ar.x; o[1] = ag.x; o[2] = ab.x; }
-            else { o[0] += ar.x; o[1] += ag.x; o[2] += ab.x; }
+            float *o = img + (size_t)(Y0 - P.row0) * P.w + X;
+            if (store) { o[0] = ar.x; o[plane] = ag.x; o[2 * plane] = ab.x; }
+            else { o[0] += ar.x; o[plane] += ag.x; o[2 * plane] += ab.x; }
         }
         if (Y1 < P.row1) {
-            float *o = img + ((size_t)(Y1 - P.row0) * P.w + X) * 3;
-            if (store) { o[0] = ar.y; o[1] = ag.y; o[2] = ab.y; }
-            else { o[0] += ar.y; o[1] += ag.y; o[2] += ab.y; }
+            float *o = img + (size_t)(Y1 - P.row0) * P.w + X;
+            if (store) { o[0] = ar.y; o[plane] = ag.y; o[2 * plane] = ab.y; }
+            else { o[0] += ar.y; o[plane] += ag.y; o[2 * plane] += ab.y; }
         }
+        return;
+    }
+    if (Y0 < P.row1) {
+        float *o = img + ((size_t)(Y0 - P.row0) * P.w + X) * 3;
+        if (store) { o[0] = ar.x; o[1] = ag.x; o[2] = ab.x; }
+        else { o[0] += ar.x; o[1] += ag.x; o[2] += ab.x; }
+    }
+    if (Y1 < P.row1) {
+        float *o = img + ((size_t)(Y1 - P.row0) * P.w + X) * 3;
+        if (store) { o[0] = ar.y; o[1] = ag.y; o[2] = ab.y; }
+        else { o[0] += ar.y; o[1] += ag.y; o[2] += ab.y; }
     }
 }
 

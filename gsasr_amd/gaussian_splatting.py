@@ -65,8 +65,9 @@ class _Splat(torch.autograd.Function):
 
 
 class _FusedStep(torch.autograd.Function):
-    """raw decoder output `gs_parameters[N,9]` -> `[H,W,3]` image with ONE prologue kernel (activations +
-    kernel-frame conversion, reference :174-180 and :121-123) in front of the splat, and the matching chain
+    """raw decoder output `gs_parameters[N,9]` -> `[3,H,W]` image with ONE prologue kernel (activations +
+    kernel-frame conversion, reference :174-180 and :121-123) in front of the splat, the splat writing the
+    planar layout directly (no `permute(2,0,1).contiguous()` pass, reference :129), and the matching chain
     rule behind the splat's backward.  Replaces ~15 elementwise launches in forward
     and ~30 in backward; numerically the same expressions evaluated in fp32."""
 
@@ -75,8 +76,8 @@ class _FusedStep(torch.autograd.Function):
         from . import _cabi
         sigmas, coords, colors = _cabi.prologue_forward(gs_parameters, step, H, W)
         plan = _cabi.plan(sigmas, coords, colors, H, W, dmax)
-        img = torch.empty(H, W, 3, device=gs_parameters.device, dtype=torch.float32)
-        _cabi.forward(plan, img, overwrite=True)
+        img = torch.empty(3, H, W, device=gs_parameters.device, dtype=torch.float32)
+        _cabi.forward(plan, img, overwrite=True, chw=True)
         ctx.save_for_backward(gs_parameters, step, sigmas, coords, colors)
         ctx.plan, ctx.hw = plan, (H, W)
         return img
@@ -87,7 +88,8 @@ class _FusedStep(torch.autograd.Function):
         from . import _cabi
         gs_parameters, step, sigmas, coords, colors = ctx.saved_tensors
         g = (torch.empty_like(sigmas), torch.empty_like(coords), torch.empty_like(colors))
-        _cabi.backward(ctx.plan, sigmas, coords, colors, grad_output.contiguous(), *g, overwrite=True)
+        grad_hwc = grad_output.permute(1, 2, 0).contiguous()   # the backward kernel sweeps 12-byte HWC pixels
+        _cabi.backward(ctx.plan, sigmas, coords, colors, grad_hwc, *g, overwrite=True)
         gp = _cabi.prologue_backward(gs_parameters, step, ctx.hw[0], ctx.hw[1], *g)
         return gp, None, None, None, None
 
@@ -105,8 +107,7 @@ def _fused_render(gs_parameters, sr_size, step_size, dmax):
         step = step_size.detach().to(device=dev, dtype=torch.float32).reshape(1)   # stays on the device: no sync
     else:
         step = torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
-    img = _FusedStep.apply(gs_parameters.contiguous(), step, H, W, None if dmax is None else float(dmax))
-    return img.permute(2, 0, 1).contiguous()
+    return _FusedStep.apply(gs_parameters.contiguous(), step, H, W, None if dmax is None else float(dmax))
 
 
 def rendering_cuda(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device):

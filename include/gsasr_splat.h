@@ -48,6 +48,8 @@ enum gsasr_status {
 /* flags */
 #define GSASR_FLAG_OVERWRITE_IMAGE 2u /* forward STORES the splat (img need not be initialised) instead of
                                          accumulating into it; saves the caller's memset and a 12 B/px read */
+#define GSASR_FLAG_CHW_IMAGE 8u       /* forward writes img as planar [3, row1-row0, w] (the layout the host API
+                                         returns, utils/gaussian_splatting.py:129) instead of [row1-row0, w, 3] */
 #define GSASR_FLAG_OVERWRITE_GRADS 4u /* backward STORES the gradients (outputs need not be zeroed) instead
                                          of adding into them */
 

@@ -448,3 +448,19 @@ def test_non_finite_parameters_are_ignored_not_propagated(dev):
     assert torch.isfinite(out).all() and float((out - sub).abs().max()) <= 1e-5
     g = HipBackend.backward(st, sig2, xy2, col, torch.ones(H, W, 3, device=dev))
     assert all(torch.isfinite(t).all() for t in g) and float(g[0][3].abs().sum()) == 0.0
+
+
+def test_chw_image_flag(dev):
+    """GSASR_FLAG_CHW_IMAGE: the forward writes the planar layout the host API returns; accumulate and store
+    variants, a row band, ragged sizes"""
+    from gsasr_amd import _cabi, synthetic
+    sig, xy, col, H, W = synthetic.kernel_inputs(19, 23, 3.0, seed=97, device=dev)
+    for rows in (None, (11, 40)):
+        plan = _cabi.plan(sig, xy, col, H, W, 0.4, rows=rows)
+        nr = H if rows is None else rows[1] - rows[0]
+        hwc = _cabi.forward(plan, torch.zeros(nr, W, 3, device=dev))
+        chw = _cabi.forward(plan, torch.full((3, nr, W), float("nan"), device=dev), overwrite=True, chw=True)
+        assert torch.equal(chw, hwc.permute(2, 0, 1))
+        base = torch.rand(3, nr, W, device=dev)
+        acc = _cabi.forward(plan, base.clone(), chw=True)
+        assert float((acc - (base + chw)).abs().max()) <= 1e-6
