@@ -77,7 +77,8 @@ struct PlanView {
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
     float4 *fin;            // [2*s] backward epilogue constants + original index
     float *sums;            // [8*s] raw backward sums {Sx,Sy,Sxx,Sxy,Syy,Cr,Cg,Cb} per (cell-ordered) Gaussian
-    uint4 *bbox;            // [s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[4], span_hi[4]}
+    uint4 *bbox;            // [2*s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[0..3], span_hi[0..3]},
+                            //       {span_lo[4..7], span_hi[4..7], -, -}
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -122,7 +123,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_rec = o;    o += align_up(s * 32, 256);
     L.off_fin = o;    o += align_up(s * 32, 256);
     L.off_sums = o;   o += align_up(s * 32, 256);
-    L.off_bbox = o;   o += align_up(s * 16, 256);
+    L.off_bbox = o;   o += align_up(s * 32, 256);
     L.total = o;
     return L;
 }
@@ -451,19 +452,19 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
     const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * sx * hx + 1.f <= P.dmax * hx &&
                                            P.kcut * sy * hy + 1.f <= P.dmax * hy);
-    uint4 bb;
+    uint4 bb, bc = make_uint4(0u, 0u, 0u, 0u);
     if (b.cls == 2) {
         bb = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
     } else {
         bb.x = (unsigned)b.c0 | (needs_test ? 0x8000u : 0u) | ((unsigned)b.c1 << 16);
         bb.y = (unsigned)b.r0 | ((unsigned)b.r1 << 16);
         bb.z = bb.w = 0u;
-        // Row spans: for each 16-row band of forward tiles the window touches (at most 4 are encoded),
+        // Row spans: for each 16-row band of forward tiles the window touches (at most 8 are encoded),
         // the range of 8-px tile columns that the ellipse {exponent >= -tau} actually reaches.  The
         // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
         // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
         const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
-        if (P.kcut > 0.f && ty1 - ty0 < 4 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
+        if (P.kcut > 0.f && ty1 - ty0 < 8 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
             const double spx = dsx * hx, spy = dsy * hy;                  // sigmas in pixels
             const double cxp = ((double)x + 1.0) * hx, cyp = ((double)y + 1.0) * hy;
             const double tau = 0.5 * (double)P.kcut * (double)P.kcut;
@@ -472,12 +473,13 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             const double umax = spx * (double)P.kcut, vmax = spy * (double)P.kcut;
             const double vstar = dr * spy / spx * umax;                   // v of the ellipse's rightmost point
             const int tx0 = b.c0 >> SUBX_SHIFT;
-            for (int t = 0; t <= ty1 - ty0; ++t) {
+            unsigned lo4[2] = {0u, 0u}, hi4[2] = {0u, 0u};
+            for (int t = 0; t < 8; ++t) {
+                unsigned lo = 1u, hi = 0u;  // empty
                 // the band's pixel rows Ya..Ya+15, relative to the centre
                 const double v0 = (double)(P.row0 + ((ty0 + t) << SUBY_SHIFT)) - cyp - WINDOW_EPS,
                              v1 = v0 + (double)(SUBY - 1) + 2.0 * WINDOW_EPS;
-                unsigned lo = 1u, hi = 0u;  // empty
-                if (v1 >= -vmax && v0 <= vmax) {
+                if (t <= ty1 - ty0 && v1 >= -vmax && v0 <= vmax) {
                     const double a0 = fmax(v0, -vmax), a1 = fmin(v1, vmax);
                     const double vr = fmin(fmax(vstar, a0), a1), vl = fmin(fmax(-vstar, a0), a1);
                     const double dr_ = 4.0 * qa * tau - (4.0 * qa * qc - qb * qb) * vr * vr;
@@ -491,13 +493,16 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                         hi = (unsigned)min(255, (xh >> SUBX_SHIFT) - tx0);
                     }
                 }
-                bb.z |= lo << (8 * t);
-                bb.w |= hi << (8 * t);
+                lo4[t >> 2] |= lo << (8 * (t & 3));
+                hi4[t >> 2] |= hi << (8 * (t & 3));
             }
+            bb.z = lo4[0]; bb.w = hi4[0];
+            bc.x = lo4[1]; bc.y = hi4[1];
             bb.y |= 0x8000u;
         }
     }
-    V.bbox[j] = bb;
+    V.bbox[2 * j] = bb;
+    V.bbox[2 * j + 1] = bc;
     if (b.cls == 1) {  // large Gaussians accumulate their row chunks atomically: start from zero
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -608,21 +613,30 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
     const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
     bool live = fwd_advance_own(seg, base, end, nseg, sbeg, send, cnt, part, nparts);
     uint4 bb = dead;
-    if (live && base + (unsigned)lane < end) bb = bbox[base + (unsigned)lane];
+    uint2 bs = make_uint2(0u, 0u);
+    if (live && base + (unsigned)lane < end) {
+        bb = bbox[2 * (size_t)(base + (unsigned)lane)];
+        bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)(base + (unsigned)lane) + 1);
+    }
     while (live) {
         int nseg_i = seg;
         unsigned nbase = base, nend = end;
         const bool nlive = fwd_advance_own(nseg_i, nbase, nend, nseg, sbeg, send, cnt, part, nparts);
         uint4 nbb = dead;
-        if (nlive && nbase + (unsigned)lane < nend) nbb = bbox[nbase + (unsigned)lane];
+        uint2 nbs = make_uint2(0u, 0u);
+        if (nlive && nbase + (unsigned)lane < nend) {
+            nbb = bbox[2 * (size_t)(nbase + (unsigned)lane)];
+            nbs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)(nbase + (unsigned)lane) + 1);
+        }
 
         const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
         const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
         bool hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
         if (bb.y & 0x8000u) {  // per-tile-row column spans (k_bin)
-            const unsigned sh = ((unsigned)(wty - ((r0 - P.row0) >> SUBY_SHIFT)) & 3u) * 8u;
+            const unsigned t = (unsigned)(wty - ((r0 - P.row0) >> SUBY_SHIFT)) & 7u, sh = (t & 3u) * 8u;
+            const unsigned lo = t < 4u ? bb.z : bs.x, hi = t < 4u ? bb.w : bs.y;
             const int txr = wtx - (c0 >> SUBX_SHIFT);
-            hit &= (txr >= (int)((bb.z >> sh) & 0xffu)) & (txr <= (int)((bb.w >> sh) & 0xffu));
+            hit &= (txr >= (int)((lo >> sh) & 0xffu)) & (txr <= (int)((hi >> sh) & 0xffu));
         }
         const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
         // Compact the hits' records into this wave's LDS stage (untested ones first), then every lane
@@ -642,7 +656,7 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
             fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
             if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
         }
-        seg = nseg_i; base = nbase; end = nend; live = nlive; bb = nbb;
+        seg = nseg_i; base = nbase; end = nend; live = nlive; bb = nbb; bs = nbs;
     }
 }
 
@@ -872,7 +886,7 @@ template <bool BOUNDED>
 __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int lane, const Params &P,
                                          const PlanView &V, const float *__restrict__ grad, float *spy, float *red)
 {
-    const uint4 bb = V.bbox[j];  // wave-uniform: scalar loads
+    const uint4 bb = V.bbox[2 * (size_t)j];  // wave-uniform: scalar loads
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
     int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
     if (c0 > c1) return;  // dead class (not finalized)
