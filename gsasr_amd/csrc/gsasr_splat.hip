@@ -546,26 +546,25 @@ __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int 
     }
 }
 
-// next 64-candidate chunk of the segment table held in lanes (sbeg/send); all arguments wave-uniform
-__device__ __forceinline__ bool fwd_advance(int &sg, unsigned &bs, unsigned &en, int nseg, unsigned sbeg, unsigned send)
+// Candidate index of this lane in flat chunk `c` of the concatenated segments.  The segment table lives in
+// lanes (lane r: start `sbeg`, exclusive/inclusive prefix of the lengths `pex`/`pin`); `r` is the first
+// segment that reaches into the chunk (wave-uniform, advanced monotonically).  Returns 0xffffffff for
+// lanes past the end.  A chunk overlaps one or two segments at 16 Gaussians per cell and 3-5 when cells
+// are sparse (x12 inference), so every chunk is full instead of one mostly-empty chunk per segment.
+__device__ __forceinline__ unsigned fwd_candidate(unsigned c, int lane, int nseg, int &r, unsigned sbeg, unsigned pex,
+                                                  unsigned pin)
 {
-    bs += 64;
-    while (bs >= en) {
-        if (++sg >= nseg) return false;
-        bs = (unsigned)__builtin_amdgcn_readlane((int)sbeg, sg);
-        en = (unsigned)__builtin_amdgcn_readlane((int)send, sg);
+    const unsigned q0 = c * 64u, q = q0 + (unsigned)lane;
+    while (r < nseg && (unsigned)__builtin_amdgcn_readlane((int)pin, r) <= q0) ++r;
+    unsigned j = 0xffffffffu;
+    for (int rr = r; rr < nseg; ++rr) {
+        const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)pex, rr);
+        if (p0 >= q0 + 64u) break;
+        const unsigned p1 = (unsigned)__builtin_amdgcn_readlane((int)pin, rr);
+        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)sbeg, rr);
+        if (q >= p0 && q < p1) j = b + (q - p0);
     }
-    return true;
-}
-
-// next chunk that belongs to this wave when the chunks of a sub-tile are dealt round-robin to `nparts` waves
-__device__ __forceinline__ bool fwd_advance_own(int &sg, unsigned &bs, unsigned &en, int nseg, unsigned sbeg,
-                                                unsigned send, unsigned &cnt, unsigned part, unsigned nparts)
-{
-    for (;;) {
-        if (!fwd_advance(sg, bs, en, nseg, sbeg, send)) return false;
-        if (cnt++ % nparts == part) return true;
-    }
+    return j;
 }
 
 // One wave, one 8x16 sub-tile at (sx0, sy0): accumulate every Gaussian binned near it into ar/ag/ab
@@ -606,27 +605,36 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
     }
     ++nseg;
 
-    // Flat walk over 64-candidate chunks of all segments, software-pipelined: the window record of the
-    // NEXT chunk is in flight while the hits of the current one are evaluated.
-    int seg = -1;
-    unsigned base = 0, end = 0, cnt = 0;
+    // Flat walk over full 64-candidate chunks of the concatenated segments (this wave takes chunks
+    // part, part+nparts, ...), software-pipelined: the window record of the NEXT chunk is in flight while
+    // the hits of the current one are evaluated.
+    const unsigned len = send - sbeg;
+    unsigned pin = len;  // inclusive prefix sum of the segment lengths over the lanes
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)pin, o);
+        if (lane >= o) pin += v;
+    }
+    const unsigned pex = pin - len;
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+    const unsigned nchunks = (total + 63u) >> 6;
     const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
-    bool live = fwd_advance_own(seg, base, end, nseg, sbeg, send, cnt, part, nparts);
+    int rseg = 0;
+    unsigned c = part;
+    unsigned j = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
     uint4 bb = dead;
     uint2 bs = make_uint2(0u, 0u);
-    if (live && base + (unsigned)lane < end) {
-        bb = bbox[2 * (size_t)(base + (unsigned)lane)];
-        bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)(base + (unsigned)lane) + 1);
+    if (j != 0xffffffffu) {
+        bb = bbox[2 * (size_t)j];
+        bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)j + 1);
     }
-    while (live) {
-        int nseg_i = seg;
-        unsigned nbase = base, nend = end;
-        const bool nlive = fwd_advance_own(nseg_i, nbase, nend, nseg, sbeg, send, cnt, part, nparts);
+    while (c < nchunks) {
+        const unsigned nc = c + nparts;
+        const unsigned nj = nc < nchunks ? fwd_candidate(nc, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
         uint4 nbb = dead;
         uint2 nbs = make_uint2(0u, 0u);
-        if (nlive && nbase + (unsigned)lane < nend) {
-            nbb = bbox[2 * (size_t)(nbase + (unsigned)lane)];
-            nbs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)(nbase + (unsigned)lane) + 1);
+        if (nj != 0xffffffffu) {
+            nbb = bbox[2 * (size_t)nj];
+            nbs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)nj + 1);
         }
 
         const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
@@ -648,7 +656,7 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
             if (hit) {
                 const unsigned long long below = (1ull << lane) - 1ull;
                 const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
-                const float4 *src = rec + 2 * (size_t)(base + (unsigned)lane);
+                const float4 *src = rec + 2 * (size_t)j;
                 stage[2 * slot] = src[0];
                 stage[2 * slot + 1] = src[1];
             }
@@ -656,7 +664,7 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
             fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
             if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
         }
-        seg = nseg_i; base = nbase; end = nend; live = nlive; bb = nbb; bs = nbs;
+        c = nc; j = nj; bb = nbb; bs = nbs;
     }
 }
 
