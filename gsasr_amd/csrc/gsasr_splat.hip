@@ -423,13 +423,63 @@ __global__ __launch_bounds__(1024) void k_scan_fix(int n, unsigned *__restrict__
 }
 
 // counting-sort placement (slot = cell start + rank, no atomics) fused with record packing
+// FUSED_SCAN (grids of at most FUSED_CELLS cells+2, e.g. 1024^2): every block rebuilds the exclusive scan of
+// the cell histogram in LDS itself (16 counts per thread) instead of waiting for a separate one-block scan
+// kernel -- one launch less on a latency-bound plan; block 0 publishes cell_start[] and the header.
+constexpr int FUSED_PER_THREAD = 17, FUSED_CELLS = 256 * FUSED_PER_THREAD;
+
+template <bool FUSED_SCAN>
 __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__ sigmas,
                                              const float *__restrict__ coords,
-                                             const float *__restrict__ colors, PlanView V)
+                                             const float *__restrict__ colors, PlanView V, int nblk)
 {
+    __shared__ unsigned s_start[FUSED_SCAN ? FUSED_CELLS + 1 : 1];
+    __shared__ unsigned s_part[FUSED_SCAN ? 256 : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (FUSED_SCAN) {
+        const int t = threadIdx.x, ncls = P.ncells + 2;
+        const int b0 = t * FUSED_PER_THREAD;
+        unsigned c[FUSED_PER_THREAD], sum = 0;
+#pragma unroll
+        for (int k = 0; k < FUSED_PER_THREAD; ++k) {
+            c[k] = b0 + k < ncls ? V.cell_count[b0 + k] : 0u;
+            sum += c[k];
+        }
+        s_part[t] = sum;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const unsigned v = t >= o ? s_part[t - o] : 0u;
+            __syncthreads();
+            s_part[t] += v;
+            __syncthreads();
+        }
+        unsigned run = s_part[t] - sum;
+#pragma unroll
+        for (int k = 0; k < FUSED_PER_THREAD; ++k) {
+            if (b0 + k <= ncls) s_start[b0 + k] = run;
+            run += c[k];
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {  // publish for the render kernels
+            for (int k = t; k <= ncls; k += 256) V.cell_start[k] = s_start[k];
+            unsigned mx = 0, my = 0;
+            for (int k = t; k < nblk; k += 256) {
+                mx = max(mx, V.blockmax[2 * k + 0]);
+                my = max(my, V.blockmax[2 * k + 1]);
+            }
+            mx = wave_max_u32(mx);
+            my = wave_max_u32(my);
+            __syncthreads();
+            if ((t & 63) == 0) { s_part[t >> 6] = mx; s_part[4 + (t >> 6)] = my; }
+            __syncthreads();
+            if (t == 0) {
+                V.hdr[0] = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+                V.hdr[1] = max(max(s_part[4], s_part[5]), max(s_part[6], s_part[7]));
+            }
+        }
+    }
     if (i >= P.s) return;
-    const unsigned j = V.cell_start[V.key[i]] + V.rank[i];
+    const unsigned j = (FUSED_SCAN ? s_start[V.key[i]] : V.cell_start[V.key[i]]) + V.rank[i];
     const float sx = sigmas[i * 3 + 0], sy = sigmas[i * 3 + 1], rho = sigmas[i * 3 + 2];
     const float x = coords[i * 2 + 0], y = coords[i * 2 + 1];
     const Box b = gaussian_box(sx, sy, x, y, P);
@@ -1118,17 +1168,23 @@ int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colo
     const int nblk = classify_blocks(dims);
     hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V);
     const int ncls = L.ncells + 2;
-    if (ncls <= 2 * SCAN_CHUNK) {
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start, nblk, V.blockmax,
-                           V.hdr);
+    const unsigned nbin = (unsigned)((dims->s + 255) / 256);
+    if (ncls <= FUSED_CELLS && dims->s > 0) {
+        // small grid: k_bin rebuilds the scan per block (no separate scan launch)
+        hipLaunchKernelGGL(k_bin<true>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);
     } else {
-        const int nchunks = (ncls + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start,
-                           V.scan_tot, nblk, V.blockmax, V.hdr);
-        hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_start, V.scan_tot, nchunks);
+        if (ncls <= 2 * SCAN_CHUNK) {
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start, nblk, V.blockmax,
+                               V.hdr);
+        } else {
+            const int nchunks = (ncls + SCAN_CHUNK - 1) / SCAN_CHUNK;
+            hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start,
+                               V.scan_tot, nblk, V.blockmax, V.hdr);
+            hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_start, V.scan_tot, nchunks);
+        }
+        if (dims->s > 0)
+            hipLaunchKernelGGL(k_bin<false>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);
     }
-    if (dims->s > 0)
-        hipLaunchKernelGGL(k_bin, dim3((dims->s + 255) / 256), dim3(256), 0, st, P, sigmas, coords, colors, V);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }

@@ -464,3 +464,35 @@ def test_chw_image_flag(dev):
         base = torch.rand(3, nr, W, device=dev)
         acc = _cabi.forward(plan, base.clone(), chw=True)
         assert float((acc - (base + chw)).abs().max()) <= 1e-6
+
+
+def test_unsorted_random_gaussians_large_n(dev):
+    """inputs that are NOT in raster order and have a wide size distribution (every class populated, heavy
+    cell-count imbalance): 200k Gaussians on 1536x1280, checked on two row bands against the oracle"""
+    from oracle import gs_oracle
+    from gsasr_amd.shard import HipBackend
+    g = torch.Generator().manual_seed(123)
+    n, H, W = 200_000, 1536, 1280
+    sig_px = torch.exp(torch.empty(n, 2).uniform_(-2.5, 3.5, generator=g))          # 0.08 .. 33 px
+    sig_px[:50] *= 40                                                                 # a few huge ones
+    sig = torch.stack([sig_px[:, 0] * 2 / (W - 1), sig_px[:, 1] * 2 / (H - 1),
+                       torch.empty(n).uniform_(-0.95, 0.95, generator=g)], 1)
+    xy = torch.empty(n, 2).uniform_(-1.05, 1.05, generator=g)
+    xy[: n // 4] = xy[: n // 4] * 0.1 + 0.3                                           # a dense cluster
+    col = torch.rand(n, 3, generator=g) * 0.05
+    wgt = torch.rand(H, W, 3, generator=g)
+    a, b, c = sig.to(dev), xy.to(dev), col.to(dev)
+    for dmax in (0.08, None):
+        img, st = HipBackend.forward(a, b, c, H, W, dmax, (0, H))
+        for rows in ((0, 24), (760, 790)):
+            ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax, rows=rows)
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert np.abs(img[rows[0]:rows[1]].cpu().numpy() - ref).max() <= IMG_ATOL * scale
+    # backward on a band (bounded): the oracle's windowed f64 backward is O(pairs)
+    rows = (700, 780)
+    slab, st = HipBackend.forward(a, b, c, H, W, 0.08, rows)
+    gw = wgt[rows[0]:rows[1]].contiguous()
+    g3 = HipBackend.backward(st, a, b, c, gw.to(dev))
+    gref = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), gw.numpy(), 0.08, h=H, rows=rows)
+    for got, want in zip(g3, gref):
+        assert _relmax(got.cpu().numpy(), want) <= 5e-4
