@@ -21,6 +21,7 @@ EXPORTS = (
     "gsasr_splat_forward", "gsasr_splat_backward", "gsasr_gs_render", "gsasr_gs_render_backward",
     "gsasr_gs_render_dmax", "gsasr_gs_render_backward_dmax", "gsasr_set_default_cutoff",
     "gsasr_get_default_cutoff", "gsasr_prologue_forward", "gsasr_prologue_backward",
+    "gsasr_step_workspace_bytes", "gsasr_step_forward", "gsasr_step_backward",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -73,6 +74,12 @@ def lib():
         L.gsasr_prologue_forward.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp]
         L.gsasr_prologue_backward.restype = i
         L.gsasr_prologue_backward.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp]
+        L.gsasr_step_workspace_bytes.restype = sz
+        L.gsasr_step_workspace_bytes.argtypes = [dp]
+        L.gsasr_step_forward.restype = i
+        L.gsasr_step_forward.argtypes = [vp, vp, dp, vp, sz, vp, vp]
+        L.gsasr_step_backward.restype = i
+        L.gsasr_step_backward.argtypes = [vp, vp, vp, vp, dp, vp, sz, vp]
         L.gsasr_set_default_cutoff.restype = None
         L.gsasr_set_default_cutoff.argtypes = [f]
         L.gsasr_get_default_cutoff.restype = f
@@ -202,6 +209,38 @@ def prologue_backward(gs_parameters, step, h: int, w: int, g_sigmas, g_coords, g
     with torch.cuda.device(dev):
         check(lib().gsasr_prologue_backward(pp, ps, n, int(h), int(w), *ptrs, gp.data_ptr(), _stream(dev)),
               "gsasr_prologue_backward")
+    return gp
+
+
+def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float]):
+    """prologue + plan + forward in ONE call: raw `gs_parameters[N,9]` -> planar image `[3,h,w]` (fresh)."""
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(step, "step_size")
+    if dmax is not None and not (float(dmax) >= 0.0):
+        raise RuntimeError("dmax must be >= 0")
+    dev = gs_parameters.device
+    d = make_dims(gs_parameters.shape[0], h, w, dmax, flags=FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE)
+    L = lib()
+    nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        check(-1, "gsasr_step_workspace_bytes")
+    with torch.cuda.device(dev):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        img = torch.empty(3, int(h), int(w), dtype=torch.float32, device=dev)
+        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), _stream(dev)),
+              "gsasr_step_forward")
+    return img, Plan(d, ws, dev)
+
+
+def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad_hwc: torch.Tensor) -> torch.Tensor:
+    """splat backward + prologue backward in ONE call; `grad_hwc` is `[h,w,3]`; returns d/d gs_parameters `[N,9]`."""
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(step, "step_size")
+    pg = _chk(grad_hwc, "grads", (p.dims.h, p.dims.w, 3))
+    with torch.cuda.device(p.device):
+        gp = torch.empty_like(gs_parameters)
+        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
+                                        p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
     return gp
 
 

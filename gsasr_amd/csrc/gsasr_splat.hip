@@ -1281,6 +1281,68 @@ int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, 
     return GSASR_OK;
 }
 
+// ---- whole-step entry points ----------------------------------------------------------------------
+namespace {
+struct StepLayout {
+    size_t plan_bytes, off_sig, off_xy, off_col, off_gsig, off_gxy, off_gcol, total;
+};
+StepLayout make_step_layout(const gsasr_dims *d)
+{
+    StepLayout S;
+    const size_t n = (size_t)d->s;
+    S.plan_bytes = make_layout(d).total;
+    size_t o = S.plan_bytes;
+    S.off_sig = o;  o += align_up(n * 12, 256);
+    S.off_xy = o;   o += align_up(n * 8, 256);
+    S.off_col = o;  o += align_up(n * 12, 256);
+    S.off_gsig = o; o += align_up(n * 12, 256);
+    S.off_gxy = o;  o += align_up(n * 8, 256);
+    S.off_gcol = o; o += align_up(n * 12, 256);
+    S.total = o;
+    return S;
+}
+}  // namespace
+
+size_t gsasr_step_workspace_bytes(const gsasr_dims *dims)
+{
+    if (!dims_ok(dims)) {
+        fail(GSASR_ERR_ARG, "bad dims");
+        return 0;
+    }
+    return make_step_layout(dims).total;
+}
+
+int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+                       size_t workspace_bytes, float *img, void *stream)
+{
+    if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
+    const StepLayout S = make_step_layout(dims);
+    if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
+        return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
+    char *b = (char *)workspace;
+    float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
+    if (int rc = gsasr_prologue_forward(gs_parameters, step_size, dims->s, dims->h, dims->w, sig, xy, col, stream)) return rc;
+    if (int rc = gsasr_splat_plan(sig, xy, col, dims, workspace, S.plan_bytes, stream)) return rc;
+    return gsasr_splat_forward(dims, workspace, S.plan_bytes, img, stream);
+}
+
+int gsasr_step_backward(const float *gs_parameters, const float *step_size, const float *grad_img,
+                        float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
+                        void *stream)
+{
+    if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
+    const StepLayout S = make_step_layout(dims);
+    if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
+        return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
+    char *b = (char *)workspace;
+    float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
+    float *gs = (float *)(b + S.off_gsig), *gc = (float *)(b + S.off_gxy), *gk = (float *)(b + S.off_gcol);
+    gsasr_dims d = *dims;
+    d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
+    if (int rc = gsasr_splat_backward(sig, xy, col, grad_img, gs, gc, gk, &d, workspace, S.plan_bytes, stream)) return rc;
+    return gsasr_prologue_backward(gs_parameters, step_size, dims->s, dims->h, dims->w, gs, gc, gk, g_parameters, stream);
+}
+
 // ---- reference-shaped launchers -------------------------------------------------------------------
 static int render_common(const float *sigmas, const float *coords, const float *colors, float *img,
                          const float *grads, float *gs, float *gc, float *gk, int s, int h, int w, int c,

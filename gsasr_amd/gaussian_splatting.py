@@ -74,24 +74,18 @@ class _FusedStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gs_parameters, step, H, W, dmax):
         from . import _cabi
-        sigmas, coords, colors = _cabi.prologue_forward(gs_parameters, step, H, W)
-        plan = _cabi.plan(sigmas, coords, colors, H, W, dmax)
-        img = torch.empty(3, H, W, device=gs_parameters.device, dtype=torch.float32)
-        _cabi.forward(plan, img, overwrite=True, chw=True)
-        ctx.save_for_backward(gs_parameters, step, sigmas, coords, colors)
-        ctx.plan, ctx.hw = plan, (H, W)
+        img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax)   # one C call: prologue + plan + splat
+        ctx.save_for_backward(gs_parameters, step)
+        ctx.plan = plan
         return img
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         from . import _cabi
-        gs_parameters, step, sigmas, coords, colors = ctx.saved_tensors
-        g = (torch.empty_like(sigmas), torch.empty_like(coords), torch.empty_like(colors))
+        gs_parameters, step = ctx.saved_tensors
         grad_hwc = grad_output.permute(1, 2, 0).contiguous()   # the backward kernel sweeps 12-byte HWC pixels
-        _cabi.backward(ctx.plan, sigmas, coords, colors, grad_hwc, *g, overwrite=True)
-        gp = _cabi.prologue_backward(gs_parameters, step, ctx.hw[0], ctx.hw[1], *g)
-        return gp, None, None, None, None
+        return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_hwc), None, None, None, None
 
 
 def _fused_ok(gs_parameters) -> bool:

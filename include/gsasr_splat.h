@@ -111,6 +111,18 @@ int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, 
                             const float *g_sigmas, const float *g_coords, const float *g_colors,
                             float *g_parameters, void *stream);
 
+/* The whole host-API step in one call each way (what generate_2D_gaussian_splatting_step enqueues):
+ * prologue + plan + forward, and splat-backward + prologue-backward.  The workspace additionally holds the
+ * kernel-frame tensors and their gradients (gsasr_step_workspace_bytes >= gsasr_splat_workspace_bytes).
+ * Forward honours dims.flags (OVERWRITE_IMAGE, CHW_IMAGE); backward always stores g_parameters[n,9] and
+ * expects grad_img as [row1-row0, w, 3]. */
+size_t gsasr_step_workspace_bytes(const gsasr_dims *dims);
+int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+                       size_t workspace_bytes, float *img, void *stream);
+int gsasr_step_backward(const float *gs_parameters, const float *step_size, const float *grad_img,
+                        float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
 /* Reference-shaped launchers (allocate their scratch stream-ordered, plan, run, free). */
 int gsasr_gs_render(const float *sigmas, const float *coords, const float *colors,
                     float *rendered_img, int s, int h, int w, int c, void *stream);
