@@ -828,11 +828,18 @@ struct Grad6 {  // the three gradient channels of the two pixels (rows Y, Y+RPI)
     float a0, a1, a2, b0, b1, b2;
 };
 
-__device__ __forceinline__ Grad6 bwd_load(const float *ga, const float *gb)
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
+
+// Two 12-byte pixels through a raw buffer resource: address = base(SGPR x4) + per-lane byte offset (VGPR,
+// constant over the sweep) + running row offset (SGPR, advanced by the scalar unit), so a trip spends no
+// VALU instruction on addressing, and reads past the end of the slab return 0 instead of faulting.
+__device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff_a, int soff_b)
 {
+    const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
+    const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_b, 0);
     Grad6 g;
-    g.a0 = ga[0]; g.a1 = ga[1]; g.a2 = ga[2];
-    g.b0 = gb[0]; g.b1 = gb[1]; g.b2 = gb[2];
+    g.a0 = __uint_as_float(a.x); g.a1 = __uint_as_float(a.y); g.a2 = __uint_as_float(a.z);
+    g.b0 = __uint_as_float(b.x); g.b1 = __uint_as_float(b.y); g.b2 = __uint_as_float(b.z);
     return g;
 }
 
@@ -878,43 +885,38 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
         const float adx2 = (A * dxe) * dxe, bdx = B * dxe;
         BwdRow R;
         R.m0 = R.m1 = R.m2 = R.k01 = R.k20 = R.k12 = (v2f){0.f, 0.f};
-        // addressing: wave-uniform row pointer (SGPRs, advanced by the scalar unit) + a 32-bit per-lane byte
-        // offset -> global_load with saddr, no per-trip VALU address arithmetic
-        const unsigned voff = (unsigned)(((size_t)X * 3 + (size_t)rsub * rowpitch) * sizeof(float));
+        const int voff = (int)(((size_t)X * 3 + (size_t)rsub * rowpitch) * sizeof(float));
+        const int halfb = (int)((size_t)RPI * rowpitch * sizeof(float));
         for (int rb = r0; rb <= r1; rb += 64) {
             const int rend = min(r1, rb + 63);
             __builtin_amdgcn_wave_barrier();
             spy[lane] = pyt[min(rb + lane, r1)] - y;  // dy of the block's rows, one LDS word per row
             __builtin_amdgcn_wave_barrier();
             const float *sp = spy + rsub;
-            const char *rowp = reinterpret_cast<const char *>(grad + (size_t)(rb - P.row0) * rowpitch);
-            const size_t halfb = (size_t)RPI * rowpitch * sizeof(float);
-            // full trips: no masks, no address clamps (manual software pipelining of the loads was measured
-            // 10% slower than letting the 8 resident waves per SIMD hide the latency)
+            // buffer resource over the slab from row `rb` on (offsets stay far below 2^31 within a 64-row block)
+            const float *blk = grad + (size_t)(rb - P.row0) * rowpitch;
+            const size_t left = (size_t)(P.row1 - rb) * rowpitch * sizeof(float);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
+            int soff = 0;
             int Yb = rb;
             // two trips per iteration: four gradient loads in flight before the first is consumed (+14% at
             // config 4's tall windows, -1% at config 2: 94 VGPRs -> 5 waves per SIMD)
-            for (; Yb + 4 * RPI - 1 <= rend; Yb += 4 * RPI, rowp += 4 * halfb, sp += 4 * RPI) {
-                const Grad6 g0 = bwd_load(reinterpret_cast<const float *>(rowp + voff),
-                                          reinterpret_cast<const float *>(rowp + halfb + voff));
-                const Grad6 g1 = bwd_load(reinterpret_cast<const float *>(rowp + 2 * halfb + voff),
-                                          reinterpret_cast<const float *>(rowp + 3 * halfb + voff));
+            for (; Yb + 4 * RPI - 1 <= rend; Yb += 4 * RPI, soff += 4 * halfb, sp += 4 * RPI) {
+                const Grad6 g0 = bwd_load(rsrc, voff, soff, soff + halfb);
+                const Grad6 g1 = bwd_load(rsrc, voff, soff + 2 * halfb, soff + 3 * halfb);
                 const v2f dy0 = {sp[0], sp[RPI]}, dy1 = {sp[2 * RPI], sp[3 * RPI]};
                 bwd_trip<TEST, false>(R, g0, dy0, true, true, adx2, bdx, C, cr, cg, cb, P.dmax);
                 bwd_trip<TEST, false>(R, g1, dy1, true, true, adx2, bdx, C, cr, cg, cb, P.dmax);
             }
-            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, rowp += 2 * halfb, sp += 2 * RPI)
-                bwd_trip<TEST, false>(R, bwd_load(reinterpret_cast<const float *>(rowp + voff),
-                                                  reinterpret_cast<const float *>(rowp + halfb + voff)),
-                                      (v2f){sp[0], sp[RPI]}, true, true, adx2, bdx, C, cr, cg, cb, P.dmax);
-            if (Yb <= rend) {  // ragged last trip: clamp the addresses, mask the rows past the window
+            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, soff += 2 * halfb, sp += 2 * RPI)
+                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, soff, soff + halfb), (v2f){sp[0], sp[RPI]}, true, true, adx2,
+                                      bdx, C, cr, cg, cb, P.dmax);
+            if (Yb <= rend) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
                 const int Ya = Yb + rsub, Yc = Ya + RPI;
-                const bool ok1 = Ya <= rend, ok2 = Yc <= rend;
-                const float *glast = grad + (size_t)X * 3 + (size_t)(rend - P.row0) * rowpitch;
-                const float *ga = ok1 ? reinterpret_cast<const float *>(rowp + voff) : glast;
-                const float *gb = ok2 ? reinterpret_cast<const float *>(rowp + halfb + voff) : glast;
-                bwd_trip<TEST, true>(R, bwd_load(ga, gb), (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, ok1,
-                                     ok2, adx2, bdx, C, cr, cg, cb, P.dmax);
+                bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, soff, soff + halfb),
+                                     (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, Ya <= rend, Yc <= rend, adx2,
+                                     bdx, C, cr, cg, cb, P.dmax);
             }
         }
         const float M0 = R.m0.x + R.m0.y, M1 = R.m1.x + R.m1.y, M2 = R.m2.x + R.m2.y;
