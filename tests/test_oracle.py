@@ -164,3 +164,29 @@ def test_rendering_python_restatement(path):
     out = host_ref.rendering_python(torch.from_numpy(z["gs_parameters"]), z["sr_size"].tolist(),
                                     torch.tensor([sc, sc]))
     np.testing.assert_allclose(out.numpy(), z["out"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_oracle_random_cases_against_autograd(seed):
+    """randomised small cases (non-square, dmax near pixel pitch multiples, Gaussians on pixel centres and on
+    the image border): C oracle f64 (forward + analytic backward) vs the torch expression + autograd"""
+    rng = np.random.default_rng(100 + seed)
+    s, h, w = int(rng.integers(1, 12)), int(rng.integers(2, 20)), int(rng.integers(2, 20))
+    sig = np.stack([rng.uniform(0.03, 0.9, s), rng.uniform(0.03, 0.9, s), rng.uniform(-0.97, 0.97, s)], 1).astype(np.float32)
+    xy = rng.uniform(-1.1, 1.1, (s, 2)).astype(np.float32)
+    xy[0] = [2.0 * rng.integers(0, w) / (w - 1) - 1.0, 2.0 * rng.integers(0, h) / (h - 1) - 1.0]   # exactly on a pixel
+    col = rng.uniform(0, 1, (s, 3)).astype(np.float32)
+    wgt = rng.uniform(-1, 1, (h, w, 3)).astype(np.float32)
+    for dmax in (None, float(rng.choice([2.0 / (w - 1), 4.0 / (h - 1), 0.37, 1.5]))):
+        a, b, c = (torch.from_numpy(t).double().requires_grad_(True) for t in (sig, xy, col))
+        img = host_ref.autograd_render(a, b, c, h, w, dmax)
+        (torch.from_numpy(wgt).double() * img).sum().backward()
+        ref = gs_oracle.forward_f64(sig, xy, col, h, w, dmax)
+        assert np.abs(img.detach().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        g = gs_oracle.backward_f64(sig, xy, col, wgt, dmax)
+        for got, t in zip(g, (a, b, c)):
+            want = t.grad.numpy()
+            assert np.abs(got - want).max() <= 5e-5 * max(1e-9, np.abs(want).max()) + 1e-9
+        # fp32 restatement stays within fp32 rounding of the truth
+        img32 = gs_oracle.forward_f32(sig, xy, col, h, w, dmax)
+        assert np.abs(img32 - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
