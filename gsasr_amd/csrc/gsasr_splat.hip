@@ -75,8 +75,8 @@ struct PlanView {
     unsigned *blockmax;     // [2*nblk] per-classify-block max half-extents
     unsigned *scan_tot;     // [ceil((ncells+2)/4096)] per-chunk totals of the two-pass scan
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
-    float4 *fin;            // [2*s] backward epilogue constants + original index
-    float *sums;            // [8*s] raw backward sums {Sx,Sy,Sxx,Sxy,Syy,Cr,Cg,Cb} per (cell-ordered) Gaussian
+    float4 *fin;            // [2*s] backward constants {1/(1-rho^2), 1-rho^2, rho, 1/sx}, {1/sy, -, -, original index}
+    float *sums;            // [8*s] raw backward sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} per (cell-ordered) Gaussian
     uint4 *bbox;            // [2*s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[0..3], span_hi[0..3]},
                             //       {span_lo[4..7], span_hi[4..7], -, -}
 };
@@ -495,8 +495,9 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     V.rec[2 * j + 0] = make_float4(x, y, A, B);
     V.rec[2 * j + 1] = make_float4(colors[i * 3 + 0], colors[i * 3 + 1], colors[i * 3 + 2], C);
     // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
-    V.fin[2 * j + 0] = make_float4((float)(2.0 * w1), (float)w2, (float)w3, (float)w4);
-    V.fin[2 * j + 1] = make_float4(rho, (float)(1.0 / dsx), (float)(1.0 / dsy), __uint_as_float((unsigned)i));
+    // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
+    V.fin[2 * j + 0] = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
+    V.fin[2 * j + 1] = make_float4((float)(1.0 / dsy), 0.f, 0.f, __uint_as_float((unsigned)i));
     // does a pixel of a tile this Gaussian is binned to ever need the dmax test?  Not if its support box
     // lies inside its dmax box: pixels beyond the support box carry < exp(-tau) whether tested or not.
     const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
@@ -844,22 +845,26 @@ __device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff,
 }
 
 template <bool TEST, bool TAIL>
-__device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dy, bool ok1, bool ok2, float adx2, float bdx,
-                                         float C, float cr, float cg, float cb, float dmax)
+__device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f dyraw, bool ok1, bool ok2, float K0,
+                                         float nK1, float rho_u, float cr, float cg, float cb, float dmax)
 {
-    // six consecutive-in-memory floats per pixel pair are used as they land: no register shuffling
-    const v2f t = C * dy + bdx;
-    const v2f pw = dy * t + adx2;
+    // With u = dx/sx, v = dy/sy and B = v - rho u (the residual of v about its conditional mean given u) the
+    // quadratic form completes to  u^2 - 2 rho u v + v^2 = (1-rho^2) u^2 + B^2,  so the exponent is
+    //   log2(e) w1 (...) = K0 - K1 B^2,   K0 = -log2(e)/2 u^2 (lane constant),  K1 = log2(e)/2 / (1-rho^2),
+    // and the same B feeds the gradient moments: nothing here cancels as |rho| -> 1.
+    const v2f Bv = dyn - rho_u;
+    const v2f pw = (Bv * nK1) * Bv + K0;
     v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
     if (TEST || TAIL) {
-        v.x = ((!TAIL || ok1) && (!TEST || fabsf(dy.x) <= dmax)) ? v.x : 0.f;
-        v.y = ((!TAIL || ok2) && (!TEST || fabsf(dy.y) <= dmax)) ? v.y : 0.f;
+        v.x = ((!TAIL || ok1) && (!TEST || fabsf(dyraw.x) <= dmax)) ? v.x : 0.f;
+        v.y = ((!TAIL || ok2) && (!TEST || fabsf(dyraw.y) <= dmax)) ? v.y : 0.f;
     }
+    // six consecutive-in-memory floats per pixel pair are used as they land: no register shuffling
     const v2f gp = {fmaf(g.a2, cb, fmaf(g.a1, cg, g.a0 * cr)), fmaf(g.b2, cb, fmaf(g.b1, cg, g.b0 * cr))};  // gs.cu:150
-    const v2f q = gp * v, qdy = q * dy;
+    const v2f q = gp * v, qB = q * Bv;
     R.m0 += q;
-    R.m1 += qdy;
-    R.m2 += qdy * dy;
+    R.m1 += qB;
+    R.m2 += qB * Bv;
     R.k01 += (v2f){g.a0, g.a1} * v.x;
     R.k20 += (v2f){g.a2, g.b0} * v;
     R.k12 += (v2f){g.b1, g.b2} * v.y;
@@ -868,21 +873,24 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dy, bool 
 template <bool TEST, int LXLOG>
 __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int lane, const Params &P,
                                           const float *__restrict__ pxt, const float *__restrict__ pyt,
-                                          const float *__restrict__ grad, float x, float y, float A, float B,
-                                          float C, float cr, float cg, float cb, float *spy, float (&acc)[8])
+                                          const float *__restrict__ grad, float x, float y, float cr, float cg,
+                                          float cb, float cinv, float rho, float kappa, float isx, float isy,
+                                          float *spy, float (&acc)[8])
 {
     constexpr int LX = 1 << LXLOG, RPI = 64 >> LXLOG;
+    constexpr float HALF_LOG2E = 0.72134752044448170368f;
     const int col = lane & (LX - 1), rsub = lane >> LXLOG;
     const size_t rowpitch = (size_t)P.w * 3;
+    const float nK1 = -HALF_LOG2E * cinv;
     for (int strip = 0; strip < bw; strip += 64) {
         const int cc = strip + col;
         const int X = c0 + min(cc, bw - 1);
         const float dx = pxt[X] - x;
-        // lanes outside the window (or, with TEST, outside the dmax box in x) are switched off by
-        // poisoning dx: the exponent becomes -inf, v = 0 exactly, and every product with it is 0
+        // lanes outside the window (or, with TEST, outside the dmax box in x) are switched off through K0:
+        // the exponent becomes -inf, v = 0 exactly, and every product with it is 0
         const bool inx = cc < bw && (!TEST || fabsf(dx) <= P.dmax);
-        const float dxe = inx ? dx : 1e18f;
-        const float adx2 = (A * dxe) * dxe, bdx = B * dxe;
+        const float u = dx * isx, rho_u = rho * u;
+        const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;
         BwdRow R;
         R.m0 = R.m1 = R.m2 = R.k01 = R.k20 = R.k12 = (v2f){0.f, 0.f};
         const int voff = (int)(((size_t)X * 3 + (size_t)rsub * rowpitch) * sizeof(float));
@@ -890,7 +898,11 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
         for (int rb = r0; rb <= r1; rb += 64) {
             const int rend = min(r1, rb + 63);
             __builtin_amdgcn_wave_barrier();
-            spy[lane] = pyt[min(rb + lane, r1)] - y;  // dy of the block's rows, one LDS word per row
+            {   // per-row values of the block in LDS: v = dy/sy, and (TEST only) the raw dy for the exact box test
+                const float dyr = pyt[min(rb + lane, r1)] - y;
+                spy[lane] = dyr * isy;
+                if (TEST) spy[64 + lane] = dyr;
+            }
             __builtin_amdgcn_wave_barrier();
             const float *sp = spy + rsub;
             // buffer resource over the slab from row `rb` on (offsets stay far below 2^31 within a 64-row block)
@@ -900,37 +912,43 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 const_cast<float *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
             int soff = 0;
             int Yb = rb;
-            // two trips per iteration: four gradient loads in flight before the first is consumed (+14% at
-            // config 4's tall windows, -1% at config 2: 94 VGPRs -> 5 waves per SIMD)
+            // two trips per iteration: four gradient loads in flight before the first is consumed
             for (; Yb + 4 * RPI - 1 <= rend; Yb += 4 * RPI, soff += 4 * halfb, sp += 4 * RPI) {
                 const Grad6 g0 = bwd_load(rsrc, voff, soff, soff + halfb);
                 const Grad6 g1 = bwd_load(rsrc, voff, soff + 2 * halfb, soff + 3 * halfb);
-                const v2f dy0 = {sp[0], sp[RPI]}, dy1 = {sp[2 * RPI], sp[3 * RPI]};
-                bwd_trip<TEST, false>(R, g0, dy0, true, true, adx2, bdx, C, cr, cg, cb, P.dmax);
-                bwd_trip<TEST, false>(R, g1, dy1, true, true, adx2, bdx, C, cr, cg, cb, P.dmax);
+                const v2f n0 = {sp[0], sp[RPI]}, n1 = {sp[2 * RPI], sp[3 * RPI]};
+                const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0, w1 = TEST ? (v2f){sp[64 + 2 * RPI], sp[64 + 3 * RPI]} : n1;
+                bwd_trip<TEST, false>(R, g0, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
+                bwd_trip<TEST, false>(R, g1, n1, w1, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
             }
-            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, soff += 2 * halfb, sp += 2 * RPI)
-                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, soff, soff + halfb), (v2f){sp[0], sp[RPI]}, true, true, adx2,
-                                      bdx, C, cr, cg, cb, P.dmax);
+            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, soff += 2 * halfb, sp += 2 * RPI) {
+                const v2f n0 = {sp[0], sp[RPI]};
+                const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0;
+                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, soff, soff + halfb), n0, w0, true, true, K0, nK1, rho_u, cr,
+                                      cg, cb, P.dmax);
+            }
             if (Yb <= rend) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
                 const int Ya = Yb + rsub, Yc = Ya + RPI;
-                bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, soff, soff + halfb),
-                                     (v2f){spy[min(Ya, rend) - rb], spy[min(Yc, rend) - rb]}, Ya <= rend, Yc <= rend, adx2,
-                                     bdx, C, cr, cg, cb, P.dmax);
+                const int ia = min(Ya, rend) - rb, ic = min(Yc, rend) - rb;
+                const v2f n0 = {spy[ia], spy[ic]};
+                const v2f w0 = TEST ? (v2f){spy[64 + ia], spy[64 + ic]} : n0;
+                bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, soff, soff + halfb), n0, w0, Ya <= rend, Yc <= rend, K0, nK1,
+                                     rho_u, cr, cg, cb, P.dmax);
             }
         }
-        const float M0 = R.m0.x + R.m0.y, M1 = R.m1.x + R.m1.y, M2 = R.m2.x + R.m2.y;
-        if (inx) {  // (dx is the true difference here; switched-off lanes have M* == 0 anyway)
-            const float sx = dx * M0;
-            acc[0] += sx;
-            acc[1] += M1;
-            acc[2] += dx * sx;
-            acc[3] += dx * M1;
-            acc[4] += M2;
-        }
-        acc[5] += R.k01.x + R.k20.y;
-        acc[6] += R.k01.y + R.k12.x;
-        acc[7] += R.k20.x + R.k12.y;
+        // Expand the column's three sums M0 = sum q, N1 = sum q B, N2 = sum q B^2 (u = dx/sx is a lane constant,
+        // A = u - rho v = u kappa - rho B, v = B + rho u):  sum qA, sum qB, sum q u A, sum q v B, sum q A B.
+        // Every difference is formed between quantities of its own size, so nothing cancels as |rho| -> 1
+        // (the plain monomial moments sum q dx^2, q dx dy, q dy^2 lose 1/(1-rho) digits there).
+        const float M0 = R.m0.x + R.m0.y, N1 = R.m1.x + R.m1.y, N2 = R.m2.x + R.m2.y;
+        // (switched-off lanes have M0 = N1 = N2 = 0, but their u is meaningless: use 0)
+        const float ue = inx ? u : 0.f, uk = ue * kappa;
+        const float sA = uk * M0 - rho * N1;
+        const float e[8] = {sA, N1, ue * sA, N2 + rho * ue * N1, uk * N1 - rho * N2,
+                            R.k01.x + R.k20.y, R.k01.y + R.k12.x, R.k20.x + R.k12.y};
+        // the first (usually only) 64-column strip assigns, so acc[] is not live during its sweep
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = strip == 0 ? e[k] : acc[k] + e[k];
     }
 }
 
@@ -968,8 +986,9 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
         if (r0 > r1) return;
     }
     const float4 ra = V.rec[2 * (size_t)j], rb = V.rec[2 * (size_t)j + 1];
-    const float x = ra.x, y = ra.y, A = ra.z, B = ra.w, cr = rb.x, cg = rb.y, cb = rb.z, C = rb.w;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float x = ra.x, y = ra.y, cr = rb.x, cg = rb.y, cb = rb.z;
+    const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];  // {c, kappa, rho, 1/sx}, {1/sy, ..}
+    float a[8];
     const int bw = c1 - c0 + 1;
     if (chunk < 0) {  // (row chunks of a large Gaussian must not overlap: they keep their ragged tail)
         // Round the row count up to a whole number of trips (8/4/2 rows for 16/32/64-lane columns) when the
@@ -981,7 +1000,8 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
         else if (r0 - pad >= P.row0) r0 -= pad;
     }
     const bool test = BOUNDED && (bb.x & 0x8000u);
-#define GSASR_SWEEP(T, L) bwd_sweep<T, L>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, A, B, C, cr, cg, cb, spy, a)
+#define GSASR_SWEEP(T, L) \
+    bwd_sweep<T, L>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
     if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
     else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
     else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
@@ -1020,17 +1040,17 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, floa
             reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    const float Sx = sa.x, Sy = sa.y, Sxx = sa.z, Sxy = sa.w, Syy = sb.x, Cr = sb.y, Cg = sb.z, Cb = sb.w;
+    const float SqA = sa.x, SqB = sa.y, SquA = sa.z, SqvB = sa.w, SqAB = sb.x, Cr = sb.y, Cg = sb.z, Cb = sb.w;
     const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
-    const float two_w1 = fa.x, w2 = fa.y, w3 = fa.z, w4 = fa.w, rho = fb.x, isx = fb.y, isy = fb.z;
+    const float c = fa.x, isx = fa.w, isy = fb.x;   // c = 1/(1-rho^2) = -2 w1
     const unsigned i = __float_as_uint(fb.w);
-    const float rw3 = rho * w3;
-    const float gx = two_w1 * (rw3 * Sy - w2 * Sx);
-    const float gy = two_w1 * (rw3 * Sx - w4 * Sy);
-    const float gsx = two_w1 * isx * (rw3 * Sxy - w2 * Sxx);
-    const float gsy = two_w1 * isy * (rw3 * Sxy - w4 * Syy);
-    const float qd = w2 * Sxx - 2.f * rw3 * Sxy + w4 * Syy;
-    const float grho = -two_w1 * (two_w1 * rho * qd + w3 * Sxy);
+    // gs.cu:139-146 with u = dx/sx, v = dy/sy, A = u - rho v, B = v - rho u:
+    //   d/dx = c/sx * q A,  d/dy = c/sy * q B,  d/dsx = c/sx * q u A,  d/dsy = c/sy * q v B,  d/drho = c^2 * q A B
+    const float gx = c * isx * SqA;
+    const float gy = c * isy * SqB;
+    const float gsx = c * isx * SquA;
+    const float gsy = c * isy * SqvB;
+    const float grho = c * c * SqAB;
     float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
     if (store) {
         os[0] = gsx; os[1] = gsy; os[2] = grho;
@@ -1055,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned gw = t * 4u + (unsigned)wv;
     const unsigned nwaves = nb * 4u;
-    __shared__ float s_py[4][64];
+    __shared__ float s_py[4][128];  // per wave: v = dy/sy of a 64-row block, then (TEST) the raw dy
     __shared__ __attribute__((aligned(16))) float s_red[4][512];
     float *spy = s_py[wv], *red = s_red[wv];
     const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
