@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Refresh profiles/pmc_latest.json from profiles/r01_pmc_fetch.txt / r01_pmc_write.txt (see its _method field).
+
+    python tools/update_pmc_latest.py [tag]        # tag defaults to r01
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def grab(fn, kern, ctr):
+    lines = open(fn).read().split("\n")
+    for i, l in enumerate(lines):
+        if kern in l:
+            for m in lines[i + 1:i + 4]:
+                if ctr in m:
+                    return float(m.split()[1])
+    raise SystemExit(f"{ctr} for {kern} not found in {fn}")
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    d = json.load(open(p))
+    for k, name in (("k_render_fwd", "k_render_fwd<true>"), ("k_render_bwd", "k_render_bwd<true>")):
+        f = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch.txt"), name, "FETCH_SIZE")
+        w = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_write.txt"), name, "WRITE_SIZE")
+        d[k].update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes=int((2 * f + w) * 1024))
+    json.dump(d, open(p, "w"), indent=1)
+    print(json.dumps(d, indent=1))
+
+
+if __name__ == "__main__":
+    main()
