@@ -22,11 +22,13 @@ EXPORTS = (
     "gsasr_gs_render_dmax", "gsasr_gs_render_backward_dmax", "gsasr_set_default_cutoff",
     "gsasr_get_default_cutoff", "gsasr_prologue_forward", "gsasr_prologue_backward",
     "gsasr_step_workspace_bytes", "gsasr_step_forward", "gsasr_step_backward",
+    "gsasr_band_select", "gsasr_band_merge",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
 FLAG_OVERWRITE_GRADS = 4   # GSASR_FLAG_OVERWRITE_GRADS
 FLAG_CHW_IMAGE = 8         # GSASR_FLAG_CHW_IMAGE
+FLAG_STRIDE8 = 16          # GSASR_FLAG_STRIDE8
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -80,6 +82,10 @@ def lib():
         L.gsasr_step_forward.argtypes = [vp, vp, dp, vp, sz, vp, vp]
         L.gsasr_step_backward.restype = i
         L.gsasr_step_backward.argtypes = [vp, vp, vp, vp, dp, vp, sz, vp]
+        L.gsasr_band_select.restype = i
+        L.gsasr_band_select.argtypes = [vp, dp, i, i, i, vp, vp, vp, vp, vp, vp]
+        L.gsasr_band_merge.restype = i
+        L.gsasr_band_merge.argtypes = [vp, i, vp, vp, vp, vp, vp, i, vp]
         L.gsasr_set_default_cutoff.restype = None
         L.gsasr_set_default_cutoff.argtypes = [f]
         L.gsasr_get_default_cutoff.restype = f
@@ -186,6 +192,84 @@ def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_co
     with torch.cuda.device(p.device):
         check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
+
+
+# ---- packed [N,8] records (GSASR_FLAG_STRIDE8): the wire format of the multi-GPU exchange --------------
+def _cols(packed: torch.Tensor, name: str):
+    base = _chk(packed, name, (8,))
+    if packed.dim() != 2:
+        raise RuntimeError(f"{name} must be [N,8]")
+    return base, base + 12, base + 20      # sigmas, coords, colors columns of the same records
+
+
+def plan_packed(packed: torch.Tensor, h: int, w: int, dmax: Optional[float],
+                rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0, workspace: Optional[torch.Tensor] = None) -> Plan:
+    """`plan` for Gaussians held as one `[N,8]` tensor {sx,sy,rho,x,y,r,g,b}; no unpacking copies."""
+    ps, pc, pk = _cols(packed, "packed")
+    if dmax is not None and not (float(dmax) >= 0.0):
+        raise RuntimeError("dmax must be >= 0")
+    d = make_dims(packed.shape[0], h, w, dmax, rows, cutoff, FLAG_STRIDE8)
+    L = lib()
+    nbytes = L.gsasr_splat_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        check(-1, "gsasr_splat_workspace_bytes")
+    dev = packed.device
+    with torch.cuda.device(dev):
+        ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if ws.numel() < nbytes:
+            raise RuntimeError("workspace smaller than gsasr_splat_workspace_bytes()")
+        check(L.gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), ws.data_ptr(), ws.numel(), _stream(dev)),
+              "gsasr_splat_plan")
+    return Plan(d, ws, dev)
+
+
+def backward_packed(p: Plan, packed: torch.Tensor, grad_img: torch.Tensor, g_packed: torch.Tensor,
+                    overwrite: bool = False) -> None:
+    """`backward` with inputs and gradients as `[N,8]` records (the plan must come from `plan_packed`)."""
+    if not (p.dims.flags & FLAG_STRIDE8):
+        raise RuntimeError("backward_packed needs a plan made by plan_packed")
+    ps, pc, pk = _cols(packed, "packed")
+    gs, gc, gk = _cols(g_packed, "g_packed")
+    pg = _chk(grad_img, "grads", (p.dims.w, 3))
+    if grad_img.shape[0] != p.dims.row1 - p.dims.row0 or g_packed.shape[0] != p.dims.s or packed.shape[0] != p.dims.s:
+        raise RuntimeError("grads / g_packed do not match the plan")
+    d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
+    with torch.cuda.device(p.device):
+        check(lib().gsasr_splat_backward(ps, pc, pk, pg, gs, gc, gk, ctypes.byref(d), p.workspace.data_ptr(),
+                                         p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
+
+
+def _chk_i32(t: torch.Tensor, name: str, n: int) -> int:
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == torch.int32 and t.numel() >= n):
+        raise RuntimeError(f"{name} must be a contiguous int32 CUDA tensor with >= {n} elements")
+    return t.data_ptr()
+
+
+def band_select(packed: torch.Tensor, h: int, w: int, dmax: Optional[float], rows: Tuple[int, int],
+                rows_above: int, rows_below: int, up: torch.Tensor, down: torch.Tensor, up_index: torch.Tensor,
+                down_index: torch.Tensor, counts: torch.Tensor, cutoff: float = 0.0) -> None:
+    """gsasr_band_select: fill `up`/`down` `[cap,8]` with this band's Gaussians that reach the neighbour bands."""
+    base = _chk(packed, "packed", (8,))
+    cap = up.shape[0]
+    if down.shape[0] != cap:
+        raise RuntimeError("up and down must have the same capacity")
+    d = make_dims(packed.shape[0], h, w, dmax, rows, cutoff, FLAG_STRIDE8)
+    with torch.cuda.device(packed.device):
+        check(lib().gsasr_band_select(base, ctypes.byref(d), int(rows_above), int(rows_below), cap,
+                                      _chk(up, "up", (8,)), _chk(down, "down", (8,)), _chk_i32(up_index, "up_index", cap),
+                                      _chk_i32(down_index, "down_index", cap), _chk_i32(counts, "counts", 4),
+                                      _stream(packed.device)), "gsasr_band_select")
+
+
+def band_merge(g_packed: torch.Tensor, g_up: torch.Tensor, g_down: torch.Tensor, up_index: torch.Tensor,
+               down_index: torch.Tensor, counts: torch.Tensor) -> None:
+    """gsasr_band_merge: g_packed[index] += the gradients the neighbours returned for the selected records."""
+    cap = g_up.shape[0]
+    with torch.cuda.device(g_packed.device):
+        check(lib().gsasr_band_merge(_chk(g_packed, "g_packed", (8,)), g_packed.shape[0], _chk(g_up, "g_up", (8,)),
+                                     _chk(g_down, "g_down", (8,)), _chk_i32(up_index, "up_index", cap),
+                                     _chk_i32(down_index, "down_index", cap), _chk_i32(counts, "counts", 4), cap,
+                                     _stream(g_packed.device)), "gsasr_band_merge")
 
 
 def prologue_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int):

@@ -65,6 +65,10 @@ struct Params {
     unsigned flags;  // GSASR_FLAG_*
 };
 
+// element strides of the caller's Gaussian arrays: [s,3]/[s,2]/[s,3], or columns of packed [s,8] records
+__device__ __forceinline__ int stride3(const Params &P) { return (P.flags & GSASR_FLAG_STRIDE8) ? 8 : 3; }
+__device__ __forceinline__ int stride2(const Params &P) { return (P.flags & GSASR_FLAG_STRIDE8) ? 8 : 2; }
+
 struct PlanView {
     unsigned *hdr;          // [HDR_WORDS]
     unsigned *cell_count;   // [ncells+2]   (ncells = "large" class, ncells+1 = "dead" class)
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     if (i < P.h) V.py[i] = (float)(2.0 * (double)i / (double)(P.h - 1) - 1.0);
     unsigned rx = 0, ry = 0, key = 0xffffffffu;
     if (i < P.s) {
-        const float sx = sigmas[i * 3 + 0], sy = sigmas[i * 3 + 1];
-        const float x = coords[i * 2 + 0], y = coords[i * 2 + 1];
+        const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
+        const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1];
+        const float x = coords[i2 + 0], y = coords[i2 + 1];
         const Box b = gaussian_box(sx, sy, x, y, P);
         if (b.cls == 2) {
             key = (unsigned)P.ncells + 1u;
@@ -480,8 +485,9 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     }
     if (i >= P.s) return;
     const unsigned j = (FUSED_SCAN ? s_start[V.key[i]] : V.cell_start[V.key[i]]) + V.rank[i];
-    const float sx = sigmas[i * 3 + 0], sy = sigmas[i * 3 + 1], rho = sigmas[i * 3 + 2];
-    const float x = coords[i * 2 + 0], y = coords[i * 2 + 1];
+    const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
+    const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1], rho = sigmas[i3 + 2];
+    const float x = coords[i2 + 0], y = coords[i2 + 1];
     const Box b = gaussian_box(sx, sy, x, y, P);
     // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56);
     // everything per-Gaussian is evaluated ONCE here, in double, and rounded to float
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     const float C = (float)(w1 * LOG2E * w4);
     // record layout {x, y, A, B | r, g, b, C}: the (r,g) pair is 8-byte aligned for packed-fp32 operands
     V.rec[2 * j + 0] = make_float4(x, y, A, B);
-    V.rec[2 * j + 1] = make_float4(colors[i * 3 + 0], colors[i * 3 + 1], colors[i * 3 + 2], C);
+    V.rec[2 * j + 1] = make_float4(colors[i3 + 0], colors[i3 + 1], colors[i3 + 2], C);
     // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
     // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
     V.fin[2 * j + 0] = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
@@ -1027,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, floa
     if (dead && !store) return;
     if (dead) {  // zero gradient (the epilogue constants of a non-finite Gaussian are not usable)
         const unsigned i = __float_as_uint(V.fin[2 * (size_t)j + 1].w);
-        float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
+        float *os = g_sigmas + (size_t)i * stride3(P), *op = g_coords + (size_t)i * stride2(P), *oc = g_colors + (size_t)i * stride3(P);
         os[0] = os[1] = os[2] = op[0] = op[1] = oc[0] = oc[1] = oc[2] = 0.f;
         return;
     }
@@ -1051,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, floa
     const float gsx = c * isx * SquA;
     const float gsy = c * isy * SqvB;
     const float grho = c * c * SqAB;
-    float *os = g_sigmas + (size_t)i * 3, *op = g_coords + (size_t)i * 2, *oc = g_colors + (size_t)i * 3;
+    float *os = g_sigmas + (size_t)i * stride3(P), *op = g_coords + (size_t)i * stride2(P), *oc = g_colors + (size_t)i * stride3(P);
     if (store) {
         os[0] = gsx; os[1] = gsy; os[2] = grho;
         op[0] = gx;  op[1] = gy;
@@ -1165,6 +1171,78 @@ int check_ws(const gsasr_dims *dims, const void *ws, size_t ws_bytes, Layout &L)
     if (!ws || ((uintptr_t)ws & 255u)) return fail(GSASR_ERR_WORKSPACE, "workspace null or not 256-byte aligned");
     if (ws_bytes < L.total) return fail(GSASR_ERR_WORKSPACE, "workspace smaller than gsasr_splat_workspace_bytes()");
     return GSASR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// row-band shard: neighbour exchange (device side of gsasr_amd/shard.py)
+// ---------------------------------------------------------------------------------------------------
+// One thread per Gaussian: its row window on the FULL grid (the same gaussian_box() the plan uses, so the
+// selection is exactly the set of Gaussians the neighbour's plan would keep) against this rank's band.
+__global__ __launch_bounds__(256) void k_band_select(Params P, int band0, int band1, int rows_above, int rows_below,
+                                                     int cap, const float *__restrict__ packed,
+                                                     float *__restrict__ up, float *__restrict__ down,
+                                                     int *__restrict__ up_index, int *__restrict__ down_index,
+                                                     int *__restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool go_up = false, go_down = false, far = false;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    if (i < P.s) {
+        ra = reinterpret_cast<const float4 *>(packed)[2 * (size_t)i];      // sx sy rho x
+        rb = reinterpret_cast<const float4 *>(packed)[2 * (size_t)i + 1];  // y r g b
+        const Box b = gaussian_box(ra.x, ra.y, ra.w, rb.x, P);             // P.row0/row1 = whole grid here
+        if (b.cls != 2) {
+            go_up = rows_above > 0 && b.r0 < band0;
+            go_down = rows_below > 0 && b.r1 >= band1;
+            far = (go_up && b.r0 < band0 - rows_above) || (go_down && b.r1 >= band1 + rows_below);
+        }
+    }
+    // wave-aggregated slot allocation: one returning atomic per wave and list
+    const unsigned long long mu = __ballot(go_up), md = __ballot(go_down), mf = __ballot(far);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int bu = 0, bd = 0;
+    if (lane == 0) {
+        if (mu) bu = atomicAdd(&counts[0], __builtin_popcountll(mu));
+        if (md) bd = atomicAdd(&counts[1], __builtin_popcountll(md));
+        if (mf) atomicAdd(&counts[2], __builtin_popcountll(mf));
+    }
+    bu = __shfl(bu, 0);
+    bd = __shfl(bd, 0);
+    if (go_up) {
+        const int slot = bu + __builtin_popcountll(mu & below);
+        if (slot < cap) {
+            reinterpret_cast<float4 *>(up)[2 * (size_t)slot] = ra;
+            reinterpret_cast<float4 *>(up)[2 * (size_t)slot + 1] = rb;
+            up_index[slot] = i;
+        }
+    }
+    if (go_down) {
+        const int slot = bd + __builtin_popcountll(md & below);
+        if (slot < cap) {
+            reinterpret_cast<float4 *>(down)[2 * (size_t)slot] = ra;
+            reinterpret_cast<float4 *>(down)[2 * (size_t)slot + 1] = rb;
+            down_index[slot] = i;
+        }
+    }
+}
+
+// 8 threads per returned record; a Gaussian can sit in both lists, hence atomics (two adds at most per word)
+__global__ __launch_bounds__(256) void k_band_merge(int s, int cap, float *__restrict__ g_packed,
+                                                    const float *__restrict__ g_up, const float *__restrict__ g_down,
+                                                    const int *__restrict__ up_index, const int *__restrict__ down_index,
+                                                    const int *__restrict__ counts)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t >> 3, k = t & 7;
+    if (j >= 2 * cap) return;
+    const bool is_down = j >= cap;
+    const int jj = is_down ? j - cap : j;
+    if (jj >= min(counts[is_down ? 1 : 0], cap)) return;
+    const int i = (is_down ? down_index : up_index)[jj];
+    if ((unsigned)i >= (unsigned)s) return;
+    atomicAdd(&g_packed[(size_t)i * 8 + k], (is_down ? g_down : g_up)[(size_t)jj * 8 + k]);
 }
 
 }  // namespace
@@ -1349,6 +1427,7 @@ int gsasr_step_forward(const float *gs_parameters, const float *step_size, const
                        size_t workspace_bytes, float *img, void *stream)
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
+    if (dims->flags & GSASR_FLAG_STRIDE8) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 does not apply to the step entry points");
     const StepLayout S = make_step_layout(dims);
     if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
@@ -1364,6 +1443,7 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
                         void *stream)
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
+    if (dims->flags & GSASR_FLAG_STRIDE8) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 does not apply to the step entry points");
     const StepLayout S = make_step_layout(dims);
     if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
@@ -1374,6 +1454,44 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
     d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
     if (int rc = gsasr_splat_backward(sig, xy, col, grad_img, gs, gc, gk, &d, workspace, S.plan_bytes, stream)) return rc;
     return gsasr_prologue_backward(gs_parameters, step_size, dims->s, dims->h, dims->w, gs, gc, gk, g_parameters, stream);
+}
+
+
+int gsasr_band_select(const float *packed, const gsasr_dims *dims, int rows_above, int rows_below, int cap,
+                      float *up, float *down, int *up_index, int *down_index, int *counts, void *stream)
+{
+    if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
+    if (cap < 0 || rows_above < 0 || rows_below < 0 || !counts || (cap > 0 && (!up || !down || !up_index || !down_index)) ||
+        (dims->s > 0 && !packed))
+        return fail(GSASR_ERR_ARG, "gsasr_band_select: null pointer or negative size");
+    hipStream_t st = (hipStream_t)stream;
+    gsasr_dims whole = *dims;   // the footprint is taken on the full grid, then compared with the band
+    whole.row0 = 0;
+    whole.row1 = dims->h;
+    const Layout L = make_layout(&whole);
+    const Params P = make_params(&whole, L);
+    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int), st));
+    if (cap > 0) {  // 0xff.. = NaN records: dead Gaussians for every kernel of this library
+        HIP_TRY(hipMemsetAsync(up, 0xff, (size_t)cap * 32, st));
+        HIP_TRY(hipMemsetAsync(down, 0xff, (size_t)cap * 32, st));
+    }
+    if (dims->s > 0)
+        hipLaunchKernelGGL(k_band_select, dim3((dims->s + 255) / 256), dim3(256), 0, st, P, dims->row0, dims->row1,
+                           rows_above, rows_below, cap, packed, up, down, up_index, down_index, counts);
+    HIP_TRY(hipGetLastError());
+    return GSASR_OK;
+}
+
+int gsasr_band_merge(float *g_packed, int s, const float *g_up, const float *g_down, const int *up_index,
+                     const int *down_index, const int *counts, int cap, void *stream)
+{
+    if (s < 0 || cap < 0 || !counts || (cap > 0 && (!g_packed || !g_up || !g_down || !up_index || !down_index)))
+        return fail(GSASR_ERR_ARG, "gsasr_band_merge: null pointer or negative size");
+    if (cap == 0 || s == 0) return GSASR_OK;
+    hipLaunchKernelGGL(k_band_merge, dim3((2 * cap * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, s, cap,
+                       g_packed, g_up, g_down, up_index, down_index, counts);
+    HIP_TRY(hipGetLastError());
+    return GSASR_OK;
 }
 
 // ---- reference-shaped launchers -------------------------------------------------------------------

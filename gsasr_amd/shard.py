@@ -11,8 +11,12 @@ because every output pixel is an independent sum and every Gaussian gradient is 
               `reduce_scatter_tensor` (rank g keeps the gradients of Gaussians [g*N/G,(g+1)*N/G)), or
               `all_reduce` when every rank needs all of them (replicated decoder).
 
-Both collectives move <= 32*N bytes (33.5 MB at N = 1M): on 7 x ~153 GB/s xGMI links that is tens of
-microseconds, so a single un-bucketed call per step is the right granularity.
+Both collectives move <= 32*N bytes per rank (33.5 MB at N = 1M) and grow with the group: fine for one
+large image, but they dominate a step whose local work is ~0.1 ms.  When every rank PRODUCES the Gaussians
+of its own band (a spatially sharded encoder/decoder, or tiled inference), `BandExchange` replaces both by
+a nearest-neighbour exchange: only the Gaussians whose footprint crosses a band edge travel (to the rank
+above / below, point-to-point -- which is what xGMI links are), and only their partial gradients come back.
+Volume and latency are then independent of the group size.
 
 The local rasterizer is pluggable only so the collective plumbing can be tested with gloo on CPU
 (tests/ inject the oracle); the default and only product backend is the HIP library.
@@ -56,6 +60,30 @@ def broadcast_gaussians(sigmas, coords, colors, src: int = 0, group=None):
 
 class HipBackend:
     """Local band rasterizer = libgsasr_splat.so through the C ABI (the product path)."""
+
+    # ---- packed [N,8] records (BandExchange) ----
+    @staticmethod
+    def forward_packed(records, h, w, dmax, rows, cutoff=0.0):
+        from . import _cabi
+        plan = _cabi.plan_packed(records, h, w, dmax, rows=rows, cutoff=cutoff)
+        slab = torch.empty(rows[1] - rows[0], w, 3, device=records.device, dtype=torch.float32)
+        _cabi.forward(plan, slab, overwrite=True)
+        return slab, plan
+
+    @staticmethod
+    def backward_packed(state, records, grad_slab, g_records):
+        from . import _cabi
+        _cabi.backward_packed(state, records, grad_slab.contiguous(), g_records, overwrite=True)
+
+    @staticmethod
+    def select(own, h, w, dmax, rows, rows_above, rows_below, up, down, up_index, down_index, counts, cutoff=0.0):
+        from . import _cabi
+        _cabi.band_select(own, h, w, dmax, rows, rows_above, rows_below, up, down, up_index, down_index, counts, cutoff)
+
+    @staticmethod
+    def merge(g_own, g_up, g_down, up_index, down_index, counts):
+        from . import _cabi
+        _cabi.band_merge(g_own, g_up, g_down, up_index, down_index, counts)
 
     @staticmethod
     def forward(sigmas, coords, colors, h, w, dmax, rows):
@@ -144,3 +172,136 @@ def gather_image(slab: torch.Tensor, h: int, group=None) -> torch.Tensor:
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf, group=group)
     return torch.cat([parts[r][: row_band(h, r, world)[1] - row_band(h, r, world)[0]] for r in range(world)], dim=0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Band-local (nearest-neighbour) exchange
+# ---------------------------------------------------------------------------------------------------
+class BandExchange:
+    """Buffers and the two point-to-point exchanges of a row-band shard with a SHARDED producer.
+
+    Rank g owns HR rows `row_band(h, g, G)` and holds `n_local` Gaussians (those its decoder produced:
+    normally the ones centred in its band, but any assignment works).  Per step:
+
+      forward : `select` (one kernel) lists the own Gaussians whose row footprint -- the plan's window,
+                dmax box ∩ support -- reaches above / below the band into fixed-capacity `[cap,8]` buffers
+                (NaN = dead padding); ONE batched isend/irecv swaps them with ranks g-1 and g+1; the local
+                plan then runs over `records = [own | from_above | from_below]`.
+      backward: the local backward writes `g_records` for all three parts; the two halo parts are sent
+                back (same batched call, reversed) and `merge` adds them into the owners' gradients.
+
+    Nothing here synchronises the host.  Two conditions cannot be detected without reading `counts`
+    (device): more than `cap` Gaussians selected for one side, or a footprint reaching beyond the adjacent
+    band.  `check()` reads them (host sync) and raises; call it once after warm-up or every few steps.
+    """
+
+    def __init__(self, n_local: int, cap: int, h: int, w: int, dmax: Optional[float], cutoff: float = 0.0,
+                 device=None, group=None, backend=None, rank: Optional[int] = None, world: Optional[int] = None):
+        self.group, self.backend = group, backend or HipBackend
+        # rank/world default to the process group's; explicit values let one process drive several bands
+        # (single-GPU tests, or a host that time-multiplexes bands)
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        self.world = dist.get_world_size(group) if world is None else int(world)
+        self.h, self.w, self.dmax, self.cutoff = int(h), int(w), dmax, float(cutoff)
+        self.n, self.cap = int(n_local), int(cap)
+        self.rows = row_band(self.h, self.rank, self.world)
+        span = lambda r: row_band(self.h, r, self.world)[1] - row_band(self.h, r, self.world)[0]
+        self.rows_above = span(self.rank - 1) if self.rank > 0 else 0
+        self.rows_below = span(self.rank + 1) if self.rank < self.world - 1 else 0
+        f = dict(device=device, dtype=torch.float32)
+        n, c = self.n, self.cap
+        self.records = torch.full((n + 2 * c, 8), float("nan"), **f)      # [own | from_above | from_below]
+        self.g_records = torch.zeros(n + 2 * c, 8, **f)
+        self.send_up, self.send_down = torch.empty(c, 8, **f), torch.empty(c, 8, **f)
+        self.ret_up, self.ret_down = torch.zeros(c, 8, **f), torch.zeros(c, 8, **f)
+        self.up_index = torch.zeros(c, device=device, dtype=torch.int32)
+        self.down_index = torch.zeros(c, device=device, dtype=torch.int32)
+        self.counts = torch.zeros(4, device=device, dtype=torch.int32)
+
+    @property
+    def own(self) -> torch.Tensor:
+        """`[n_local,8]` view the producer writes this rank's Gaussians into."""
+        return self.records[: self.n]
+
+    @property
+    def from_above(self) -> torch.Tensor:
+        return self.records[self.n: self.n + self.cap]
+
+    @property
+    def from_below(self) -> torch.Tensor:
+        return self.records[self.n + self.cap:]
+
+    def select(self) -> None:
+        """fill send_up / send_down (+ indices, counts) from `own`"""
+        self.backend.select(self.own, self.h, self.w, self.dmax, self.rows, self.rows_above, self.rows_below,
+                            self.send_up, self.send_down, self.up_index, self.down_index, self.counts, self.cutoff)
+
+    def merge(self) -> torch.Tensor:
+        """add the returned halo gradients (ret_up / ret_down) into the own part of g_records"""
+        self.backend.merge(self.g_records[: self.n], self.ret_up, self.ret_down, self.up_index, self.down_index,
+                           self.counts)
+        return self.g_records[: self.n]
+
+    def _swap(self, to_above, from_above, to_below, from_below):
+        ops = []
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, to_above, self._peer(self.rank - 1), self.group),
+                    dist.P2POp(dist.irecv, from_above, self._peer(self.rank - 1), self.group)]
+        if self.rank < self.world - 1:
+            ops += [dist.P2POp(dist.isend, to_below, self._peer(self.rank + 1), self.group),
+                    dist.P2POp(dist.irecv, from_below, self._peer(self.rank + 1), self.group)]
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+    def _peer(self, group_rank: int) -> int:
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
+
+    def exchange_forward(self) -> torch.Tensor:
+        """own Gaussians are in `self.own`; returns `records` with the neighbours' halos in place."""
+        self.select()
+        self._swap(self.send_up, self.from_above, self.send_down, self.from_below)
+        return self.records
+
+    def exchange_backward(self) -> torch.Tensor:
+        """`self.g_records` holds the local backward's output; returns the complete gradients of the own
+        Gaussians (`[n_local,8]` view of `g_records`)."""
+        n, c = self.n, self.cap
+        self._swap(self.g_records[n:n + c], self.ret_up, self.g_records[n + c:], self.ret_down)
+        return self.merge()
+
+    def check(self) -> Tuple[int, int]:
+        """Host-synchronising validity check of the last `exchange_forward`; returns (n_up, n_down)."""
+        n_up, n_down, n_far, _ = (int(v) for v in self.counts.tolist())
+        if n_up > self.cap or n_down > self.cap:
+            raise RuntimeError(f"BandExchange: {max(n_up, n_down)} Gaussians cross a band edge but cap = {self.cap}; "
+                               "results of this step are incomplete -- enlarge cap")
+        if n_far:
+            raise RuntimeError(f"BandExchange: {n_far} Gaussians reach beyond the adjacent band (bands too thin for "
+                               "this dmax / cutoff); use broadcast_gaussians + splat_band instead")
+        return n_up, n_down
+
+
+class _BandLocalSplat(Function):
+    @staticmethod
+    def forward(ctx, packed_local, ex):
+        if packed_local.data_ptr() != ex.own.data_ptr():
+            ex.own.copy_(packed_local)
+        records = ex.exchange_forward()
+        slab, state = ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff)
+        ctx.ex, ctx.state = ex, state
+        return slab
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_slab):
+        ex = ctx.ex
+        ex.backend.backward_packed(ctx.state, ex.records, grad_slab, ex.g_records)
+        return ex.exchange_backward().clone(), None
+
+
+def splat_band_local(packed_local: torch.Tensor, ex: BandExchange) -> torch.Tensor:
+    """Render this rank's row band from the Gaussians it produced (`[n_local,8]` records) plus the
+    neighbours' halos; differentiable w.r.t. `packed_local`, whose gradient includes what the
+    neighbouring bands contribute.  Returns `[r1-r0, w, 3]`."""
+    return _BandLocalSplat.apply(packed_local, ex)

@@ -52,6 +52,10 @@ enum gsasr_status {
                                          returns, utils/gaussian_splatting.py:129) instead of [row1-row0, w, 3] */
 #define GSASR_FLAG_OVERWRITE_GRADS 4u /* backward STORES the gradients (outputs need not be zeroed) instead
                                          of adding into them */
+#define GSASR_FLAG_STRIDE8 16u        /* sigmas/coords/colors AND g_sigmas/g_coords/g_colors are columns of packed
+                                         [s,8] records {sx,sy,rho,x,y,r,g,b}: element k of Gaussian i is at
+                                         ptr[8*i+k].  Pass base, base+3, base+5 of one array; this is the wire
+                                         format of the multi-GPU exchange, so nothing is repacked around it */
 
 typedef struct gsasr_dims {
     int s;        /* number of Gaussians                                              */
@@ -135,6 +139,26 @@ int gsasr_gs_render_backward_dmax(const float *sigmas, const float *coords, cons
                                   const float *grads, float *grads_sigmas, float *grads_coords,
                                   float *grads_colors, int s, int h, int w, int c, float dmax,
                                   void *stream);
+
+/* Row-band shard (one process per GPU): neighbour exchange of the Gaussians whose footprint
+ * crosses an edge of this rank's band.  The reference has no counterpart (its rasterizer is rank-local,
+ * basicsr/models/base_model.py:96-99); these two kernels are the device side of gsasr_amd/shard.py.
+ *
+ * gsasr_band_select: `packed` is this rank's [s,8] Gaussians, dims = FULL grid h,w with [row0,row1) the
+ * rank's band, dmax/cutoff as for the plan (the footprint is the plan's own row window: box ∩ support).
+ * Gaussians reaching rows < row0 are appended to up[cap,8] (+ their index to up_index[cap]), those reaching
+ * rows >= row1 to down/down_index; unused slots are filled with NaN records, which every kernel of this
+ * library treats as dead Gaussians.  counts[4] (device) = {n_up, n_down, n_far, 0}: n_up/n_down may exceed
+ * `cap` (overflow: the excess was dropped -- the caller must check and re-run with a larger cap), n_far =
+ * Gaussians reaching beyond the adjacent band (more than rows_above above row0 / rows_below below row1),
+ * which a nearest-neighbour exchange cannot serve.  rows_above/rows_below = 0: no neighbour on that side.
+ *
+ * gsasr_band_merge: g_packed[index[j], :] += g_up[j, :] for j < min(n_up, cap), same for down: adds the
+ * partial gradients a neighbour computed for the records it was sent. */
+int gsasr_band_select(const float *packed, const gsasr_dims *dims, int rows_above, int rows_below, int cap,
+                      float *up, float *down, int *up_index, int *down_index, int *counts, void *stream);
+int gsasr_band_merge(float *g_packed, int s, const float *g_up, const float *g_down, const int *up_index,
+                     const int *down_index, const int *counts, int cap, void *stream);
 
 /* Process-wide default used when dims.cutoff == 0 (initially GSASR_SPLAT_DEFAULT_CUTOFF, or the
  * value of the environment variable GSASR_SPLAT_CUTOFF if set). */

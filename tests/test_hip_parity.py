@@ -562,3 +562,104 @@ def test_fuzz_extreme_parameters(seed, dev):
         bad = (err > tol) & well[:, None]
         assert not bad.any(), (name, int(np.argwhere(bad)[0][0]), float(err[bad].max()), float(np.abs(want).max()),
                                sig[np.argwhere(bad)[0][0]].tolist())
+
+
+# ---------------------------------------------------------------------------------------------------
+# packed [N,8] records (GSASR_FLAG_STRIDE8) and the band-local exchange kernels
+# ---------------------------------------------------------------------------------------------------
+def test_packed_records_equal_separate_arrays(dev):
+    from gsasr_amd import _cabi, shard, synthetic
+    sig, xy, col, H, W = synthetic.kernel_inputs(48, 40, 4.0, seed=90, device=dev)
+    wgt = synthetic.grad_image(H, W, 91, device=dev)
+    for dmax in (None, 0.2):
+        full, st = shard.HipBackend.forward(sig, xy, col, H, W, dmax, (0, H))
+        g = shard.HipBackend.backward(st, sig, xy, col, wgt)
+        rec = shard.pack(sig, xy, col)
+        slab, st2 = shard.HipBackend.forward_packed(rec, H, W, dmax, (0, H))
+        grec = torch.full_like(rec, float("nan"))
+        shard.HipBackend.backward_packed(st2, rec, wgt, grec)
+        assert float((slab - full).abs().max()) <= 1e-6
+        for a, b in zip(shard.unpack(grec), g):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        # accumulate-into contract holds for the packed outputs too
+        gacc = torch.ones_like(rec)
+        _cabi.backward_packed(st2, rec, wgt, gacc, overwrite=False)
+        assert float((gacc - 1 - grec).abs().max()) <= 1e-5 * float(grec.abs().max())
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_band_exchange_emulated_on_one_gpu(world, dev):
+    """G bands driven from one process: select -> (copies standing in for the P2P swap) -> local plan over
+    [own | halos] -> backward -> return halos -> merge; equals the single full-image render and gradient."""
+    from gsasr_amd import shard, synthetic
+    h_lr, w_lr, scale, dmax = 64, 24, 4.0, 0.08
+    sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=92, device=dev)
+    wgt = synthetic.grad_image(H, W, 93, device=dev)
+    rec = shard.pack(sig, xy, col)
+    full, st = shard.HipBackend.forward_packed(rec, H, W, dmax, (0, H))
+    gfull = torch.empty_like(rec)
+    shard.HipBackend.backward_packed(st, rec, wgt, gfull)
+
+    cap = 1024
+    exs = []
+    for r in range(world):
+        lr0, lr1 = shard.row_band(h_lr, r, world)
+        ex = shard.BandExchange((lr1 - lr0) * w_lr, cap, H, W, dmax, device=dev, rank=r, world=world)
+        ex.lr = (lr0 * w_lr, lr1 * w_lr)
+        ex.own.copy_(rec[ex.lr[0]: ex.lr[1]])
+        ex.select()
+        exs.append(ex)
+    n_cross = 0
+    for r, ex in enumerate(exs):
+        n_up, n_down = ex.check()
+        n_cross += n_up + n_down
+        # padding is NaN, selected records are copies of own records at the stored indices
+        assert torch.isnan(ex.send_up[n_up:]).all() and torch.isnan(ex.send_down[n_down:]).all()
+        assert torch.equal(ex.send_up[:n_up], ex.own[ex.up_index[:n_up].long()])
+        assert torch.equal(ex.send_down[:n_down], ex.own[ex.down_index[:n_down].long()])
+        if r > 0:
+            ex.from_above.copy_(exs[r - 1].send_down)
+        if r < world - 1:
+            ex.from_below.copy_(exs[r + 1].send_up)
+    assert n_cross > 0
+    states = []
+    for ex in exs:
+        slab, st = shard.HipBackend.forward_packed(ex.records, H, W, dmax, ex.rows)
+        assert float((slab - full[ex.rows[0]: ex.rows[1]]).abs().max()) <= 1e-5
+        shard.HipBackend.backward_packed(st, ex.records, wgt[ex.rows[0]: ex.rows[1]].contiguous(), ex.g_records)
+        states.append(st)
+    for r, ex in enumerate(exs):
+        n, c = ex.n, ex.cap
+        if r > 0:
+            ex.ret_up.copy_(exs[r - 1].g_records[exs[r - 1].n + c:])        # what rank r-1 computed for my send_up
+        if r < world - 1:
+            ex.ret_down.copy_(exs[r + 1].g_records[exs[r + 1].n: exs[r + 1].n + c])
+    for ex in exs:
+        g = ex.merge()
+        want = gfull[ex.lr[0]: ex.lr[1]]
+        for cols in (slice(0, 3), slice(3, 5), slice(5, 8)):
+            assert float((g[:, cols] - want[:, cols]).abs().max()) <= 2e-4 * float(gfull[:, cols].abs().max())
+
+
+def test_band_select_flags_overflow_and_far(dev):
+    from gsasr_amd import shard, synthetic
+    sig, xy, col, H, W = synthetic.kernel_inputs(64, 24, 4.0, seed=94, device=dev)
+    rec = shard.pack(sig, xy, col)
+    # 16 thin bands with the unbounded op and no cutoff: every footprint spans the whole image -> "far"
+    ex = shard.BandExchange(rec.shape[0], 8, H, W, None, cutoff=-1.0, device=dev, rank=5, world=16)
+    ex.own.copy_(rec)
+    ex.select()
+    n_up, n_down, n_far, _ = ex.counts.tolist()
+    assert n_up == n_down == n_far == rec.shape[0]
+    with pytest.raises(RuntimeError, match="enlarge cap"):
+        ex.check()
+    ex2 = shard.BandExchange(rec.shape[0], rec.shape[0], H, W, None, cutoff=-1.0, device=dev, rank=5, world=16)
+    ex2.own.copy_(rec)
+    ex2.select()
+    with pytest.raises(RuntimeError, match="beyond the adjacent band"):
+        ex2.check()
+    # edge ranks have no neighbour on one side
+    top = shard.BandExchange(rec.shape[0], rec.shape[0], H, W, 0.05, device=dev, rank=0, world=2)
+    top.own.copy_(rec)
+    top.select()
+    assert top.counts[0].item() == 0 and top.counts[1].item() > 0 and top.counts[2].item() == 0

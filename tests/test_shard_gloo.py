@@ -118,3 +118,114 @@ def test_single_process_without_dist_is_full_image():
     sig, xy, col, H, W = synthetic.kernel_inputs(6, 6, 3.0, seed=9)
     slab = shard.splat_band(sig, xy, col, H, W, dmax=None, backend=OracleBackend)
     assert slab.shape == (H, W, 3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# band-local exchange (BandExchange): every rank produces the Gaussians of its own band
+# ---------------------------------------------------------------------------------------------------
+class OraclePackedBackend(OracleBackend):
+    """CPU stand-in for the packed half of HipBackend; NaN records are dead padding, as in the library."""
+
+    @staticmethod
+    def _live(records):
+        return torch.isfinite(records).all(dim=1)
+
+    @classmethod
+    def forward_packed(cls, records, h, w, dmax, rows, cutoff=0.0):
+        live = cls._live(records)
+        s, c, k = shard.unpack(records[live])
+        slab, _ = OracleBackend.forward(s, c, k, h, w, dmax, rows)
+        return slab, (h, w, dmax, rows, live)
+
+    @classmethod
+    def backward_packed(cls, state, records, grad_slab, g_records):
+        h, w, dmax, rows, live = state
+        s, c, k = shard.unpack(records[live])
+        g = OracleBackend.backward((h, w, dmax, rows), s, c, k, grad_slab)
+        g_records.zero_()
+        g_records[live] = shard.pack(*g)
+
+    @staticmethod
+    def select(own, h, w, dmax, rows, rows_above, rows_below, up, down, up_index, down_index, counts, cutoff=0.0):
+        # conservative footprint: the dmax box in rows (+ half a pixel), as the exact-semantics oracle needs
+        y = own[:, 4].double()
+        hy = 0.5 * (h - 1)
+        r0 = torch.ceil((y - dmax + 1.0) * hy - 0.5).clamp(min=0)
+        r1 = torch.floor((y + dmax + 1.0) * hy + 0.5).clamp(max=h - 1)
+        live = torch.isfinite(own).all(dim=1) & (r0 <= r1)
+        go_up = live & (r0 < rows[0]) & (rows_above > 0)
+        go_down = live & (r1 >= rows[1]) & (rows_below > 0)
+        far = (go_up & (r0 < rows[0] - rows_above)) | (go_down & (r1 >= rows[1] + rows_below))
+        cap = up.shape[0]
+        for buf, idx, m in ((up, up_index, go_up), (down, down_index, go_down)):
+            buf.fill_(float("nan"))
+            sel = torch.nonzero(m).flatten()[:cap]
+            buf[: sel.numel()] = own[sel]
+            idx[: sel.numel()] = sel.int()
+        counts[0], counts[1], counts[2], counts[3] = int(go_up.sum()), int(go_down.sum()), int(far.sum()), 0
+
+    @staticmethod
+    def merge(g_own, g_up, g_down, up_index, down_index, counts):
+        cap = g_up.shape[0]
+        for g, idx, n in ((g_up, up_index, int(counts[0])), (g_down, down_index, int(counts[1]))):
+            n = min(n, cap)
+            g_own.index_add_(0, idx[:n].long(), g[:n])
+
+
+H_LR, W_LR, SCALE, DMAX_X = 12, 10, 3.0, 0.2
+
+
+def _exchange_worker(rank, world, port, cap, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
+        lr0, lr1 = shard.row_band(H_LR, rank, world)           # this rank "decodes" its own LR rows
+        mine = shard.pack(sig, xy, col)[lr0 * W_LR: lr1 * W_LR]
+        ex = shard.BandExchange(mine.shape[0], cap, H, W, DMAX_X, backend=OraclePackedBackend)
+        p = mine.clone().requires_grad_(True)
+        slab = shard.splat_band_local(p, ex)
+        err = None
+        try:
+            counts = ex.check()
+        except RuntimeError as e:
+            counts, err = None, str(e)
+        r0, r1 = ex.rows
+        wgt = synthetic.grad_image(H, W, 6)
+        (slab * wgt[r0:r1]).sum().backward()
+        out[rank] = dict(slab=slab.detach().numpy(), rows=(r0, r1), g=p.grad.numpy(), lr=(lr0, lr1), counts=counts, err=err)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_exchange_matches_single_process(world):
+    from oracle import gs_oracle
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, _free_port(), 64, out), nprocs=world, join=True)
+    sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
+    wgt = synthetic.grad_image(H, W, 6)
+    ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, DMAX_X)
+    gref = shard.pack(*(torch.from_numpy(a) for a in
+                        gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), DMAX_X))).numpy()
+    crossing = 0
+    for r in range(world):
+        o = out[r]
+        assert o["err"] is None, o["err"]
+        crossing += sum(o["counts"])
+        r0, r1 = o["rows"]
+        np.testing.assert_allclose(o["slab"], ref[r0:r1], rtol=0, atol=1e-5)
+        a, b = o["lr"][0] * W_LR, o["lr"][1] * W_LR
+        for cols in (slice(0, 3), slice(3, 5), slice(5, 8)):       # complete gradients of the rank's own Gaussians
+            want = gref[a:b, cols]
+            assert np.abs(o["g"][:, cols] - want).max() <= 1e-5 * np.abs(gref[:, cols]).max()
+    assert crossing > 0     # the case does exercise the exchange
+
+
+def test_band_exchange_reports_overflow():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange_worker, args=(2, _free_port(), 2, out), nprocs=2, join=True)   # cap far too small
+    assert any(out[r]["err"] and "enlarge cap" in out[r]["err"] for r in range(2))
