@@ -9,8 +9,12 @@ plan (bin) -> forward splat into a fresh [H,W,3] image -> backward to {sigmas, c
 
   N = 1   BASELINE.json config 2: 256x256 LR -> x4 (1024^2 HR), 65 536 Gaussians (1 per LR pixel), fp32.
   N > 1   weak scaling of the row-band shard: the image grows to (1024*N) x 1024 with
-          65 536*N Gaussians; rank g renders rows [g*1024,(g+1)*1024).  Per step: ONE broadcast of the
-          [N_g,8] Gaussians from rank 0 and ONE reduce_scatter of the per-Gaussian gradients (RCCL).
+          65 536*N Gaussians; rank g renders rows [g*1024,(g+1)*1024).
+          --exchange halo (default): rank g holds the Gaussians of its own band (sharded producer); per step
+            ONE batched point-to-point swap of the Gaussians that cross a band edge with ranks g-1/g+1 before
+            the plan, and ONE swap of their partial gradients after the backward (RCCL send/recv over xGMI).
+          --exchange broadcast: ONE broadcast of all [N,8] Gaussians from rank 0 and ONE reduce_scatter of
+            the per-Gaussian gradients per step (the literal 8e pattern; volume grows with N).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel, measured
 live with events on the launch stream) and `cpu_baseline` (the oracle on the host cores, bounded sample).
@@ -47,6 +51,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "broadcast"],
+                    help="multi-rank data path: neighbour halo swap (default) or broadcast + reduce_scatter")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even at world size 1 (self-test)")
     return ap.parse_args()
 
@@ -65,16 +71,40 @@ class Step:
         self.fwd_only = args.fwd_only or args.config == "c3"
         sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=0, device="cpu")
         self.H, self.W, self.n = H, W, sig.shape[0]
+        self.n_rank = self.n
         self.rows = row_band(H, rank, world)
         self.dmax = None if args.dmax < 0 else args.dmax
         self.cutoff = args.cutoff
-        self.sig, self.xy, self.col = (t.to(dev) for t in (sig, xy, col))
         nrows = self.rows[1] - self.rows[0]
         self.grad_img = synthetic.grad_image(H, W, 1)[self.rows[0]:self.rows[1]].contiguous().to(dev)
         self.img = torch.zeros(nrows, W, 3, device=dev)
+        self.dist = world > 1 or args.force_dist
+        self.halo = self.dist and args.exchange == "halo"
+        self.ex = None
+        if self.halo:
+            # sharded producer: this rank holds the Gaussians of its own LR rows (raster order => one slice)
+            import torch.distributed as dist
+            from gsasr_amd import shard
+            lr0, lr1 = row_band(h_lr, rank, world)
+            mine = shard.pack(sig, xy, col)[lr0 * w_lr: lr1 * w_lr].to(dev)
+            n_local = mine.shape[0]
+            probe = shard.BandExchange(n_local, max(n_local, 1), H, W, self.dmax, self.cutoff, device=dev)
+            probe.own.copy_(mine)
+            probe.select()
+            need = torch.tensor([max(probe.check())], device=dev)       # raises if a footprint outreaches a band
+            if world > 1:
+                dist.all_reduce(need, op=dist.ReduceOp.MAX)
+            self.halo_records = int(need.item())
+            cap = max(1024, -(-int(self.halo_records * 1.25) // 1024) * 1024)
+            del probe
+            self.ex = shard.BandExchange(n_local, cap, H, W, self.dmax, self.cutoff, device=dev)
+            self.ex.own.copy_(mine)
+            self.n_rank = n_local
+            self.plan = _cabi.plan_packed(self.ex.records, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
+            return
+        self.sig, self.xy, self.col = (t.to(dev) for t in (sig, xy, col))
         self.g = [torch.zeros_like(t) for t in (self.sig, self.xy, self.col)]
         self.plan = _cabi.plan(self.sig, self.xy, self.col, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
-        self.dist = world > 1 or args.force_dist
         if self.dist:
             from gsasr_amd import shard
             self.shard = shard
@@ -87,6 +117,10 @@ class Step:
     def do_plan(self):
         import ctypes
         p = self.plan
+        if self.halo:
+            self.cabi.plan_packed(self.ex.records, self.H, self.W, self.dmax, rows=self.rows, cutoff=self.cutoff,
+                                  workspace=p.workspace)
+            return
         self.cabi.check(self.cabi.lib().gsasr_splat_plan(self.sig.data_ptr(), self.xy.data_ptr(), self.col.data_ptr(),
                                                          ctypes.byref(p.dims), p.workspace.data_ptr(),
                                                          p.workspace.numel(), self.cabi._stream(self.dev)), "plan")
@@ -95,9 +129,20 @@ class Step:
         self.cabi.forward(self.plan, self.img, overwrite=True)      # what rendering_cuda_dmax enqueues
 
     def do_backward(self):
+        if self.halo:
+            self.cabi.backward_packed(self.plan, self.ex.records, self.grad_img, self.ex.g_records, overwrite=True)
+            return
         self.cabi.backward(self.plan, self.sig, self.xy, self.col, self.grad_img, *self.g, overwrite=True)
 
     def __call__(self):
+        if self.halo:
+            self.ex.exchange_forward()          # Gaussians crossing a band edge -> neighbours (P2P)
+            self.do_plan()
+            self.do_forward()
+            if not self.fwd_only:
+                self.do_backward()
+                self.ex.exchange_backward()     # their partial gradients come back and are merged
+            return
         if self.dist:
             import torch.distributed as dist
             dist.broadcast(self.packed, src=0)                       # Gaussians from the decoder rank ...
@@ -119,10 +164,10 @@ class Step:
     # step stores into a fresh image (GSASR_FLAG_OVERWRITE_IMAGE), so the image is written once and never read:
     # fwd = 32 N + 12 H W.  bwd = 64 N + 12 H W.  (per rank: own rows)
     def bytes_fwd(self):
-        return 32 * self.n + 12 * (self.rows[1] - self.rows[0]) * self.W
+        return 32 * self.n_rank + 12 * (self.rows[1] - self.rows[0]) * self.W
 
     def bytes_bwd(self):
-        return 64 * self.n + 12 * (self.rows[1] - self.rows[0]) * self.W
+        return 64 * self.n_rank + 12 * (self.rows[1] - self.rows[0]) * self.W
 
 
 def time_stage(fn, iters, dev):
@@ -247,6 +292,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if step.ex is not None:
+        step.ex.check()      # the timed steps dropped nothing (capacity) -- raises otherwise
+
     ms = dt / args.steps * 1e3
     mpix = step.H * step.W / (dt / args.steps) / 1e6        # whole-job HR pixels per second (all ranks)
 
@@ -288,6 +336,10 @@ def main():
                        "launch": launch, "parallelism": f"row-band x{world}" if world > 1 else "single"},
             "roofline": roofline, "kernels": kern,
         }
+        if step.dist:
+            out["config"]["exchange"] = ("halo swap with ranks g-1/g+1 (send/recv), "
+                                         f"{step.halo_records} records max per edge, capacity {step.ex.cap}"
+                                         if step.halo else "broadcast + reduce_scatter")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
