@@ -332,7 +332,7 @@ def main():
             "config": {"workload": desc + (f"; weak-scaled to {step.H}x{step.W} HR / {step.n} Gaussians over {world} row bands"
                                            if world > 1 and not step.strong else ""),
                        "H": step.H, "W": step.W, "gaussians": step.n, "dmax": args.dmax,
-                       "cutoff_tau": step.cabi.get_default_cutoff() if args.cutoff == 0 else args.cutoff,
+                       "cutoff_tau": round(step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 3),
                        "launch": launch, "parallelism": f"row-band x{world}" if world > 1 else "single"},
             "roofline": roofline, "kernels": kern,
         }

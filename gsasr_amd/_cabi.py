@@ -22,7 +22,7 @@ EXPORTS = (
     "gsasr_gs_render_dmax", "gsasr_gs_render_backward_dmax", "gsasr_set_default_cutoff",
     "gsasr_get_default_cutoff", "gsasr_prologue_forward", "gsasr_prologue_backward",
     "gsasr_step_workspace_bytes", "gsasr_step_forward", "gsasr_step_backward",
-    "gsasr_band_select", "gsasr_band_merge",
+    "gsasr_band_select", "gsasr_band_merge", "gsasr_resolve_cutoff",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -89,6 +89,8 @@ def lib():
         L.gsasr_set_default_cutoff.restype = None
         L.gsasr_set_default_cutoff.argtypes = [f]
         L.gsasr_get_default_cutoff.restype = f
+        L.gsasr_resolve_cutoff.restype = f
+        L.gsasr_resolve_cutoff.argtypes = [f, i]
         if L.gsasr_abi_version() != 1:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
@@ -329,9 +331,14 @@ def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad
 
 
 def set_default_cutoff(tau: float) -> None:
-    """tau > 0: skip exponent < -tau; tau < 0: never skip; 0 restores the library default (32)."""
+    """tau > 0: skip exponent < -tau; tau < 0: never skip; 0 restores the adaptive default ln(N/1e-5)."""
     lib().gsasr_set_default_cutoff(float(tau))
 
 
 def get_default_cutoff() -> float:
     return float(lib().gsasr_get_default_cutoff())
+
+
+def resolve_cutoff(cutoff: float, s: int) -> float:
+    """tau a plan with `cutoff` (0 = process default) over `s` Gaussians uses."""
+    return float(lib().gsasr_resolve_cutoff(float(cutoff), int(s)))

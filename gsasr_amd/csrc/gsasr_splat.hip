@@ -152,16 +152,24 @@ PlanView make_view(const Layout &L, void *ws)
     return V;
 }
 
-float g_default_cutoff = -12345.f;  // resolved lazily (env GSASR_SPLAT_CUTOFF or the header default)
+float g_default_cutoff = -12345.f;  // process default: 0 = adaptive; resolved lazily from env GSASR_SPLAT_CUTOFF
 
 float default_cutoff()
 {
     if (g_default_cutoff == -12345.f) {
         const char *e = getenv("GSASR_SPLAT_CUTOFF");
-        g_default_cutoff = e ? (float)atof(e) : GSASR_SPLAT_DEFAULT_CUTOFF;
-        if (g_default_cutoff == 0.f) g_default_cutoff = GSASR_SPLAT_DEFAULT_CUTOFF;
+        g_default_cutoff = e ? (float)atof(e) : 0.f;
     }
     return g_default_cutoff;
+}
+
+// tau used for `s` Gaussians: explicit, process-fixed, or adaptive ln(s/eps) in [16, 104] (see the header)
+float resolve_cutoff(float cutoff, int s)
+{
+    if (cutoff == 0.f) cutoff = default_cutoff();
+    if (cutoff != 0.f) return cutoff;
+    const double tau = std::log((double)(s > 1 ? s : 1) / (double)GSASR_SPLAT_DEFAULT_EPS);
+    return (float)(tau < 16.0 ? 16.0 : tau > (double)GSASR_SPLAT_EXACT_CUTOFF ? (double)GSASR_SPLAT_EXACT_CUTOFF : tau);
 }
 
 Params make_params(const gsasr_dims *d, const Layout &L)
@@ -170,7 +178,7 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.s = d->s; P.h = d->h; P.w = d->w; P.row0 = d->row0; P.row1 = d->row1;
     P.bounded = d->dmax >= 0.f;
     P.dmax = P.bounded ? d->dmax : INFINITY;
-    float tau = d->cutoff == 0.f ? default_cutoff() : d->cutoff;
+    const float tau = resolve_cutoff(d->cutoff, d->s);
     P.kcut = tau > 0.f ? (float)(std::sqrt(2.0 * (double)tau) * (1.0 + 1e-6)) : 0.f;
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
     P.flags = d->flags;
@@ -1253,9 +1261,11 @@ int gsasr_abi_version(void) { return GSASR_SPLAT_ABI_VERSION; }
 
 const char *gsasr_last_error(void) { return tl_err; }
 
-void gsasr_set_default_cutoff(float tau) { g_default_cutoff = tau == 0.f ? GSASR_SPLAT_DEFAULT_CUTOFF : tau; }
+void gsasr_set_default_cutoff(float tau) { g_default_cutoff = tau; }
 
 float gsasr_get_default_cutoff(void) { return default_cutoff(); }
+
+float gsasr_resolve_cutoff(float cutoff, int s) { return resolve_cutoff(cutoff, s); }
 
 size_t gsasr_splat_workspace_bytes(const gsasr_dims *dims)
 {

@@ -86,6 +86,11 @@ class HipBackend:
         _cabi.band_merge(g_own, g_up, g_down, up_index, down_index, counts)
 
     @staticmethod
+    def resolve_cutoff(cutoff, s):
+        from . import _cabi
+        return _cabi.resolve_cutoff(cutoff, s)
+
+    @staticmethod
     def forward(sigmas, coords, colors, h, w, dmax, rows):
         from . import _cabi
         plan = _cabi.plan(sigmas, coords, colors, h, w, dmax, rows=rows)
@@ -204,6 +209,11 @@ class BandExchange:
         self.world = dist.get_world_size(group) if world is None else int(world)
         self.h, self.w, self.dmax, self.cutoff = int(h), int(w), dmax, float(cutoff)
         self.n, self.cap = int(n_local), int(cap)
+        # one tau for `select` and the local plan: the default is adaptive in the number of Gaussians, which
+        # differs between the two calls (n_local vs n_local + 2 cap)
+        resolve = getattr(self.backend, "resolve_cutoff", None)
+        if resolve is not None:
+            self.cutoff = resolve(self.cutoff, self.n + 2 * self.cap)
         self.rows = row_band(self.h, self.rank, self.world)
         span = lambda r: row_band(self.h, r, self.world)[1] - row_band(self.h, r, self.world)[0]
         self.rows_above = span(self.rank - 1) if self.rank > 0 else 0

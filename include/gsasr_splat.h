@@ -65,17 +65,22 @@ typedef struct gsasr_dims {
     int row0, row1; /* HR rows [row0,row1) owned by this call; 0,h for a single GPU   */
     float cutoff; /* support cutoff tau: a Gaussian is skipped for an 8x8 pixel tile when its
                      exponent is < -tau everywhere on it (|d| > sigma*sqrt(2 tau)).
-                     0 -> library default (GSASR_SPLAT_DEFAULT_CUTOFF); < 0 -> never skip
+                     0 -> process default (adaptive, see below); < 0 -> never skip
                      (every in-box term is summed, as the reference does).                */
     unsigned flags;
 } gsasr_dims;
 
-/* Default tau = 32: every skipped term is < exp(-32) = 1.3e-14 times its colour (<= 1), so even
- * 10^6 skipped terms on one pixel add up to < 1.3e-8 -- four orders below the 1e-4 parity tolerance
- * and below one fp32 ulp of an O(1) pixel.  tau = 104 (GSASR_SPLAT_EXACT_CUTOFF) skips only terms for
- * which fp32 expf() in the reference returns exactly +0 (exp(-104) < 2^-150), i.e. it sums the same
- * set of non-zero terms as the reference; tau < 0 never skips. */
-#define GSASR_SPLAT_DEFAULT_CUTOFF 32.0f
+/* Default tau is ADAPTIVE: tau = ln(s / GSASR_SPLAT_DEFAULT_EPS), clamped to [16, 104].  Every skipped
+ * term is < exp(-tau) times its colour (<= 1 after the host prologue's sigmoid * alpha), and at most s terms
+ * can be skipped on one pixel, so the image error is < s * exp(-tau) = 1e-5 absolute per pixel for ANY input
+ * -- an order below the 1e-4 parity tolerance and at the level of fp32 summation noise; in practice the
+ * skipped mass is ~1e-9 because terms decay further outside the ellipse.  Gradients lose the same tail:
+ * relative error ~ tau * exp(-tau) < 1e-8.  (s = 65 536 -> tau = 22.6; s = 2^20 -> tau = 25.4.)
+ * A fixed tau can be set per call (dims.cutoff) or per process (gsasr_set_default_cutoff / environment
+ * GSASR_SPLAT_CUTOFF): tau = 104 (GSASR_SPLAT_EXACT_CUTOFF) skips only terms for which fp32 expf() in the
+ * reference returns exactly +0 (exp(-104) < 2^-150), i.e. it sums the same set of non-zero terms as the
+ * reference; tau < 0 never skips. */
+#define GSASR_SPLAT_DEFAULT_EPS 1e-5f
 #define GSASR_SPLAT_EXACT_CUTOFF 104.0f
 
 int gsasr_abi_version(void);
@@ -160,10 +165,12 @@ int gsasr_band_select(const float *packed, const gsasr_dims *dims, int rows_abov
 int gsasr_band_merge(float *g_packed, int s, const float *g_up, const float *g_down, const int *up_index,
                      const int *down_index, const int *counts, int cap, void *stream);
 
-/* Process-wide default used when dims.cutoff == 0 (initially GSASR_SPLAT_DEFAULT_CUTOFF, or the
- * value of the environment variable GSASR_SPLAT_CUTOFF if set). */
+/* Process-wide default used when dims.cutoff == 0: 0 = adaptive (initial state), otherwise a fixed tau
+ * (initially the value of the environment variable GSASR_SPLAT_CUTOFF if set).  gsasr_resolve_cutoff
+ * returns the tau a plan with dims.cutoff = `cutoff` over `s` Gaussians uses. */
 void gsasr_set_default_cutoff(float tau);
 float gsasr_get_default_cutoff(void);
+float gsasr_resolve_cutoff(float cutoff, int s);
 
 #ifdef __cplusplus
 }

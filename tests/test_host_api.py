@@ -84,7 +84,12 @@ def test_workspace_bytes_and_bad_dims_no_gpu():
     assert _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(bad)) == 0
     bad = _cabi.make_dims(10, 8, 8, 0.1, rows=(4, 2))
     assert _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(bad)) == 0
-    assert abs(_cabi.get_default_cutoff() - 32.0) < 1e-6
+    # default support cutoff is adaptive: tau = ln(N / 1e-5) clamped to [16, 104]; explicit values pass through
+    import math
+    assert _cabi.get_default_cutoff() == 0.0
+    assert abs(_cabi.resolve_cutoff(0.0, 65536) - math.log(65536 / 1e-5)) < 1e-4
+    assert _cabi.resolve_cutoff(0.0, 1) == 16.0 and _cabi.resolve_cutoff(0.0, 2 ** 31 - 1) < 104.0
+    assert _cabi.resolve_cutoff(32.0, 10) == 32.0 and _cabi.resolve_cutoff(-1.0, 10) == -1.0
 
 
 def test_tensor_checks_raise_runtimeerror_like_reference():
