@@ -185,6 +185,38 @@ def time_stage(fn, iters, dev):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
+def window_pairs(sig, xy, H, W, dmax, tau, rows):
+    """(Gaussian, pixel) pairs: inside the reference's dmax box (what gs_cuda_dmax sums) and
+    inside the window the kernels sweep (box ∩ marginal support |d| <= sigma*sqrt(2 tau)); exact integer
+    counts from the same double-precision window arithmetic as the plan (gaussian_box in gsasr_splat.hip)."""
+    s64, x64 = sig.double().cpu(), xy.double().cpu()
+    hx, hy = 0.5 * (W - 1), 0.5 * (H - 1)
+    cx, cy = (x64[:, 0] + 1.0) * hx, (x64[:, 1] + 1.0) * hy
+    out = []
+    for cut in (False, True):
+        ex = torch.full_like(cx, float("inf") if dmax is None else dmax)
+        ey = ex.clone()
+        if cut and tau > 0:
+            k = (2.0 * tau) ** 0.5
+            ex, ey = torch.minimum(ex, k * s64[:, 0]), torch.minimum(ey, k * s64[:, 1])
+        c0 = torch.ceil(cx - ex * hx).clamp(min=0)
+        c1 = torch.floor(cx + ex * hx).clamp(max=W - 1)
+        r0 = torch.ceil(cy - ey * hy).clamp(min=rows[0])
+        r1 = torch.floor(cy + ey * hy).clamp(max=rows[1] - 1)
+        ok = torch.isfinite(cx) & torch.isfinite(cy)
+        out.append(int(((c1 - c0 + 1).clamp(min=0) * (r1 - r0 + 1).clamp(min=0))[ok].sum().item()))
+    return out
+
+
+def copy_bandwidth(dev):
+    """measured HBM stream rate on this box: device-to-device copy of 1 GiB (read + write = 2 GiB of traffic)"""
+    n = 1 << 28
+    a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    a.fill_(1.0)
+    avg, _ = time_stage(lambda: b.copy_(a), 5, dev)
+    return 2.0 * 4.0 * n / (avg * 1e-3) / 1e9
+
+
 def cpu_baseline(args):
     """The oracle's fp32 restatement of the reference kernels (OpenMP over the host cores) on a bounded
     sample of the SAME workload: a row band of config 2 (sized for ~10 s on this host) with all 65 536 Gaussians, forward + backward."""
@@ -320,6 +352,29 @@ def main():
                 "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                 "note": "backward stage = k_render_bwd + k_bwd_finalize; outputs are stored, not accumulated (no memsets)"}
+    # The binding unit is the fp32 VALU / v_exp_f32 pipe, not HBM: report pair rates and the VALU
+    # occupancy next to the HBM fraction.
+    if rank == 0:
+        try:
+            roofline["hbm_copy_GBps_measured"] = round(copy_bandwidth(dev), 1)
+        except Exception as e:
+            roofline["hbm_copy_GBps_measured"] = None
+            print(f"[bench] copy bandwidth probe failed: {e!r}", file=sys.stderr)
+        if not step.halo:
+            tau = step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s)
+            in_box, swept = window_pairs(step.sig, step.xy, step.H, step.W, step.dmax, tau, step.rows)
+            valu = {"pairs_in_dmax_box": in_box, "pairs_in_swept_window": swept,
+                    "Gpairs_per_s": {k: round(swept / (kern[k]["avg_ms"] * 1e-3) / 1e9, 1) for k in kern if k != "plan"},
+                    "note": "pairs = (Gaussian, pixel) terms; box = what gs_cuda_dmax sums, swept window = box ∩ support cutoff"}
+            if os.path.exists(pmc) and args.config == "c2" and world == 1:
+                try:
+                    j = json.load(open(pmc))
+                    valu["valu_busy_rocprof"] = {"forward": j["k_render_fwd"].get("valu_busy"),
+                                                 "backward": j["k_render_bwd"].get("valu_busy"),
+                                                 "source": "profiles/pmc_latest.json (SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES)"}
+                except Exception:
+                    pass
+            roofline["valu"] = valu
 
     if rank == 0:
         h_lr, w_lr, scale, desc = CONFIGS[args.config]

@@ -966,9 +966,16 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     }
 }
 
+// lane i reads lane i+N of its row of 16 (0 past the row end)
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+
 // Sum eight per-lane values over the wave through LDS: lanes park their 8 partials ([8][64] floats per wave),
 // lane l then adds the 8 consecutive partials {l&7} of value {l>>3} (two ds_read_b128) and three butterfly
-// steps finish inside each 8-lane group.  Afterwards lane 8k holds the total of value k.  ~14 VALU
+// steps (DPP) finish inside each 8-lane group.  Afterwards lane 8k holds the total of value k.  ~14 VALU
 // instructions instead of ~45 for a register-only exchange network; the LDS pipe is otherwise idle here.
 __device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane, float *red)
 {
@@ -979,17 +986,61 @@ __device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane, float 
     const float4 u = *reinterpret_cast<const float4 *>(red + lane * 8);
     const float4 v = *reinterpret_cast<const float4 *>(red + lane * 8 + 4);
     float d = ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
-    d += __shfl_xor(d, 4);
-    d += __shfl_xor(d, 2);
-    d += __shfl_xor(d, 1);
-    return d;
+    // lane 8k += lanes 8k+4, then +2, then +1, as DPP row shifts folded into the adds (a __shfl_xor is a
+    // ds_bpermute round trip plus five address instructions each)
+    d += dpp_row_shl<4>(d);
+    d += dpp_row_shl<2>(d);
+    d += dpp_row_shl<1>(d);
+    return d;   // valid in lanes 8k only
+}
+
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u8v __attribute__((ext_vector_type(8)));
+
+// Everything the sweep needs about Gaussian j, fetched by the SCALAR unit in one batch (one round trip).
+// Left to the compiler these are vector loads + v_readfirstlane (the kernel also stores to the workspace, so
+// it will not use the non-coherent scalar cache) issued as three dependent round trips, which was most of a
+// wave's life.  The plan was written by an earlier kernel, so the scalar cache is coherent for it.
+struct BwdRec {
+    u4v bb;    // bbox word 0
+    u8v rec;   // {x, y, A, B | r, g, b, C}
+    u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, -, -, index}
+};
+
+__device__ __forceinline__ void bwd_fetch(const PlanView &V, unsigned j, BwdRec &R)
+{
+    const uint4 *pb = V.bbox + 2 * (size_t)j;
+    const float4 *pr = V.rec + 2 * (size_t)j, *pf = V.fin + 2 * (size_t)j;
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\t"
+                 "s_load_dwordx8 %1, %4, 0x0\n\t"
+                 "s_load_dwordx8 %2, %5, 0x0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(R.bb), "=&s"(R.rec), "=&s"(R.fin)
+                 : "s"(pb), "s"(pr), "s"(pf)
+                 : "memory");
+}
+
+// the same plus the two class boundaries cell_start[ncells], cell_start[ncells+1]
+__device__ __forceinline__ void bwd_fetch_first(const PlanView &V, const unsigned *bounds, unsigned j, BwdRec &R, u2v &lim)
+{
+    const uint4 *pb = V.bbox + 2 * (size_t)j;
+    const float4 *pr = V.rec + 2 * (size_t)j, *pf = V.fin + 2 * (size_t)j;
+    asm volatile("s_load_dwordx2 %3, %7, 0x0\n\t"
+                 "s_load_dwordx4 %0, %4, 0x0\n\t"
+                 "s_load_dwordx8 %1, %5, 0x0\n\t"
+                 "s_load_dwordx8 %2, %6, 0x0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(R.bb), "=&s"(R.rec), "=&s"(R.fin), "=&s"(lim)
+                 : "s"(pb), "s"(pr), "s"(pf), "s"(bounds)
+                 : "memory");
 }
 
 template <bool BOUNDED>
-__device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int lane, const Params &P,
+__device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk, bool atomic, int lane, const Params &P,
                                          const PlanView &V, const float *__restrict__ grad, float *spy, float *red)
 {
-    const uint4 bb = V.bbox[2 * (size_t)j];  // wave-uniform: scalar loads
+    const u4v bb = G.bb;
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
     int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
     if (c0 > c1) return;  // dead class (not finalized)
@@ -999,9 +1050,11 @@ __device__ __forceinline__ void bwd_item(unsigned j, int chunk, bool atomic, int
         r1 = min(r1, r0 + rpc - 1);
         if (r0 > r1) return;
     }
-    const float4 ra = V.rec[2 * (size_t)j], rb = V.rec[2 * (size_t)j + 1];
-    const float x = ra.x, y = ra.y, cr = rb.x, cg = rb.y, cb = rb.z;
-    const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];  // {c, kappa, rho, 1/sx}, {1/sy, ..}
+    const float x = __uint_as_float(G.rec[0]), y = __uint_as_float(G.rec[1]);
+    const float cr = __uint_as_float(G.rec[4]), cg = __uint_as_float(G.rec[5]), cb = __uint_as_float(G.rec[6]);
+    const float4 fa = make_float4(__uint_as_float(G.fin[0]), __uint_as_float(G.fin[1]), __uint_as_float(G.fin[2]),
+                                  __uint_as_float(G.fin[3]));   // {c, kappa, rho, 1/sx}
+    const float4 fb = make_float4(__uint_as_float(G.fin[4]), 0.f, 0.f, 0.f);   // {1/sy, ..}
     float a[8];
     const int bw = c1 - c0 + 1;
     if (chunk < 0) {  // (row chunks of a large Gaussian must not overlap: they keep their ragged tail)
@@ -1092,20 +1145,24 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     __shared__ float s_py[4][128];  // per wave: v = dy/sy of a 64-row block, then (TEST) the raw dy
     __shared__ __attribute__((aligned(16))) float s_red[4][512];
     float *spy = s_py[wv], *red = s_red[wv];
-    const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
     // one Gaussian per wave, dispatched by the hardware (a persistent-workgroup variant with a static
     // partition was measured 13% slower at config 2 and 60% slower at config 3: load imbalance)
     // (two or four Gaussians per wave, one after the other, measured the same: wave launch is not the cost)
+    BwdRec G;
+    u2v lim;
+    bwd_fetch_first(V, V.cell_start + P.ncells, min(gw, (unsigned)P.s - 1u), G, lim);  // speculative: class checked below
+    const unsigned large_beg = lim.x, large_end = lim.y;
     if (gw < large_beg)
-        bwd_item<BOUNDED>(gw, -1, false, lane, P, V, grad, spy, red);
+        bwd_item<BOUNDED>(gw, G, -1, false, lane, P, V, grad, spy, red);
     else if (gw < large_end)
-        bwd_item<BOUNDED>(gw, 0, true, lane, P, V, grad, spy, red);
+        bwd_item<BOUNDED>(gw, G, 0, true, lane, P, V, grad, spy, red);
     // remaining row chunks of the large class, spread over all waves
     const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
     for (unsigned it = gw; it < extra; it += nwaves) {
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
-        bwd_item<BOUNDED>(j, chunk, true, lane, P, V, grad, spy, red);
+        bwd_fetch(V, j, G);
+        bwd_item<BOUNDED>(j, G, chunk, true, lane, P, V, grad, spy, red);
     }
 }
 

@@ -20,6 +20,16 @@ def grab(fn, kern, ctr):
     raise SystemExit(f"{ctr} for {kern} not found in {fn}")
 
 
+def grab_any(fn, kern, ctr):
+    lines = open(fn).read().split("\n")
+    for i, l in enumerate(lines):
+        if kern in l:
+            for m in lines[i + 1:i + 12]:
+                if m.split() and m.split()[0] == ctr:
+                    return float(m.split()[1])
+    raise SystemExit(f"{ctr} for {kern} not found in {fn}")
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -28,6 +38,17 @@ def main():
         f = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch.txt"), name, "FETCH_SIZE")
         w = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_write.txt"), name, "WRITE_SIZE")
         d[k].update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes=int((2 * f + w) * 1024))
+        sq = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.txt")
+        if os.path.exists(sq):
+            # counters are averages per shader-engine instance (32 SEs x 32 SIMDs); ACTIVE_INST_VALU counts
+            # quad-cycles, so VALU-busy = 4 * ACTIVE / (32 SIMDs * BUSY_CYCLES)
+            act = grab_any(sq, name, "SQ_ACTIVE_INST_VALU")
+            busy = grab_any(sq, name, "SQ_BUSY_CYCLES")
+            insts = grab_any(sq, name, "SQ_INSTS_VALU")
+            d[k].update(valu_busy=round(4.0 * act / (32.0 * busy), 4), valu_insts=int(insts * 32))
+    d["_valu_method"] = ("valu_busy = 4 * SQ_ACTIVE_INST_VALU / (32 * SQ_BUSY_CYCLES), both per shader-engine averages from "
+                         "profiles/r01_pmc_sq.txt (quad-cycle units; 32 SIMDs per SE); valu_insts = wave-level VALU "
+                         "instructions per launch (SQ_INSTS_VALU x 32 SE instances)")
     json.dump(d, open(p, "w"), indent=1)
     print(json.dumps(d, indent=1))
 
