@@ -24,12 +24,13 @@
 //                        LDS reads; no atomics, one coalesced store / read-modify-write of the tile.
 //            k_render_fwd_split   same per-wave code for small images: one sub-tile per workgroup, its
 //                        chunks dealt to 2..16 waves, partial sums combined through LDS.
-//   backward k_render_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian, lanes laid 16/32/64 wide over its
-//                        window, two rows per trip (packed fp32), grad_img through L1/L2, three row
-//                        moments + three colour sums per lane, one LDS wave reduction, raw sums stored.
-//                        Gaussians of the "large" class are split into row chunks spread over all waves
-//                        and combined with fp32 atomics.
-//            k_bwd_finalize  Gaussian-constant factors applied once per Gaussian (one thread each).
+//   backward k_render_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian (its records fetched by the scalar
+//                        unit in one batch), lanes laid 16/32/64 wide over its window, two rows per trip
+//                        (packed fp32), grad_img through L1/L2, three residual moments + three colour
+//                        sums per lane, one LDS + DPP wave reduction, and the gradient written by the same
+//                        wave (no finalize pass).  Gaussians of the "large" class are split into row chunks
+//                        spread over all waves, combined with fp32 atomics; the wave finishing the last
+//                        chunk writes the gradient.
 //   prologue k_prologue_fwd/bwd  the reference's host prologue (activations + kernel frame) and its
 //                        chain rule as one kernel each.
 //
@@ -80,7 +81,8 @@ struct PlanView {
     unsigned *scan_tot;     // [ceil((ncells+2)/4096)] per-chunk totals of the two-pass scan
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
     float4 *fin;            // [2*s] backward constants {1/(1-rho^2), 1-rho^2, rho, 1/sx}, {1/sy, -, -, original index}
-    float *sums;            // [8*s] raw backward sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} per (cell-ordered) Gaussian
+    float *sums;            // [8*s] raw backward sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb}: atomic accumulators of the large class
+    unsigned *done;         // [s] row chunks of a large Gaussian finished so far (backward)
     uint4 *bbox;            // [2*s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[0..3], span_hi[0..3]},
                             //       {span_lo[4..7], span_hi[4..7], -, -}
 };
@@ -88,7 +90,7 @@ struct PlanView {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_bbox;
+    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox;
     size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
     size_t total;
     int ncx, ncy, ncells;
@@ -127,6 +129,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_rec = o;    o += align_up(s * 32, 256);
     L.off_fin = o;    o += align_up(s * 32, 256);
     L.off_sums = o;   o += align_up(s * 32, 256);
+    L.off_done = o;   o += align_up(s * 4, 256);
     L.off_bbox = o;   o += align_up(s * 32, 256);
     L.total = o;
     return L;
@@ -148,6 +151,7 @@ PlanView make_view(const Layout &L, void *ws)
     V.rec = (float4 *)(b + L.off_rec);
     V.fin = (float4 *)(b + L.off_fin);
     V.sums = (float *)(b + L.off_sums);
+    V.done = (unsigned *)(b + L.off_done);
     V.bbox = (uint4 *)(b + L.off_bbox);
     return V;
 }
@@ -571,6 +575,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     if (b.cls == 1) {  // large Gaussians accumulate their row chunks atomically: start from zero
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        V.done[j] = 0u;
     }
 }
 
@@ -827,14 +832,14 @@ __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V,
 // ---------------------------------------------------------------------------------------------------
 // Sweep the pixel window [c0,c0+bw) x [r0,r1] of one Gaussian with a wave.  Lanes are laid LX = 16/32/64
 // wide (the narrowest that covers bw, a template parameter so all the lane geometry is constant) and
-// 64/LX rows deep; a lane keeps ONE column (dx is a lane constant) and handles TWO rows per trip, so
-// the per-pixel arithmetic is 2-wide packed fp32.  Because dx is constant per lane only three
-// row-moments are accumulated per pixel,
-//     M0 = sum q,  M1 = sum q*dy,  M2 = sum q*dy^2,      q = v * <grad, colour>,
-// and expanded at the end of the column: Sx = dx*M0, Sxx = dx^2*M0, Sy = M1, Sxy = dx*M1, Syy = M2.
-// The py values of a 64-row block are staged in LDS (256 B per wave); full trips carry no masks or
+// 64/LX rows deep; a lane keeps ONE column (u = dx/sx is a lane constant) and handles TWO rows per trip, so
+// the per-pixel arithmetic is 2-wide packed fp32.  Because u is constant per lane only three sums over
+// rows are accumulated per pixel column,
+//     M0 = sum q,  N1 = sum q*B,  N2 = sum q*B^2,      q = v * <grad, colour>,  B = dy/sy - rho u,
+// and expanded at the end of the column (see below).
+// The dy/sy values of a 64-row block are staged in LDS (256 B per wave); full trips carry no masks or
 // address clamps, the ragged last trip is peeled.
-// acc[] = {Sx, Sy, Sxx, Sxy, Syy, Cr, Cg, Cb} (per lane, summed over the wave by the caller).
+// acc[] = {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} (per lane, summed over the wave by the caller).
 struct BwdRow {
     v2f m0, m1, m2, k01, k20, k12;  // moments; colour sums in the mixed pairing of two HWC pixels
 };
@@ -896,6 +901,9 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     const int col = lane & (LX - 1), rsub = lane >> LXLOG;
     const size_t rowpitch = (size_t)P.w * 3;
     const float nK1 = -HALF_LOG2E * cinv;
+    // issued together with the px load below: one round trip for both tables instead of two dependent ones
+    // (also issuing the first trips' gradient loads here was measured: no gain, +8 VGPRs)
+    const float py_first = pyt[min(r0 + lane, r1)];
     for (int strip = 0; strip < bw; strip += 64) {
         const int cc = strip + col;
         const int X = c0 + min(cc, bw - 1);
@@ -913,7 +921,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             const int rend = min(r1, rb + 63);
             __builtin_amdgcn_wave_barrier();
             {   // per-row values of the block in LDS: v = dy/sy, and (TEST only) the raw dy for the exact box test
-                const float dyr = pyt[min(rb + lane, r1)] - y;
+                const float dyr = (rb == r0 ? py_first : pyt[min(rb + lane, r1)]) - y;
                 spy[lane] = dyr * isy;
                 if (TEST) spy[64 + lane] = dyr;
             }
@@ -994,6 +1002,32 @@ __device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane, float 
     return d;   // valid in lanes 8k only
 }
 
+// Epilogue of one Gaussian (gs.cu:139-146).  With u = dx/sx, v = dy/sy, A = u - rho v, B = v - rho u each gradient
+// component is ONE of the eight sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} times a Gaussian constant:
+//   d/dx = c/sx qA,  d/dy = c/sy qB,  d/dsx = c/sx quA,  d/dsy = c/sy qvB,  d/drho = c^2 qAB,  c = 1/(1-rho^2),
+// and the colour gradients are the sums themselves.  The constants are applied to the per-lane partials
+// (bwd_scale, five full-wave multiplies by a scalar) so that after the wave reduction lane 8k simply holds
+// output k of {x, y | sx, sy, rho | r, g, b}: three exec-masked stores off scalar bases, no per-lane selects.
+__device__ __forceinline__ void bwd_scale(float (&a)[8], float c, float isx, float isy)
+{
+    const float fx = c * isx, fy = c * isy;
+    a[0] *= fx; a[1] *= fy; a[2] *= fx; a[3] *= fy; a[4] *= c * c;
+}
+
+__device__ __forceinline__ void bwd_write(float v, int lane, const Params &P, unsigned i, float *__restrict__ g_sigmas,
+                                          float *__restrict__ g_coords, float *__restrict__ g_colors)
+{
+    if (lane & 7) return;
+    const int k = lane >> 3;
+    float *pc = g_coords + (size_t)i * stride2(P), *ps = g_sigmas + (size_t)i * stride3(P) - 2,
+          *pk = g_colors + (size_t)i * stride3(P) - 5;   // wave-uniform, pre-biased so that every array is indexed by k
+    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) {
+        if (k < 2) pc[k] = v; else if (k < 5) ps[k] = v; else pk[k] = v;
+    } else {  // fire-and-forget atomics: the wave must not end on a load-add-store round trip
+        if (k < 2) atomicAdd(pc + k, v); else if (k < 5) atomicAdd(ps + k, v); else atomicAdd(pk + k, v);
+    }
+}
+
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u8v __attribute__((ext_vector_type(8)));
@@ -1038,17 +1072,20 @@ __device__ __forceinline__ void bwd_fetch_first(const PlanView &V, const unsigne
 
 template <bool BOUNDED>
 __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk, bool atomic, int lane, const Params &P,
-                                         const PlanView &V, const float *__restrict__ grad, float *spy, float *red)
+                                         const PlanView &V, const float *__restrict__ grad, float *spy, float *red,
+                                         float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                         float *__restrict__ g_colors)
 {
     const u4v bb = G.bb;
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
     int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
-    if (c0 > c1) return;  // dead class (not finalized)
+    if (c0 > c1) return;  // dead class (handled by the caller)
+    bool empty = false;
     if (chunk >= 0) {
         const int rpc = (r1 - r0 + NCH) / NCH;
         r0 = r0 + chunk * rpc;
         r1 = min(r1, r0 + rpc - 1);
-        if (r0 > r1) return;
+        empty = r0 > r1;   // still counted as a finished chunk below
     }
     const float x = __uint_as_float(G.rec[0]), y = __uint_as_float(G.rec[1]);
     const float cr = __uint_as_float(G.rec[4]), cg = __uint_as_float(G.rec[5]), cb = __uint_as_float(G.rec[6]);
@@ -1067,71 +1104,38 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
         else if (r0 - pad >= P.row0) r0 -= pad;
     }
     const bool test = BOUNDED && (bb.x & 0x8000u);
+    float d = 0.f;
+    if (!empty) {
 #define GSASR_SWEEP(T, L) \
     bwd_sweep<T, L>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
-    if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
-    else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
-    else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
+        if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
+        else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
+        else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
 #undef GSASR_SWEEP
-    // lane 8k now holds raw sum k: one 32-byte store per Gaussian; the Gaussian-constant factors are applied
-    // by k_bwd_finalize, vectorised over Gaussians (64 per wave instead of one)
-    const float d = wave_sum8(a, lane, red);
-    if ((lane & 7) == 0) {
-        float *o = V.sums + 8 * (size_t)j + (lane >> 3);
-        if (atomic) atomicAdd(o, d); else *o = d;
+        bwd_scale(a, fa.x, fa.w, fb.x);
+        d = wave_sum8(a, lane, red);   // lane 8k now holds gradient component k
     }
-}
-
-// The per-pixel partials of gs.cu:139-146 are linear in {q dx, q dy, q dx^2, q dx dy, q dy^2}: the
-// Gaussian-constant factors are applied once to the five moment sums, one thread per Gaussian.
-__global__ __launch_bounds__(256) void k_bwd_finalize(Params P, PlanView V, float *__restrict__ g_sigmas,
-                                                      float *__restrict__ g_coords, float *__restrict__ g_colors)
-{
-    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (unsigned)P.s) return;
-    const bool store = P.flags & GSASR_FLAG_OVERWRITE_GRADS;
-    const bool dead = j >= V.cell_start[P.ncells + 1];  // dead class: never swept, sums undefined
-    if (dead && !store) return;
-    if (dead) {  // zero gradient (the epilogue constants of a non-finite Gaussian are not usable)
-        const unsigned i = __float_as_uint(V.fin[2 * (size_t)j + 1].w);
-        float *os = g_sigmas + (size_t)i * stride3(P), *op = g_coords + (size_t)i * stride2(P), *oc = g_colors + (size_t)i * stride3(P);
-        os[0] = os[1] = os[2] = op[0] = op[1] = oc[0] = oc[1] = oc[2] = 0.f;
-        return;
+    if (atomic) {
+        // Large class: the row chunks add into sums[] and count themselves; the wave that finishes the
+        // last chunk takes the totals (re-arming the accumulators for the next backward) and writes the
+        // gradient, so no separate finalize pass exists.
+        if (!empty && (lane & 7) == 0) atomicAdd(V.sums + 8 * (size_t)j + (lane >> 3), d);
+        __threadfence();
+        unsigned prev = 0;
+        if (lane == 0) prev = atomicAdd(&V.done[j], 1u);
+        prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+        if (prev != (unsigned)(NCH - 1)) return;
+        __threadfence();
+        if ((lane & 7) == 0) d = atomicExch(V.sums + 8 * (size_t)j + (lane >> 3), 0.f);
+        if (lane == 0) V.done[j] = 0u;
     }
-    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
-    {
-        sa = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j];
-        sb = reinterpret_cast<const float4 *>(V.sums)[2 * (size_t)j + 1];
-        if (j >= V.cell_start[P.ncells]) {  // large class: leave the atomic accumulators zeroed for the next backward
-            reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    const float SqA = sa.x, SqB = sa.y, SquA = sa.z, SqvB = sa.w, SqAB = sb.x, Cr = sb.y, Cg = sb.z, Cb = sb.w;
-    const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
-    const float c = fa.x, isx = fa.w, isy = fb.x;   // c = 1/(1-rho^2) = -2 w1
-    const unsigned i = __float_as_uint(fb.w);
-    // gs.cu:139-146 with u = dx/sx, v = dy/sy, A = u - rho v, B = v - rho u:
-    //   d/dx = c/sx * q A,  d/dy = c/sy * q B,  d/dsx = c/sx * q u A,  d/dsy = c/sy * q v B,  d/drho = c^2 * q A B
-    const float gx = c * isx * SqA;
-    const float gy = c * isy * SqB;
-    const float gsx = c * isx * SquA;
-    const float gsy = c * isy * SqvB;
-    const float grho = c * c * SqAB;
-    float *os = g_sigmas + (size_t)i * stride3(P), *op = g_coords + (size_t)i * stride2(P), *oc = g_colors + (size_t)i * stride3(P);
-    if (store) {
-        os[0] = gsx; os[1] = gsy; os[2] = grho;
-        op[0] = gx;  op[1] = gy;
-        oc[0] = Cr; oc[1] = Cg; oc[2] = Cb;
-    } else {
-        os[0] += gsx; os[1] += gsy; os[2] += grho;
-        op[0] += gx;  op[1] += gy;
-        oc[0] += Cr; oc[1] += Cg; oc[2] += Cb;
-    }
+    bwd_write(d, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
 }
 
 template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad)
+__global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
+                                                    float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                                    float *__restrict__ g_colors)
 {
     const int lane = threadIdx.x & 63;
     // XCD-aware order (block b runs on XCD b%8): each XCD sweeps a contiguous run of the cell-ordered
@@ -1153,16 +1157,18 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     bwd_fetch_first(V, V.cell_start + P.ncells, min(gw, (unsigned)P.s - 1u), G, lim);  // speculative: class checked below
     const unsigned large_beg = lim.x, large_end = lim.y;
     if (gw < large_beg)
-        bwd_item<BOUNDED>(gw, G, -1, false, lane, P, V, grad, spy, red);
+        bwd_item<BOUNDED>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     else if (gw < large_end)
-        bwd_item<BOUNDED>(gw, G, 0, true, lane, P, V, grad, spy, red);
+        bwd_item<BOUNDED>(gw, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+    else if (gw < (unsigned)P.s && (P.flags & GSASR_FLAG_OVERWRITE_GRADS))   // dead class: the gradient is zero
+        bwd_write(0.f, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
     // remaining row chunks of the large class, spread over all waves
     const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
     for (unsigned it = gw; it < extra; it += nwaves) {
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
         bwd_fetch(V, j, G);
-        bwd_item<BOUNDED>(j, G, chunk, true, lane, P, V, grad, spy, red);
+        bwd_item<BOUNDED>(j, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     }
 }
 
@@ -1424,11 +1430,9 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
     const dim3 grid((unsigned)((dims->s + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (P.bounded)
-        hipLaunchKernelGGL(k_render_bwd<true>, grid, block, 0, st, P, V, grad_img);
+        hipLaunchKernelGGL(k_render_bwd<true>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
     else
-        hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, grad_img);
-    hipLaunchKernelGGL(k_bwd_finalize, dim3((unsigned)((dims->s + 255) / 256)), block, 0, st, P, V, g_sigmas, g_coords,
-                       g_colors);
+        hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }

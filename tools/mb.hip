@@ -1,7 +1,7 @@
 // tools/mb.hip -- standalone micro-benchmark of libgsasr_splat's kernels (development aid, not product).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Iinclude [-DVARIANT...] tools/mb.hip -o /tmp/mb
-//   /tmp/mb [lr_h lr_w scale dmax tau iters gpp]
+//   /tmp/mb [lr_h lr_w scale dmax tau iters gpp flags]
 //
 // It #includes the library source so that -D switches can select kernel variants, generates
 // GSASR-shaped Gaussians (LR raster + jitter, sigmoid/tanh activations) with its own
@@ -70,7 +70,8 @@ int main(int argc, char **argv)
     }
     for (auto &g : grad) g = ud(rng);
 
-    gsasr_dims d{n, H, W, 3, dmax, 0, H, tau, 0u};
+    const unsigned flags = argc > 8 ? (unsigned)atoi(argv[8]) : 0u;   // 6 = overwrite image + grads
+    gsasr_dims d{n, H, W, 3, dmax, 0, H, tau, flags};
     const size_t wsb = gsasr_splat_workspace_bytes(&d);
     float *dsig, *dxy, *dcol, *dgrad, *dimg, *dgs, *dgc, *dgk;
     void *ws;
