@@ -14,7 +14,7 @@
 //            k_scan      exclusive scan of the cell histogram + max-extent reduction (one workgroup;
 //                        k_scan_local + k_scan_fix for grids above 8192 cells).
 //            k_bin       counting-sort placement (cell start + rank) fused with packing: 32-byte records
-//                        {x, y, A, B, r, g, b, C} (A,B,C = exponent coefficients with log2(e) folded,
+//                        {x, y, A, B, C, r, g, b} (A,B,C = exponent coefficients with log2(e) folded,
 //                        computed in double), backward-epilogue constants, 16-byte windows with the
 //                        per-tile-band column spans of the ellipse {exponent >= -tau}.
 //   forward  k_render_fwd  PIXEL-stationary: one wave64 = one 8x16 pixel sub-tile (2 px per lane, packed
@@ -509,9 +509,10 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     const float A = (float)(w1 * LOG2E * w2);
     const float B = (float)(-2.0 * dr * w1 * LOG2E * w3);
     const float C = (float)(w1 * LOG2E * w4);
-    // record layout {x, y, A, B | r, g, b, C}: the (r,g) pair is 8-byte aligned for packed-fp32 operands
+    // record layout {x, y, A, B | C, r, g, b}: after the two 16-byte LDS reads of the forward every value it
+    // broadcasts into a packed-fp32 operand (y, C, r, g, b) is the low or high half of an aligned register pair
     V.rec[2 * j + 0] = make_float4(x, y, A, B);
-    V.rec[2 * j + 1] = make_float4(colors[i3 + 0], colors[i3 + 1], colors[i3 + 2], C);
+    V.rec[2 * j + 1] = make_float4(C, colors[i3 + 0], colors[i3 + 1], colors[i3 + 2]);
     // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
     // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
     V.fin[2 * j + 0] = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
@@ -592,28 +593,41 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // Evaluate `n` records staged in LDS (32 B each, broadcast reads).  Unlike scalar-memory loads, LDS reads
 // return in order, so the compiler can keep several records in flight behind counted lgkmcnt waits.
 template <bool TEST>
+__device__ __forceinline__ void fwd_eval_one(const float4 a, const float4 b, float px, v2f py, float dmax, v2f &ar,
+                                             v2f &ag, v2f &ab)
+{
+    // a = {x, y, A, B}, b = {C, r, g, b}
+    const float dx = px - a.x;
+    const v2f dy = py - a.y;
+    const float adx = a.z * dx, bdx = a.w * dx;
+    const float adx2 = adx * dx;
+    const v2f t = b.x * dy + bdx;
+    const v2f pw = dy * t + adx2;
+    v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+    if (TEST) {
+        const bool inx = fabsf(dx) <= dmax;
+        v.x = (inx && fabsf(dy.x) <= dmax) ? v.x : 0.f;
+        v.y = (inx && fabsf(dy.y) <= dmax) ? v.y : 0.f;
+    }
+    ar += v * b.y;
+    ag += v * b.z;
+    ab += v * b.w;
+    // (The compiler folds four of the five broadcasts {y, C, r, g, b} into op_sel and copies the fifth with a
+    // v_mov, whatever the record order.  Issuing that v_pk_fma_f32 through inline asm removes the copy but
+    // measured no faster, and inline asm is outside the compiler's trans-use hazard handling after v_exp_f32.)
+}
+
+template <bool TEST>
 __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int beg, int end, float px, v2f py,
                                              float dmax, v2f &ar, v2f &ag, v2f &ab)
 {
-#pragma unroll 2
-    for (int i = beg; i < end; ++i) {
-        const float4 a = st[2 * i], b = st[2 * i + 1];
-        const float dx = px - a.x;
-        const v2f dy = py - a.y;
-        const float adx = a.z * dx, bdx = a.w * dx;
-        const float adx2 = adx * dx;
-        const v2f t = b.w * dy + bdx;
-        const v2f pw = dy * t + adx2;
-        v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
-        if (TEST) {
-            const bool inx = fabsf(dx) <= dmax;
-            v.x = (inx && fabsf(dy.x) <= dmax) ? v.x : 0.f;
-            v.y = (inx && fabsf(dy.y) <= dmax) ? v.y : 0.f;
-        }
-        ar += v * b.x;
-        ag += v * b.y;
-        ab += v * b.z;
+    int i = beg;
+    for (; i + 1 < end; i += 2) {   // two records per iteration so their dependent chains interleave
+        const float4 a0 = st[2 * i], b0 = st[2 * i + 1], a1 = st[2 * i + 2], b1 = st[2 * i + 3];
+        fwd_eval_one<TEST>(a0, b0, px, py, dmax, ar, ag, ab);
+        fwd_eval_one<TEST>(a1, b1, px, py, dmax, ar, ag, ab);
     }
+    if (i < end) fwd_eval_one<TEST>(st[2 * i], st[2 * i + 1], px, py, dmax, ar, ag, ab);
 }
 
 // Candidate index of this lane in flat chunk `c` of the concatenated segments.  The segment table lives in
@@ -1038,7 +1052,7 @@ typedef unsigned u8v __attribute__((ext_vector_type(8)));
 // wave's life.  The plan was written by an earlier kernel, so the scalar cache is coherent for it.
 struct BwdRec {
     u4v bb;    // bbox word 0
-    u8v rec;   // {x, y, A, B | r, g, b, C}
+    u8v rec;   // {x, y, A, B | C, r, g, b}
     u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, -, -, index}
 };
 
@@ -1088,7 +1102,7 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
         empty = r0 > r1;   // still counted as a finished chunk below
     }
     const float x = __uint_as_float(G.rec[0]), y = __uint_as_float(G.rec[1]);
-    const float cr = __uint_as_float(G.rec[4]), cg = __uint_as_float(G.rec[5]), cb = __uint_as_float(G.rec[6]);
+    const float cr = __uint_as_float(G.rec[5]), cg = __uint_as_float(G.rec[6]), cb = __uint_as_float(G.rec[7]);
     const float4 fa = make_float4(__uint_as_float(G.fin[0]), __uint_as_float(G.fin[1]), __uint_as_float(G.fin[2]),
                                   __uint_as_float(G.fin[3]));   // {c, kappa, rho, 1/sx}
     const float4 fb = make_float4(__uint_as_float(G.fin[4]), 0.f, 0.f, 0.f);   // {1/sy, ..}
