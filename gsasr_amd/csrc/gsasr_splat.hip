@@ -453,15 +453,112 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     __shared__ unsigned s_start[FUSED_SCAN ? FUSED_CELLS + 1 : 1];
     __shared__ unsigned s_part[FUSED_SCAN ? 256 : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Everything that does not depend on the Gaussian's slot j is done FIRST (its loads are issued together with
+    // the counter loads of the scan below): this kernel runs one wave per SIMD, so its run time is the length
+    // of its dependent chain, not its instruction count.
+    const bool valid = i < P.s;
+    unsigned c[FUSED_SCAN ? FUSED_PER_THREAD : 1];   // this thread's share of the per-cell counters (scan below)
+    if (FUSED_SCAN) {
+#pragma unroll
+        for (int k = 0; k < FUSED_PER_THREAD; ++k) {
+            const int q = (int)threadIdx.x * FUSED_PER_THREAD + k;
+            c[k] = q < P.ncells + 2 ? V.cell_count[q] : 0u;
+        }
+    }
+    unsigned key = 0u, rnk = 0u;
+    float4 recA = make_float4(0.f, 0.f, 0.f, 0.f), recB = recA, finA = recA, finB = recA;
+    uint4 bb = make_uint4(0u, 0u, 0u, 0u), bc = bb;
+    bool large = false;
+    if (valid) {
+        key = V.key[i];
+        rnk = V.rank[i];
+        const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
+        const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1], rho = sigmas[i3 + 2];
+        const float x = coords[i2 + 0], y = coords[i2 + 1];
+        const Box b = gaussian_box(sx, sy, x, y, P);
+        large = b.cls == 1;
+        // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56);
+        // everything per-Gaussian is evaluated ONCE here, in double, and rounded to float
+        const double dr = rho, dsx = sx, dsy = sy;
+        const double w1 = -0.5 / (1.0 - dr * dr);
+        const double w2 = 1.0 / (dsx * dsx), w3 = 1.0 / (dsx * dsy), w4 = 1.0 / (dsy * dsy);
+        const float A = (float)(w1 * LOG2E * w2);
+        const float B = (float)(-2.0 * dr * w1 * LOG2E * w3);
+        const float C = (float)(w1 * LOG2E * w4);
+        // record layout {x, y, A, B | C, r, g, b}: after the two 16-byte LDS reads of the forward every value it
+        // broadcasts into a packed-fp32 operand (y, C, r, g, b) is the low or high half of an aligned register pair
+        recA = make_float4(x, y, A, B);
+        recB = make_float4(C, colors[i3 + 0], colors[i3 + 1], colors[i3 + 2]);
+        // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
+        // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
+        finA = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
+        finB = make_float4((float)(1.0 / dsy), 0.f, 0.f, __uint_as_float((unsigned)i));
+        // does a pixel of a tile this Gaussian is binned to ever need the dmax test?  Not if its support box
+        // lies inside its dmax box: pixels beyond the support box carry < exp(-tau) whether tested or not.
+        const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
+        const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * sx * hx + 1.f <= P.dmax * hx &&
+                                               P.kcut * sy * hy + 1.f <= P.dmax * hy);
+        if (b.cls == 2) {
+            bb = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
+        } else {
+            bb.x = (unsigned)b.c0 | (needs_test ? 0x8000u : 0u) | ((unsigned)b.c1 << 16);
+            bb.y = (unsigned)b.r0 | ((unsigned)b.r1 << 16);
+            bb.z = bb.w = 0u;
+            // Row spans: for each 16-row band of forward tiles the window touches (at most 8 are encoded),
+            // the range of 8-px tile columns that the ellipse {exponent >= -tau} actually reaches.  The
+            // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
+            // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
+            const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
+            if (P.kcut > 0.f && ty1 - ty0 < 8 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
+                // (fp32 relative to the centre: the plan runs one wave per SIMD, so the length of this dependent
+                // chain is k_bin's run time; an ulp of a <= 128 px offset is far inside WINDOW_EPS.  Only the absolute
+                // pixel coordinates stay in double.)
+                const float spx = sx * hx, spy = sy * hy;                     // sigmas in pixels
+                const double cxp = ((double)x + 1.0) * (double)hx, cyp = ((double)y + 1.0) * (double)hy;
+                const float tau = 0.5f * P.kcut * P.kcut;
+                const float omr = (float)(1.0 - dr * dr);
+                const float iq = 1.f / (omr * spx * spy);
+                const float qa = 0.5f * iq * (spy / spx), qb = -rho * iq, qc = 0.5f * iq * (spx / spy);
+                const float umax = spx * P.kcut, vmax = spy * P.kcut;
+                const float vstar = rho * spy / spx * umax;                   // v of the ellipse's rightmost point
+                const float disc0 = 4.f * qa * tau, disc2 = 4.f * qa * qc - qb * qb, i2qa = 0.5f / qa;
+                const float eps = (float)WINDOW_EPS;
+                const int tx0 = b.c0 >> SUBX_SHIFT;
+                unsigned lo4[2] = {0u, 0u}, hi4[2] = {0u, 0u};
+                for (int t = 0; t < 8; ++t) {
+                    unsigned lo = 1u, hi = 0u;  // empty
+                    // the band's pixel rows Ya..Ya+15, relative to the centre
+                    const float v0 = (float)((double)(P.row0 + ((ty0 + t) << SUBY_SHIFT)) - cyp) - eps,
+                                v1 = v0 + (float)(SUBY - 1) + 2.f * eps;
+                    if (t <= ty1 - ty0 && v1 >= -vmax && v0 <= vmax) {
+                        const float a0 = fmaxf(v0, -vmax), a1 = fminf(v1, vmax);
+                        const float vr = fminf(fmaxf(vstar, a0), a1), vl = fminf(fmaxf(-vstar, a0), a1);
+                        const float dr_ = disc0 - disc2 * vr * vr;
+                        const float dl_ = disc0 - disc2 * vl * vl;
+                        const float uhi = (-qb * vr + sqrtf(fmaxf(dr_, 0.f))) * i2qa;
+                        const float ulo = (-qb * vl - sqrtf(fmaxf(dl_, 0.f))) * i2qa;
+                        const int xl = max(b.c0, (int)fmax(ceil(cxp + (double)(ulo - eps)), -1.0));
+                        const int xh = min(b.c1, (int)fmin(floor(cxp + (double)(uhi + eps)), 40000.0));
+                        if (xl <= xh && !(umax != umax)) {
+                            lo = (unsigned)min(255, (xl >> SUBX_SHIFT) - tx0);
+                            hi = (unsigned)min(255, (xh >> SUBX_SHIFT) - tx0);
+                        }
+                    }
+                    lo4[t >> 2] |= lo << (8 * (t & 3));
+                    hi4[t >> 2] |= hi << (8 * (t & 3));
+                }
+                bb.z = lo4[0]; bb.w = hi4[0];
+                bc.x = lo4[1]; bc.y = hi4[1];
+                bb.y |= 0x8000u;
+            }
+        }
+    }
     if (FUSED_SCAN) {
         const int t = threadIdx.x, ncls = P.ncells + 2;
         const int b0 = t * FUSED_PER_THREAD;
-        unsigned c[FUSED_PER_THREAD], sum = 0;
+        unsigned sum = 0;
 #pragma unroll
-        for (int k = 0; k < FUSED_PER_THREAD; ++k) {
-            c[k] = b0 + k < ncls ? V.cell_count[b0 + k] : 0u;
-            sum += c[k];
-        }
+        for (int k = 0; k < FUSED_PER_THREAD; ++k) sum += c[k];
         s_part[t] = sum;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
@@ -495,85 +592,15 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             }
         }
     }
-    if (i >= P.s) return;
-    const unsigned j = (FUSED_SCAN ? s_start[V.key[i]] : V.cell_start[V.key[i]]) + V.rank[i];
-    const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
-    const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1], rho = sigmas[i3 + 2];
-    const float x = coords[i2 + 0], y = coords[i2 + 1];
-    const Box b = gaussian_box(sx, sy, x, y, P);
-    // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56);
-    // everything per-Gaussian is evaluated ONCE here, in double, and rounded to float
-    const double dr = rho, dsx = sx, dsy = sy;
-    const double w1 = -0.5 / (1.0 - dr * dr);
-    const double w2 = 1.0 / (dsx * dsx), w3 = 1.0 / (dsx * dsy), w4 = 1.0 / (dsy * dsy);
-    const float A = (float)(w1 * LOG2E * w2);
-    const float B = (float)(-2.0 * dr * w1 * LOG2E * w3);
-    const float C = (float)(w1 * LOG2E * w4);
-    // record layout {x, y, A, B | C, r, g, b}: after the two 16-byte LDS reads of the forward every value it
-    // broadcasts into a packed-fp32 operand (y, C, r, g, b) is the low or high half of an aligned register pair
-    V.rec[2 * j + 0] = make_float4(x, y, A, B);
-    V.rec[2 * j + 1] = make_float4(C, colors[i3 + 0], colors[i3 + 1], colors[i3 + 2]);
-    // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
-    // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
-    V.fin[2 * j + 0] = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
-    V.fin[2 * j + 1] = make_float4((float)(1.0 / dsy), 0.f, 0.f, __uint_as_float((unsigned)i));
-    // does a pixel of a tile this Gaussian is binned to ever need the dmax test?  Not if its support box
-    // lies inside its dmax box: pixels beyond the support box carry < exp(-tau) whether tested or not.
-    const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
-    const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * sx * hx + 1.f <= P.dmax * hx &&
-                                           P.kcut * sy * hy + 1.f <= P.dmax * hy);
-    uint4 bb, bc = make_uint4(0u, 0u, 0u, 0u);
-    if (b.cls == 2) {
-        bb = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
-    } else {
-        bb.x = (unsigned)b.c0 | (needs_test ? 0x8000u : 0u) | ((unsigned)b.c1 << 16);
-        bb.y = (unsigned)b.r0 | ((unsigned)b.r1 << 16);
-        bb.z = bb.w = 0u;
-        // Row spans: for each 16-row band of forward tiles the window touches (at most 8 are encoded),
-        // the range of 8-px tile columns that the ellipse {exponent >= -tau} actually reaches.  The
-        // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
-        // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
-        const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
-        if (P.kcut > 0.f && ty1 - ty0 < 8 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
-            const double spx = dsx * hx, spy = dsy * hy;                  // sigmas in pixels
-            const double cxp = ((double)x + 1.0) * hx, cyp = ((double)y + 1.0) * hy;
-            const double tau = 0.5 * (double)P.kcut * (double)P.kcut;
-            const double omr = 1.0 - dr * dr;
-            const double qa = 0.5 / (omr * spx * spx), qb = -dr / (omr * spx * spy), qc = 0.5 / (omr * spy * spy);
-            const double umax = spx * (double)P.kcut, vmax = spy * (double)P.kcut;
-            const double vstar = dr * spy / spx * umax;                   // v of the ellipse's rightmost point
-            const int tx0 = b.c0 >> SUBX_SHIFT;
-            unsigned lo4[2] = {0u, 0u}, hi4[2] = {0u, 0u};
-            for (int t = 0; t < 8; ++t) {
-                unsigned lo = 1u, hi = 0u;  // empty
-                // the band's pixel rows Ya..Ya+15, relative to the centre
-                const double v0 = (double)(P.row0 + ((ty0 + t) << SUBY_SHIFT)) - cyp - WINDOW_EPS,
-                             v1 = v0 + (double)(SUBY - 1) + 2.0 * WINDOW_EPS;
-                if (t <= ty1 - ty0 && v1 >= -vmax && v0 <= vmax) {
-                    const double a0 = fmax(v0, -vmax), a1 = fmin(v1, vmax);
-                    const double vr = fmin(fmax(vstar, a0), a1), vl = fmin(fmax(-vstar, a0), a1);
-                    const double dr_ = 4.0 * qa * tau - (4.0 * qa * qc - qb * qb) * vr * vr;
-                    const double dl_ = 4.0 * qa * tau - (4.0 * qa * qc - qb * qb) * vl * vl;
-                    const double uhi = (-qb * vr + sqrt(fmax(dr_, 0.0))) / (2.0 * qa);
-                    const double ulo = (-qb * vl - sqrt(fmax(dl_, 0.0))) / (2.0 * qa);
-                    const int xl = max(b.c0, (int)fmax(ceil(cxp + ulo - WINDOW_EPS), -1.0));
-                    const int xh = min(b.c1, (int)fmin(floor(cxp + uhi + WINDOW_EPS), 40000.0));
-                    if (xl <= xh && !(umax != umax)) {
-                        lo = (unsigned)min(255, (xl >> SUBX_SHIFT) - tx0);
-                        hi = (unsigned)min(255, (xh >> SUBX_SHIFT) - tx0);
-                    }
-                }
-                lo4[t >> 2] |= lo << (8 * (t & 3));
-                hi4[t >> 2] |= hi << (8 * (t & 3));
-            }
-            bb.z = lo4[0]; bb.w = hi4[0];
-            bc.x = lo4[1]; bc.y = hi4[1];
-            bb.y |= 0x8000u;
-        }
-    }
+    if (!valid) return;
+    const unsigned j = (FUSED_SCAN ? s_start[key] : V.cell_start[key]) + rnk;
+    V.rec[2 * j + 0] = recA;
+    V.rec[2 * j + 1] = recB;
+    V.fin[2 * j + 0] = finA;
+    V.fin[2 * j + 1] = finB;
     V.bbox[2 * j] = bb;
     V.bbox[2 * j + 1] = bc;
-    if (b.cls == 1) {  // large Gaussians accumulate their row chunks atomically: start from zero
+    if (large) {  // large Gaussians accumulate their row chunks atomically: start from zero
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         V.done[j] = 0u;
