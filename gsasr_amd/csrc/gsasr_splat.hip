@@ -53,6 +53,10 @@ constexpr int SUBX = 8;         // forward sub-tile: 8 px wide x 16 px tall per 
 constexpr int SUBY = 16;
 constexpr int SUBX_SHIFT = 3, SUBY_SHIFT = 4;
 constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is binned as "large"
+#ifndef BWD_WAVES_N
+#define BWD_WAVES_N 4
+#endif
+constexpr int BWD_WAVES = BWD_WAVES_N;  // waves (= consecutive cell-ordered Gaussians) per backward workgroup
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y
 constexpr double LOG2E = 1.4426950408889634074;
@@ -638,10 +642,15 @@ __device__ __forceinline__ void fwd_eval_one(const float4 a, const float4 b, flo
     }
     ar += v * b.y;
     ag += v * b.z;
-    ab += v * b.w;
-    // (The compiler folds four of the five broadcasts {y, C, r, g, b} into op_sel and copies the fifth with a
-    // v_mov, whatever the record order.  Issuing that v_pk_fma_f32 through inline asm removes the copy but
-    // measured no faster, and inline asm is outside the compiler's trans-use hazard handling after v_exp_f32.)
+    // ab += v * b.w with b.w read as the HIGH half of the (g, b) register pair.  The compiler folds four of the
+    // five broadcasts {y, C, r, g, b} into op_sel but copies the fifth with a v_mov whatever the record order (one
+    // VALU slot in 13.5 per record; -3% at config 2, -8% at config 3).  Inline asm is outside the compiler's
+    // hazard recogniser, and this instruction may be scheduled right behind the v_exp_f32 that produces `v`
+    // (trans-use hazard on gfx950: one wait state) -- hence the s_nop, without which results are garbage.
+    {
+        const v2f gb = {b.z, b.w};
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(ab) : "v"(gb), "v"(v));
+    }
 }
 
 template <bool TEST>
@@ -930,7 +939,7 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     R.k12 += (v2f){g.b1, g.b2} * v.y;
 }
 
-template <bool TEST, int LXLOG>
+template <bool TEST, int LXLOG, bool UNROLL>
 __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int lane, const Params &P,
                                           const float *__restrict__ pxt, const float *__restrict__ pyt,
                                           const float *__restrict__ grad, float x, float y, float cr, float cg,
@@ -943,7 +952,6 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     const size_t rowpitch = (size_t)P.w * 3;
     const float nK1 = -HALF_LOG2E * cinv;
     // issued together with the px load below: one round trip for both tables instead of two dependent ones
-    // (also issuing the first trips' gradient loads here was measured: no gain, +8 VGPRs)
     const float py_first = pyt[min(r0 + lane, r1)];
     for (int strip = 0; strip < bw; strip += 64) {
         const int cc = strip + col;
@@ -975,8 +983,14 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 const_cast<float *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
             int soff = 0;
             int Yb = rb;
-            // two trips per iteration: four gradient loads in flight before the first is consumed
-            for (; Yb + 4 * RPI - 1 <= rend; Yb += 4 * RPI, soff += 4 * halfb, sp += 4 * RPI) {
+            // Lanes outside the window sit the trips out (exec mask): the backward is co-limited by the CU's
+            // vector-memory pipe (two 768-byte loads per trip and wave, four SIMDs behind one L1), and idle
+            // lanes would fetch gradient pixels only to multiply them by zero.
+            if (inx) {
+            // UNROLL: two trips per iteration, four gradient loads in flight before the first is consumed.  Pays
+            // for windows of many trips (x8 and up); costs 18 VGPRs = two waves per SIMD, which small windows
+            // (x4, 6 trips) need more: the host picks the instantiation (gsasr_splat_backward).
+            for (; UNROLL && Yb + 4 * RPI - 1 <= rend; Yb += 4 * RPI, soff += 4 * halfb, sp += 4 * RPI) {
                 const Grad6 g0 = bwd_load(rsrc, voff, soff, soff + halfb);
                 const Grad6 g1 = bwd_load(rsrc, voff, soff + 2 * halfb, soff + 3 * halfb);
                 const v2f n0 = {sp[0], sp[RPI]}, n1 = {sp[2 * RPI], sp[3 * RPI]};
@@ -997,6 +1011,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 const v2f w0 = TEST ? (v2f){spy[64 + ia], spy[64 + ic]} : n0;
                 bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, soff, soff + halfb), n0, w0, Ya <= rend, Yc <= rend, K0, nK1,
                                      rho_u, cr, cg, cb, P.dmax);
+            }
             }
         }
         // Expand the column's three sums M0 = sum q, N1 = sum q B, N2 = sum q B^2 (u = dx/sx is a lane constant,
@@ -1111,7 +1126,7 @@ __device__ __forceinline__ void bwd_fetch_first(const PlanView &V, const unsigne
                  : "memory");
 }
 
-template <bool BOUNDED>
+template <bool BOUNDED, bool UNROLL>
 __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk, bool atomic, int lane, const Params &P,
                                          const PlanView &V, const float *__restrict__ grad, float *spy, float *red,
                                          float *__restrict__ g_sigmas, float *__restrict__ g_coords,
@@ -1148,7 +1163,7 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
     float d = 0.f;
     if (!empty) {
 #define GSASR_SWEEP(T, L) \
-    bwd_sweep<T, L>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
+    bwd_sweep<T, L, UNROLL>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
         if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
         else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
         else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
@@ -1173,8 +1188,8 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
     bwd_write(d, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
 }
 
-template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
+template <bool BOUNDED, bool UNROLL>
+__global__ __launch_bounds__(64 * BWD_WAVES) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
                                                     float *__restrict__ g_sigmas, float *__restrict__ g_coords,
                                                     float *__restrict__ g_colors)
 {
@@ -1185,10 +1200,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
     const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned gw = t * 4u + (unsigned)wv;
-    const unsigned nwaves = nb * 4u;
-    __shared__ float s_py[4][128];  // per wave: v = dy/sy of a 64-row block, then (TEST) the raw dy
-    __shared__ __attribute__((aligned(16))) float s_red[4][512];
+    const unsigned gw = t * (unsigned)BWD_WAVES + (unsigned)wv;
+    const unsigned nwaves = nb * (unsigned)BWD_WAVES;
+    __shared__ float s_py[BWD_WAVES][128];  // per wave: v = dy/sy of a 64-row block, then (TEST) the raw dy
+    __shared__ __attribute__((aligned(16))) float s_red[BWD_WAVES][512];
     float *spy = s_py[wv], *red = s_red[wv];
     // one Gaussian per wave, dispatched by the hardware (a persistent-workgroup variant with a static
     // partition was measured 13% slower at config 2 and 60% slower at config 3: load imbalance)
@@ -1198,9 +1213,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
     bwd_fetch_first(V, V.cell_start + P.ncells, min(gw, (unsigned)P.s - 1u), G, lim);  // speculative: class checked below
     const unsigned large_beg = lim.x, large_end = lim.y;
     if (gw < large_beg)
-        bwd_item<BOUNDED>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED, UNROLL>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     else if (gw < large_end)
-        bwd_item<BOUNDED>(gw, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED, UNROLL>(gw, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     else if (gw < (unsigned)P.s && (P.flags & GSASR_FLAG_OVERWRITE_GRADS))   // dead class: the gradient is zero
         bwd_write(0.f, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
     // remaining row chunks of the large class, spread over all waves
@@ -1209,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Params P, PlanView V, const 
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
         bwd_fetch(V, j, G);
-        bwd_item<BOUNDED>(j, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED, UNROLL>(j, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     }
 }
 
@@ -1468,12 +1483,16 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
     if (!grad_img) return fail(GSASR_ERR_ARG, "null pointer");
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, const_cast<void *>(workspace));
-    const dim3 grid((unsigned)((dims->s + 3) / 4)), block(256);
+    const dim3 grid((unsigned)((dims->s + BWD_WAVES - 1) / BWD_WAVES)), block(64 * BWD_WAVES);
     hipStream_t st = (hipStream_t)stream;
-    if (P.bounded)
-        hipLaunchKernelGGL(k_render_bwd<true>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
-    else
-        hipLaunchKernelGGL(k_render_bwd<false>, grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
+    // Two instantiations of the same sweep (identical results): with the two-trip unrolled loop (88 VGPRs, 5 waves
+    // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
+    // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
+    const bool unroll = (double)(dims->row1 - dims->row0) * (double)dims->w >= 32.0 * (double)dims->s;
+#define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
+    if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
+    else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
+#undef GSASR_BWD
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }

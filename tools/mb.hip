@@ -1,12 +1,18 @@
 // tools/mb.hip -- standalone micro-benchmark of libgsasr_splat's kernels (development aid, not product).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Iinclude [-DVARIANT...] tools/mb.hip -o /tmp/mb
-//   /tmp/mb [lr_h lr_w scale dmax tau iters gpp flags]
+//   bash tools/build_mb.sh [name] [-DVARIANT... | -DGSASR_SRC='"/tmp/variant.hip"']     -> tools/bin/mb[_name]
+//   tools/bin/mb [lr_h lr_w scale dmax tau iters gpp flags]
 //
-// It #includes the library source so that -D switches can select kernel variants, generates
+// It #includes the library SOURCE (it does not link libgsasr_splat.so: LD_LIBRARY_PATH tricks do nothing, the
+// binary must be rebuilt after every kernel change -- tools/build_mb.sh uses the library's own flags) so that
+// -D switches or an alternative source file can select kernel variants, generates
 // GSASR-shaped Gaussians (LR raster + jitter, sigmoid/tanh activations) with its own
 // RNG, and times plan / forward / backward with hipEvents on one stream.
+#ifdef GSASR_SRC
+#include GSASR_SRC
+#else
 #include "../gsasr_amd/csrc/gsasr_splat.hip"
+#endif
 
 #include <algorithm>
 #include <random>
