@@ -351,7 +351,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
                 "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                "note": "backward stage = k_render_bwd + k_bwd_finalize; outputs are stored, not accumulated (no memsets)"}
+                "note": "stage times from events on the launch stream; outputs are stored, not accumulated (no memsets)"}
     # The binding unit is the fp32 VALU / v_exp_f32 pipe, not HBM: report pair rates and the VALU
     # occupancy next to the HBM fraction.
     if rank == 0:

@@ -28,3 +28,14 @@ cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls -la $OUT
 cat $OUT/kernel_stats.txt $OUT/pmc_fetch.txt $OUT/pmc_write.txt
 tail -c 2500 $OUT/bench.json
+# 4. the other BASELINE configs and variants on this GPU (bench lines only)
+cd $R
+python bench.py --no-cpu-baseline --config c3 --steps 10 --warmup 3 > $OUT/bench_c3.json 2>> $OUT/bench.err
+python bench.py --no-cpu-baseline --config c4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2>> $OUT/bench.err
+python bench.py --no-cpu-baseline --dmax 0.5 > $OUT/bench_c2_dmax0p5.json 2>> $OUT/bench.err
+python bench.py --no-cpu-baseline --dmax -1 > $OUT/bench_c2_unbounded.json 2>> $OUT/bench.err
+python bench.py --no-cpu-baseline --cutoff 104 > $OUT/bench_c2_tau104.json 2>> $OUT/bench.err
+python bench.py --no-cpu-baseline --cutoff 32 > $OUT/bench_c2_tau32.json 2>> $OUT/bench.err
+python tools/e2e_time.py > $OUT/e2e_time.txt 2>&1
+for f in $OUT/bench_c*.json; do echo $f; python -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],4), {k:round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items()})"; done
+cat $OUT/e2e_time.txt | tail -5
