@@ -37,7 +37,8 @@ class Dims(ctypes.Structure):
     """struct gsasr_dims"""
     _fields_ = [("s", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("c", ctypes.c_int),
                 ("dmax", ctypes.c_float), ("row0", ctypes.c_int), ("row1", ctypes.c_int),
-                ("cutoff", ctypes.c_float), ("flags", ctypes.c_uint)]
+                ("cutoff", ctypes.c_float), ("flags", ctypes.c_uint),
+                ("batch", ctypes.c_int), ("slot", ctypes.c_int), ("sample_hw", ctypes.POINTER(ctypes.c_int))]
 
 
 _lib = None
@@ -91,7 +92,7 @@ def lib():
         L.gsasr_get_default_cutoff.restype = f
         L.gsasr_resolve_cutoff.restype = f
         L.gsasr_resolve_cutoff.argtypes = [f, i]
-        if L.gsasr_abi_version() != 1:
+        if L.gsasr_abi_version() != 2:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
     return _lib
@@ -323,6 +324,62 @@ def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(step, "step_size")
     pg = _chk(grad_hwc, "grads", (p.dims.h, p.dims.w, 3))
+    with torch.cuda.device(p.device):
+        gp = torch.empty_like(gs_parameters)
+        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
+                                        p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
+    return gp
+
+
+# ---- batched canvas --------------------------------------------------------------
+MAX_BATCH = 64   # GSASR_MAX_BATCH
+
+
+def make_batch_dims(n_per: int, sizes, w_max: int, h_max: int, dmax: Optional[float], cutoff: float = 0.0,
+                    flags: int = 0) -> Dims:
+    """dims of a canvas of len(sizes) slots; `sizes` = [(h_b, w_b)].  The returned struct owns the host array."""
+    B = len(sizes)
+    if not (1 < B <= MAX_BATCH):
+        raise RuntimeError(f"batch size must be in 2..{MAX_BATCH}")
+    slot = (int(h_max) + 15) // 16 * 16
+    hw = (ctypes.c_int * (2 * B))(*[int(v) for hw_ in sizes for v in hw_])
+    d = Dims(int(n_per) * B, slot * B, int(w_max), 3, -1.0 if dmax is None else float(dmax), 0, slot * B,
+             float(cutoff), int(flags), B, slot, ctypes.cast(hw, ctypes.POINTER(ctypes.c_int)))
+    d._keepalive = hw
+    return d
+
+
+def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax: Optional[float]):
+    """prologue + plan + forward of a whole batch in ONE set of launches.
+    `gs_parameters` [B,N,9], `steps` [B] (device), `sizes` [(h_b, w_b)] -> planar images `[B,3,slot,w_max]`
+    (sample b in `[:, :, :h_b, :w_b]`, zero elsewhere) and the plan for `batch_backward`."""
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(steps, "step_sizes")
+    if gs_parameters.dim() != 3 or steps.numel() != gs_parameters.shape[0] or len(sizes) != gs_parameters.shape[0]:
+        raise RuntimeError("gs_parameters must be [B,N,9] with one step size and one (h,w) per sample")
+    if dmax is not None and not (float(dmax) >= 0.0):
+        raise RuntimeError("dmax must be >= 0")
+    B, n = gs_parameters.shape[0], gs_parameters.shape[1]
+    h_max, w_max = max(h for h, _ in sizes), max(w for _, w in sizes)
+    d = make_batch_dims(n, sizes, w_max, h_max, dmax, flags=FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE)
+    L = lib()
+    nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        check(-1, "gsasr_step_workspace_bytes")
+    dev = gs_parameters.device
+    with torch.cuda.device(dev):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        img = torch.empty(B, 3, d.slot, w_max, dtype=torch.float32, device=dev)
+        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), _stream(dev)),
+              "gsasr_step_forward")
+    return img, Plan(d, ws, dev)
+
+
+def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, grad_bhwc: torch.Tensor) -> torch.Tensor:
+    """`grad_bhwc` is `[B, slot, w_max, 3]`; returns d/d gs_parameters `[B,N,9]`."""
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(steps, "step_sizes")
+    pg = _chk(grad_bhwc, "grads", (p.dims.batch, p.dims.slot, p.dims.w, 3))
     with torch.cuda.device(p.device):
         gp = torch.empty_like(gs_parameters)
         check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),

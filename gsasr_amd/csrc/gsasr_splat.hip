@@ -68,6 +68,15 @@ struct Params {
     float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled
     int ncx, ncy, ncells;
     unsigned flags;  // GSASR_FLAG_*
+    int batch;       // 1: one image.  B > 1: B samples stacked in a canvas of B slots (h = B*slot rows, w columns)
+    int slot;        // rows per slot (multiple of 16)
+    int nper;        // Gaussians per sample (sample-major order)
+};
+
+// One sample of a batched canvas: its own pixel-grid size, its first canvas row and its px-table offset.
+// A single image is the sample {h, w, 0, 0}.
+struct Geo {
+    int h, w, base, pxo;
 };
 
 // element strides of the caller's Gaussian arrays: [s,3]/[s,2]/[s,3], or columns of packed [s,8] records
@@ -75,6 +84,7 @@ __device__ __forceinline__ int stride3(const Params &P) { return (P.flags & GSAS
 __device__ __forceinline__ int stride2(const Params &P) { return (P.flags & GSASR_FLAG_STRIDE8) ? 8 : 2; }
 
 struct PlanView {
+    int4 *geo;              // [GSASR_MAX_BATCH] {h_b, w_b, first canvas row, px-table offset} (batched canvas only)
     unsigned *hdr;          // [HDR_WORDS]
     unsigned *cell_count;   // [ncells+2]   (ncells = "large" class, ncells+1 = "dead" class)
     unsigned *cell_start;   // [ncells+3]   exclusive scan of cell_count, last = s
@@ -93,8 +103,15 @@ struct PlanView {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+__device__ __forceinline__ Geo sample_geo(const Params &P, const PlanView &V, int b)
+{
+    if (P.batch <= 1) return Geo{P.h, P.w, 0, 0};
+    const int4 g = V.geo[b];
+    return Geo{g.x, g.y, g.z, g.w};
+}
+
 struct Layout {
-    size_t off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox;
+    size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox;
     size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
     size_t total;
     int ncx, ncy, ncells;
@@ -102,13 +119,27 @@ struct Layout {
 
 bool dims_ok(const gsasr_dims *d)
 {
-    return d && d->s >= 0 && d->h >= 2 && d->w >= 2 && d->h <= 32767 && d->w <= 32767 && d->c == 3 &&
-           d->row0 >= 0 && d->row0 <= d->row1 && d->row1 <= d->h && !(d->dmax != d->dmax);
+    if (!(d && d->s >= 0 && d->h >= 2 && d->w >= 2 && d->h <= 32767 && d->w <= 32767 && d->c == 3 &&
+          d->row0 >= 0 && d->row0 <= d->row1 && d->row1 <= d->h && !(d->dmax != d->dmax)))
+        return false;
+    if (d->batch <= 1) return true;
+    // batched canvas: B slots of `slot` rows, whole canvas, uniform Gaussian count, per-sample sizes inside the slot
+    if (d->batch > GSASR_MAX_BATCH || d->slot < 16 || (d->slot & 15) || d->h != d->batch * d->slot || d->row0 != 0 ||
+        d->row1 != d->h || !d->sample_hw || d->s % d->batch != 0)
+        return false;
+    for (int b = 0; b < d->batch; ++b)
+        if (d->sample_hw[2 * b] < 2 || d->sample_hw[2 * b] > d->slot || d->sample_hw[2 * b + 1] < 2 ||
+            d->sample_hw[2 * b + 1] > d->w)
+            return false;
+    return true;
 }
+
+int batch_of(const gsasr_dims *d) { return d->batch > 1 ? d->batch : 1; }
 
 int classify_blocks(const gsasr_dims *d)
 {
-    const int n = d->s > d->w ? (d->s > d->h ? d->s : d->h) : (d->w > d->h ? d->w : d->h);
+    const int pxn = d->w * batch_of(d);  // one px table per sample
+    const int n = d->s > pxn ? (d->s > d->h ? d->s : d->h) : (pxn > d->h ? pxn : d->h);
     return (n + 255) / 256;
 }
 
@@ -123,8 +154,9 @@ Layout make_layout(const gsasr_dims *d)
     L.off_hdr = o;    o += HDR_WORDS * 4;
     L.off_count = o;  o += align_up(ncls * 4, 256);
     L.zero_bytes = o;
+    L.off_geo = o;    o += GSASR_MAX_BATCH * 16;   // (outside the zeroed region: written once by k_batch_geo)
     L.off_start = o;  o += align_up((ncls + 1) * 4, 256);
-    L.off_px = o;     o += align_up((size_t)d->w * 4, 256);
+    L.off_px = o;     o += align_up((size_t)d->w * 4 * (size_t)batch_of(d), 256);
     L.off_py = o;     o += align_up((size_t)d->h * 4, 256);
     L.off_key = o;    o += align_up(s * 4, 256);
     L.off_rank = o;   o += align_up(s * 4, 256);
@@ -143,6 +175,7 @@ PlanView make_view(const Layout &L, void *ws)
 {
     char *b = (char *)ws;
     PlanView V;
+    V.geo = (int4 *)(b + L.off_geo);
     V.hdr = (unsigned *)(b + L.off_hdr);
     V.cell_count = (unsigned *)(b + L.off_count);
     V.cell_start = (unsigned *)(b + L.off_start);
@@ -190,6 +223,9 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.kcut = tau > 0.f ? (float)(std::sqrt(2.0 * (double)tau) * (1.0 + 1e-6)) : 0.f;
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
     P.flags = d->flags;
+    P.batch = batch_of(d);
+    P.slot = d->batch > 1 ? d->slot : d->h;
+    P.nper = d->batch > 1 ? d->s / d->batch : d->s;
     return P;
 }
 
@@ -218,7 +254,7 @@ struct Box {
 
 constexpr double WINDOW_EPS = 0.02;  // px; covers every rounding between these windows and the kernels' float tests
 
-__device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y, const Params &P)
+__device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y, const Params &P, const Geo &g)
 {
     Box b;
     float ext_x = P.dmax, ext_y = P.dmax;
@@ -229,8 +265,9 @@ __device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y
     // Pixel X sits at px = 2X/(w-1)-1, so |px - x| <= ext  <=>  |X - cxp| <= ext*hx with cxp = (x+1)*hx.
     // Evaluated in double (once per Gaussian); the float pixel table differs from the exact grid by
     // < 1e-2 px even at w = 32767, which WINDOW_EPS covers, so the window is tight to the pixel.
-    const double hx = 0.5 * (double)(P.w - 1), hy = 0.5 * (double)(P.h - 1);
-    const double cxp = ((double)x + 1.0) * hx, cyp = ((double)y + 1.0) * hy;
+    // (g = the sample's own grid; its rows start at canvas row g.base.)
+    const double hx = 0.5 * (double)(g.w - 1), hy = 0.5 * (double)(g.h - 1);
+    const double cxp = ((double)x + 1.0) * hx, cyp = ((double)y + 1.0) * hy + (double)g.base;
     const double ex = (double)ext_x * hx, ey = (double)ext_y * hy;
     b.ex = (float)ex;
     b.ey = (float)ey;
@@ -238,10 +275,10 @@ __device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y
     const double loy = ceil(cyp - ey - WINDOW_EPS), hiy = floor(cyp + ey + WINDOW_EPS);
     const bool finite = (sx - sx == 0.f) && (sy - sy == 0.f) && (x - x == 0.f) && (y - y == 0.f);
     b.c0 = (int)fmax(lox, 0.0);
-    b.c1 = (int)fmin(hix, (double)(P.w - 1));
-    b.r0 = (int)fmax(loy, (double)P.row0);
-    b.r1 = (int)fmin(hiy, (double)(P.row1 - 1));
-    if (!finite || b.c0 > b.c1 || b.r0 > b.r1 || !(hix >= 0.0) || !(hiy >= 0.0))
+    b.c1 = (int)fmin(hix, (double)(g.w - 1));
+    b.r0 = (int)fmax(loy, (double)max(P.row0, g.base));
+    b.r1 = (int)fmin(hiy, (double)(min(P.row1, g.base + g.h) - 1));
+    if (!finite || b.c0 > b.c1 || b.r0 > b.r1 || !(hix >= 0.0) || !(hiy >= (double)g.base))
         b.cls = 2;
     else if (!(b.ex <= (float)RCAP_PX && b.ey <= (float)RCAP_PX))
         b.cls = 1;
@@ -266,6 +303,16 @@ __device__ __forceinline__ float wave_sum(float v)
 // ---------------------------------------------------------------------------------------------------
 // plan kernels
 // ---------------------------------------------------------------------------------------------------
+struct BatchSizes {   // kernel argument: the host's per-sample sizes
+    unsigned short h[GSASR_MAX_BATCH], w[GSASR_MAX_BATCH];
+};
+
+__global__ __launch_bounds__(64) void k_batch_geo(BatchSizes S, int batch, int slot, int w, int4 *__restrict__ geo)
+{
+    const int b = threadIdx.x;
+    if (b < batch) geo[b] = make_int4((int)S.h[b], (int)S.w[b], b * slot, b * w);
+}
+
 __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restrict__ sigmas,
                                                   const float *__restrict__ coords, PlanView V)
 {
@@ -273,22 +320,28 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
-    if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
-    if (i < P.h) V.py[i] = (float)(2.0 * (double)i / (double)(P.h - 1) - 1.0);
+    if (P.batch <= 1) {
+        if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
+        if (i < P.h) V.py[i] = (float)(2.0 * (double)i / (double)(P.h - 1) - 1.0);
+    } else {  // one px table per sample, py over the canvas rows: each sample's own grid (padding continues it)
+        if (i < P.w * P.batch) V.px[i] = (float)(2.0 * (double)(i % P.w) / (double)(V.geo[i / P.w].y - 1) - 1.0);
+        if (i < P.h) V.py[i] = (float)(2.0 * (double)(i % P.slot) / (double)(V.geo[i / P.slot].x - 1) - 1.0);
+    }
     unsigned rx = 0, ry = 0, key = 0xffffffffu;
     if (i < P.s) {
         const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
         const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1];
         const float x = coords[i2 + 0], y = coords[i2 + 1];
-        const Box b = gaussian_box(sx, sy, x, y, P);
+        const Geo g = sample_geo(P, V, P.batch > 1 ? i / P.nper : 0);
+        const Box b = gaussian_box(sx, sy, x, y, P, g);
         if (b.cls == 2) {
             key = (unsigned)P.ncells + 1u;
         } else if (b.cls == 1) {
             key = (unsigned)P.ncells;
         } else {
-            const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
-            int cx = (int)fminf(fmaxf(floorf((x + 1.f) * hx), 0.f), (float)(P.w - 1)) >> CELL_SHIFT;
-            int cy = (int)fminf(fmaxf(floorf((y + 1.f) * hy), 0.f), (float)(P.h - 1)) >> CELL_SHIFT;
+            const float hx = 0.5f * (float)(g.w - 1), hy = 0.5f * (float)(g.h - 1);
+            int cx = (int)fminf(fmaxf(floorf((x + 1.f) * hx), 0.f), (float)(g.w - 1)) >> CELL_SHIFT;
+            int cy = ((int)fminf(fmaxf(floorf((y + 1.f) * hy), 0.f), (float)(g.h - 1)) + g.base) >> CELL_SHIFT;
             key = (unsigned)(cy * P.ncx + cx);
             rx = (unsigned)ceilf(b.ex) + 2u;
             ry = (unsigned)ceilf(b.ey) + 2u;
@@ -479,7 +532,9 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
         const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1], rho = sigmas[i3 + 2];
         const float x = coords[i2 + 0], y = coords[i2 + 1];
-        const Box b = gaussian_box(sx, sy, x, y, P);
+        const int smp = P.batch > 1 ? i / P.nper : 0;
+        const Geo g = sample_geo(P, V, smp);
+        const Box b = gaussian_box(sx, sy, x, y, P, g);
         large = b.cls == 1;
         // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56);
         // everything per-Gaussian is evaluated ONCE here, in double, and rounded to float
@@ -496,10 +551,12 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
         // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
         finA = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
-        finB = make_float4((float)(1.0 / dsy), 0.f, 0.f, __uint_as_float((unsigned)i));
+        // + where the sample's px table starts and which slot it is (0, 0 for a single image)
+        finB = make_float4((float)(1.0 / dsy), __uint_as_float((unsigned)g.pxo), __uint_as_float((unsigned)smp),
+                           __uint_as_float((unsigned)i));
         // does a pixel of a tile this Gaussian is binned to ever need the dmax test?  Not if its support box
         // lies inside its dmax box: pixels beyond the support box carry < exp(-tau) whether tested or not.
-        const float hx = 0.5f * (float)(P.w - 1), hy = 0.5f * (float)(P.h - 1);
+        const float hx = 0.5f * (float)(g.w - 1), hy = 0.5f * (float)(g.h - 1);
         const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * sx * hx + 1.f <= P.dmax * hx &&
                                                P.kcut * sy * hy + 1.f <= P.dmax * hy);
         if (b.cls == 2) {
@@ -518,7 +575,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 // chain is k_bin's run time; an ulp of a <= 128 px offset is far inside WINDOW_EPS.  Only the absolute
                 // pixel coordinates stay in double.)
                 const float spx = sx * hx, spy = sy * hy;                     // sigmas in pixels
-                const double cxp = ((double)x + 1.0) * (double)hx, cyp = ((double)y + 1.0) * (double)hy;
+                const double cxp = ((double)x + 1.0) * (double)hx, cyp = ((double)y + 1.0) * (double)hy + (double)g.base;
                 const float tau = 0.5f * P.kcut * P.kcut;
                 const float omr = (float)(1.0 - dr * dr);
                 const float iq = 1.f / (omr * spx * spy);
@@ -696,7 +753,8 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
 {
     const int sx1 = min(sx0 + SUBX - 1, P.w - 1), sy1 = min(sy0 + SUBY - 1, P.row1 - 1);
     const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
-    const float px = V.px[min(X, P.w - 1)];
+    // (batched canvas: slots are whole tile rows, so a sub-tile belongs to one sample; its px table is the sy0/slot-th)
+    const float px = V.px[(P.batch > 1 ? (sy0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
     const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y1, P.h - 1)]};
 
     const float4 *__restrict__ rec = V.rec;
@@ -788,32 +846,45 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
     }
 }
 
-__device__ __forceinline__ void fwd_store(const Params &P, float *__restrict__ img, int sx0, int sy0, int lane,
-                                          v2f ar, v2f ag, v2f ab)
+__device__ __forceinline__ void fwd_store(const Params &P, const PlanView &V, float *__restrict__ img, int sx0, int sy0,
+                                          int lane, v2f ar, v2f ag, v2f ab)
 {
     const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
     if (X >= P.w) return;
     const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
-    if (P.flags & GSASR_FLAG_CHW_IMAGE) {  // planar [3, rows, w]
-        const size_t plane = (size_t)(P.row1 - P.row0) * P.w;
-        if (Y0 < P.row1) {
-            float *o = img + (size_t)(Y0 - P.row0) * P.w + X;
+    bool ok0 = Y0 < P.row1, ok1 = Y1 < P.row1;
+    // CHW: planar [3, rows, w]; batched canvas: [B, 3, slot, w] (HWC is simply the canvas [B*slot, w, 3])
+    size_t plane = (size_t)(P.row1 - P.row0) * P.w, chw0 = (size_t)(Y0 - P.row0) * P.w + X, chw1 = chw0 + 8 * (size_t)P.w;
+    if (P.batch > 1) {
+        // pixels of the slot outside the sample's own h_b x w_b grid are padding: stored as zero, never added to
+        const int smp = sy0 / P.slot;
+        const Geo g = sample_geo(P, V, smp);
+        const bool inx = X < g.w, in0 = inx && Y0 - g.base < g.h, in1 = inx && Y1 - g.base < g.h;
+        if (!in0) { ar.x = ag.x = ab.x = 0.f; ok0 = ok0 && store; }
+        if (!in1) { ar.y = ag.y = ab.y = 0.f; ok1 = ok1 && store; }
+        plane = (size_t)P.slot * P.w;
+        chw0 = ((size_t)smp * 3 * P.slot + (size_t)(Y0 - g.base)) * P.w + X;
+        chw1 = chw0 + 8 * (size_t)P.w;
+    }
+    if (P.flags & GSASR_FLAG_CHW_IMAGE) {
+        if (ok0) {
+            float *o = img + chw0;
             if (store) { o[0] = ar.x; o[plane] = ag.x; o[2 * plane] = ab.x; }
             else { o[0] += ar.x; o[plane] += ag.x; o[2 * plane] += ab.x; }
         }
-        if (Y1 < P.row1) {
-            float *o = img + (size_t)(Y1 - P.row0) * P.w + X;
+        if (ok1) {
+            float *o = img + chw1;
             if (store) { o[0] = ar.y; o[plane] = ag.y; o[2 * plane] = ab.y; }
             else { o[0] += ar.y; o[plane] += ag.y; o[2 * plane] += ab.y; }
         }
         return;
     }
-    if (Y0 < P.row1) {
+    if (ok0) {
         float *o = img + ((size_t)(Y0 - P.row0) * P.w + X) * 3;
         if (store) { o[0] = ar.x; o[1] = ag.x; o[2] = ab.x; }
         else { o[0] += ar.x; o[1] += ag.x; o[2] += ab.x; }
     }
-    if (Y1 < P.row1) {
+    if (ok1) {
         float *o = img + ((size_t)(Y1 - P.row0) * P.w + X) * 3;
         if (store) { o[0] = ar.y; o[1] = ag.y; o[2] = ab.y; }
         else { o[0] += ar.y; o[1] += ag.y; o[2] += ab.y; }
@@ -843,7 +914,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
     if (sx0 >= P.w) return;  // wave-uniform
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
     fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, 0u, 1u, s_stage[wv], ar, ag, ab);
-    fwd_store(P, img, sx0, sy0, lane, ar, ag, ab);
+    fwd_store(P, V, img, sx0, sy0, lane, ar, ag, ab);
 }
 
 // Small images (fewer sub-tiles than the chip has wave slots, e.g. the 192x192 training crops of
@@ -873,7 +944,7 @@ __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V,
             ag.x += s_part[k][2][lane]; ag.y += s_part[k][3][lane];
             ab.x += s_part[k][4][lane]; ab.y += s_part[k][5][lane];
         }
-        fwd_store(P, img, sx0, sy0, lane, ar, ag, ab);
+        fwd_store(P, V, img, sx0, sy0, lane, ar, ag, ab);
     }
 }
 
@@ -1095,7 +1166,7 @@ typedef unsigned u8v __attribute__((ext_vector_type(8)));
 struct BwdRec {
     u4v bb;    // bbox word 0
     u8v rec;   // {x, y, A, B | C, r, g, b}
-    u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, -, -, index}
+    u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, px-table offset, sample, index}
 };
 
 __device__ __forceinline__ void bwd_fetch(const PlanView &V, unsigned j, BwdRec &R)
@@ -1156,14 +1227,22 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
         // dmax test), and the ragged, masked last trip disappears.
         const int rows_per_trip = bw <= 16 ? 8 : (bw <= 32 ? 4 : 2);
         const int pad = (rows_per_trip - ((r1 - r0 + 1) & (rows_per_trip - 1))) & (rows_per_trip - 1);
-        if (r1 + pad <= P.row1 - 1) r1 += pad;
-        else if (r0 - pad >= P.row0) r0 -= pad;
+        // (batched canvas: stay inside the sample's own rows -- whatever gradient the caller left in the padding
+        // of the slot must not be read)
+        int lo = P.row0, hi = P.row1 - 1;
+        if (P.batch > 1) {
+            const int4 gg = V.geo[G.fin[6]];
+            lo = gg.z;
+            hi = gg.z + gg.x - 1;
+        }
+        if (r1 + pad <= hi) r1 += pad;
+        else if (r0 - pad >= lo) r0 -= pad;
     }
     const bool test = BOUNDED && (bb.x & 0x8000u);
     float d = 0.f;
     if (!empty) {
 #define GSASR_SWEEP(T, L) \
-    bwd_sweep<T, L, UNROLL>(c0, bw, r0, r1, lane, P, V.px, V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
+    bwd_sweep<T, L, UNROLL>(c0, bw, r0, r1, lane, P, V.px + G.fin[5], V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
         if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
         else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
         else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
@@ -1235,11 +1314,17 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 
 __global__ __launch_bounds__(256) void k_prologue_fwd(const float *__restrict__ p, const float *__restrict__ step_ptr,
                                                       int n, int h, int w, float *__restrict__ sigmas,
-                                                      float *__restrict__ coords, float *__restrict__ colors)
+                                                      float *__restrict__ coords, float *__restrict__ colors,
+                                                      int nper, const int4 *__restrict__ geo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float step = step_ptr[0];
+    if (geo) {  // batched canvas: sample i/nper has its own size and step size
+        const int4 g = geo[i / nper];
+        h = g.x;
+        w = g.y;
+    }
+    const float step = step_ptr[geo ? i / nper : 0];
     const float *q = p + (size_t)i * 9;
     const float sx = 0.99999f * sigmoidf_(q[0]) + 1e-6f;  // the network's sigma_x is the ROW std
     const float sy = 0.99999f * sigmoidf_(q[1]) + 1e-6f;
@@ -1260,11 +1345,16 @@ __global__ __launch_bounds__(256) void k_prologue_fwd(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_prologue_bwd(const float *__restrict__ p, const float *__restrict__ step_ptr,
                                                       int n, int h, int w, const float *__restrict__ gs,
                                                       const float *__restrict__ gc, const float *__restrict__ gk,
-                                                      float *__restrict__ gp)
+                                                      float *__restrict__ gp, int nper, const int4 *__restrict__ geo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float step = step_ptr[0];
+    if (geo) {
+        const int4 g = geo[i / nper];
+        h = g.x;
+        w = g.y;
+    }
+    const float step = step_ptr[geo ? i / nper : 0];
     const float *q = p + (size_t)i * 9;
     const float W = (float)w, H = (float)h;
     const float s0 = sigmoidf_(q[0]), s1 = sigmoidf_(q[1]), th = tanhf(q[2]), al = sigmoidf_(q[3]);
@@ -1290,6 +1380,20 @@ __global__ __launch_bounds__(256) void k_prologue_bwd(const float *__restrict__ 
         hipError_t _e = (expr);                          \
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
+
+// batched canvas: publish the per-sample geometry (host array in dims) to the workspace
+int launch_batch_geo(const gsasr_dims *dims, const PlanView &V, hipStream_t st)
+{
+    if (dims->batch <= 1) return GSASR_OK;
+    BatchSizes S;
+    for (int b = 0; b < GSASR_MAX_BATCH; ++b) {
+        S.h[b] = (unsigned short)(b < dims->batch ? dims->sample_hw[2 * b] : 0);
+        S.w[b] = (unsigned short)(b < dims->batch ? dims->sample_hw[2 * b + 1] : 0);
+    }
+    hipLaunchKernelGGL(k_batch_geo, dim3(1), dim3(64), 0, st, S, dims->batch, dims->slot, dims->w, V.geo);
+    HIP_TRY(hipGetLastError());
+    return GSASR_OK;
+}
 
 int check_ws(const gsasr_dims *dims, const void *ws, size_t ws_bytes, Layout &L)
 {
@@ -1319,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_band_select(Params P, int band0, int ba
     if (i < P.s) {
         ra = reinterpret_cast<const float4 *>(packed)[2 * (size_t)i];      // sx sy rho x
         rb = reinterpret_cast<const float4 *>(packed)[2 * (size_t)i + 1];  // y r g b
-        const Box b = gaussian_box(ra.x, ra.y, ra.w, rb.x, P);             // P.row0/row1 = whole grid here
+        const Box b = gaussian_box(ra.x, ra.y, ra.w, rb.x, P, Geo{P.h, P.w, 0, 0});   // P.row0/row1 = whole grid here
         if (b.cls != 2) {
             go_up = rows_above > 0 && b.r0 < band0;
             go_down = rows_below > 0 && b.r1 >= band1;
@@ -1405,6 +1509,7 @@ int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colo
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, workspace);
     HIP_TRY(hipMemsetAsync(workspace, 0, L.zero_bytes, st));
+    if (int rc = launch_batch_geo(dims, V, st)) return rc;
     const int nblk = classify_blocks(dims);
     hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V);
     const int ncls = L.ncells + 2;
@@ -1504,7 +1609,7 @@ int gsasr_prologue_forward(const float *gs_parameters, const float *step_size, i
     if (n == 0) return GSASR_OK;
     if (!gs_parameters || !step_size || !sigmas || !coords || !colors) return fail(GSASR_ERR_ARG, "null pointer");
     hipLaunchKernelGGL(k_prologue_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       gs_parameters, step_size, n, h, w, sigmas, coords, colors);
+                       gs_parameters, step_size, n, h, w, sigmas, coords, colors, 0, (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }
@@ -1518,7 +1623,7 @@ int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, 
     if (!gs_parameters || !step_size || !g_sigmas || !g_coords || !g_colors || !g_parameters)
         return fail(GSASR_ERR_ARG, "null pointer");
     hipLaunchKernelGGL(k_prologue_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       gs_parameters, step_size, n, h, w, g_sigmas, g_coords, g_colors, g_parameters);
+                       gs_parameters, step_size, n, h, w, g_sigmas, g_coords, g_colors, g_parameters, 0, (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }
@@ -1564,7 +1669,17 @@ int gsasr_step_forward(const float *gs_parameters, const float *step_size, const
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
     char *b = (char *)workspace;
     float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
-    if (int rc = gsasr_prologue_forward(gs_parameters, step_size, dims->s, dims->h, dims->w, sig, xy, col, stream)) return rc;
+    if (dims->batch > 1) {  // per-sample sizes and step sizes (step_size[b]); the geometry must be in place first
+        if (dims->s == 0) return GSASR_OK;
+        if (!gs_parameters || !step_size) return fail(GSASR_ERR_ARG, "null pointer");
+        const PlanView V = make_view(make_layout(dims), workspace);
+        if (int rc = launch_batch_geo(dims, V, (hipStream_t)stream)) return rc;
+        hipLaunchKernelGGL(k_prologue_fwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           gs_parameters, step_size, dims->s, 0, 0, sig, xy, col, dims->s / dims->batch,
+                           (const int4 *)V.geo);
+        HIP_TRY(hipGetLastError());
+    } else if (int rc = gsasr_prologue_forward(gs_parameters, step_size, dims->s, dims->h, dims->w, sig, xy, col, stream))
+        return rc;
     if (int rc = gsasr_splat_plan(sig, xy, col, dims, workspace, S.plan_bytes, stream)) return rc;
     return gsasr_splat_forward(dims, workspace, S.plan_bytes, img, stream);
 }
@@ -1584,6 +1699,16 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
     gsasr_dims d = *dims;
     d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
     if (int rc = gsasr_splat_backward(sig, xy, col, grad_img, gs, gc, gk, &d, workspace, S.plan_bytes, stream)) return rc;
+    if (dims->batch > 1) {
+        if (dims->s == 0) return GSASR_OK;
+        if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
+        const PlanView V = make_view(make_layout(dims), workspace);
+        hipLaunchKernelGGL(k_prologue_bwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           gs_parameters, step_size, dims->s, 0, 0, gs, gc, gk, g_parameters, dims->s / dims->batch,
+                           (const int4 *)V.geo);
+        HIP_TRY(hipGetLastError());
+        return GSASR_OK;
+    }
     return gsasr_prologue_backward(gs_parameters, step_size, dims->s, dims->h, dims->w, gs, gc, gk, g_parameters, stream);
 }
 
@@ -1591,7 +1716,7 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
 int gsasr_band_select(const float *packed, const gsasr_dims *dims, int rows_above, int rows_below, int cap,
                       float *up, float *down, int *up_index, int *down_index, int *counts, void *stream)
 {
-    if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
+    if (!dims_ok(dims) || dims->batch > 1) return fail(GSASR_ERR_ARG, "bad dims (the band exchange does not take a batched canvas)");
     if (cap < 0 || rows_above < 0 || rows_below < 0 || !counts || (cap > 0 && (!up || !down || !up_index || !down_index)) ||
         (dims->s > 0 && !packed))
         return fail(GSASR_ERR_ARG, "gsasr_band_select: null pointer or negative size");
@@ -1630,7 +1755,7 @@ static int render_common(const float *sigmas, const float *coords, const float *
                          const float *grads, float *gs, float *gc, float *gk, int s, int h, int w, int c,
                          float dmax, bool backward, void *stream)
 {
-    gsasr_dims d;
+    gsasr_dims d{};   // (batch fields zero: one image)
     d.s = s; d.h = h; d.w = w; d.c = c; d.dmax = dmax; d.row0 = 0; d.row1 = h; d.cutoff = 0.f; d.flags = 0;
     const size_t bytes = gsasr_splat_workspace_bytes(&d);
     if (!bytes) return GSASR_ERR_ARG;

@@ -247,6 +247,63 @@ def generate_2D_gaussian_splatting_step(sr_size, gs_parameters, scale, scale_mod
     return _sample(final_image, sample_coords)
 
 
+class _FusedBatch(torch.autograd.Function):
+    """A whole training batch in one set of launches: `gs_parameters[B,N,9]` ->
+    `[B,3,Hmax,Wmax]`, sample b rendered on its own `sizes[b]` pixel grid in the top-left corner of its slot
+    and zero elsewhere.  Replaces the reference's per-sample Python loop of `generate_2D_gaussian_splatting_step`
+    + `F.pad` (basicsr/models/gsasr_model.py:191-233): B x (prologue, plan, splat) launches and B autograd nodes
+    become one of each."""
+
+    @staticmethod
+    def forward(ctx, gs_parameters, steps, sizes, dmax):
+        from . import _cabi
+        img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax)
+        ctx.save_for_backward(gs_parameters, steps)
+        ctx.plan = plan
+        ctx.h_max = max(h for h, _ in sizes)
+        return img[:, :, : ctx.h_max]          # the slot is h_max rounded up to whole 16-row tiles
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        from . import _cabi
+        gs_parameters, steps = ctx.saved_tensors
+        d = ctx.plan.dims
+        grad = grad_output.new_zeros(d.batch, d.slot, d.w, 3)      # [B, slot, Wmax, 3]: what the backward sweeps
+        grad[:, : ctx.h_max] = grad_output.permute(0, 2, 3, 1)
+        return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad), None, None, None
+
+
+def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_modifies, default_step_size=1.2,
+                                         mode='scale_modify', if_dmax=True, dmax_mode='fix', dmax=25):
+    """Batched `generate_2D_gaussian_splatting_step` (no `sample_coords`): `gs_parameters` `[B,N,9]`, per-sample
+    `sr_sizes[b]`, `scales[b]`, `scale_modifies[b]`; returns `[B,3,Hmax,Wmax]` with every sample zero-padded to
+    the largest size -- exactly `torch.stack([F.pad(step(...), ...)])` of the reference's loop."""
+    B = gs_parameters.shape[0]
+    sizes = [_hw(s) for s in sr_sizes]
+    if not (len(sizes) == B == len(scales) == len(scale_modifies)):
+        raise ValueError("one sr_size, scale and scale_modify per sample")
+    if gs_parameters.dtype != torch.float32:
+        gs_parameters = gs_parameters.float()
+    uniform_dmax = (not if_dmax) or dmax_mode == 'fix' or len(set(sizes)) == 1
+    if 1 < B <= 64 and gs_parameters.is_cuda and gs_parameters.dim() == 3 and gs_parameters.shape[2] == 9 and uniform_dmax:
+        dev = gs_parameters.device
+        steps = torch.stack([torch.as_tensor(_step_size(scales[b], scale_modifies[b], default_step_size, mode),
+                                             dtype=torch.float32, device=dev).reshape(()) for b in range(B)])
+        dmax_eff = _resolve_dmax(dmax, dmax_mode, sr_sizes[0]) if if_dmax else None
+        return _FusedBatch.apply(gs_parameters.contiguous(), steps, tuple(sizes),
+                                 None if dmax_eff is None else float(dmax_eff))
+    # per-sample path (single sample, > 64 samples, or a per-sample dmax): same kernels, one sample at a time
+    h_max, w_max = max(h for h, _ in sizes), max(w for _, w in sizes)
+    outs = []
+    for b in range(B):
+        o = generate_2D_gaussian_splatting_step(sr_sizes[b], gs_parameters[b], scales[b], scale_modifies[b],
+                                                default_step_size=default_step_size, mode=mode, if_dmax=if_dmax,
+                                                dmax_mode=dmax_mode, dmax=dmax)
+        outs.append(torch.nn.functional.pad(o, (0, w_max - sizes[b][1], 0, h_max - sizes[b][0])))
+    return torch.stack(outs)
+
+
 def generate_2D_gaussian_splatting_step_buffer(sr_size, gs_parameters, scale, scale_modify, sample_coords=None,
                                                default_step_size=1.2, cuda_rendering=True, mode='scale_modify',
                                                if_dmax=True, dmax_mode='fix', dmax=25, buffer_size=4000000):

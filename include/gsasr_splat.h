@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GSASR_SPLAT_ABI_VERSION 1
+#define GSASR_SPLAT_ABI_VERSION 2
 
 enum gsasr_status {
     GSASR_OK = 0,
@@ -68,7 +68,20 @@ typedef struct gsasr_dims {
                      0 -> process default (adaptive, see below); < 0 -> never skip
                      (every in-box term is summed, as the reference does).                */
     unsigned flags;
+    /* Batched canvas (the reference splats a training batch sample by sample,
+     * basicsr/models/gsasr_model.py:191-233).  All three zero = one image.  With batch = B > 1 the s Gaussians
+     * are B samples of s/B each (sample-major) and the "image" is a canvas of B slots stacked vertically:
+     * h = B * slot rows (slot a multiple of 16), w columns, row0 = 0, row1 = h.  Sample b has its OWN pixel grid
+     * of sample_hw[2b] x sample_hw[2b+1] pixels (each <= slot x w; pixel centres 2i/(n-1)-1 of that size, so every
+     * sample is computed exactly as a single-image call would) in the top-left corner of slot b; the rest of
+     * the slot is padding (stored as 0 with GSASR_FLAG_OVERWRITE_IMAGE, like the reference's F.pad).  Image
+     * layouts: [B*slot, w, 3], or with GSASR_FLAG_CHW_IMAGE [B, 3, slot, w].  Not combinable with row bands. */
+    int batch;
+    int slot;
+    const int *sample_hw; /* HOST array [2*batch]: (h_b, w_b) per sample, read during the call */
 } gsasr_dims;
+
+#define GSASR_MAX_BATCH 64
 
 /* Default tau is ADAPTIVE: tau = ln(s / GSASR_SPLAT_DEFAULT_EPS), clamped to [16, 104].  Every skipped
  * term is < exp(-tau) times its colour (<= 1 after the host prologue's sigmoid * alpha), and at most s terms

@@ -663,3 +663,96 @@ def test_band_select_flags_overflow_and_far(dev):
     top.own.copy_(rec)
     top.select()
     assert top.counts[0].item() == 0 and top.counts[1].item() > 0 and top.counts[2].item() == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# batched canvas: a ragged training batch in one set of launches
+# ---------------------------------------------------------------------------------------------------
+def _batch_case(dev, sizes, lr=(12, 10), seed=120):
+    from gsasr_amd import synthetic
+    B = len(sizes)
+    p = torch.stack([synthetic.gs_parameters(lr[0], lr[1], seed=seed + b) for b in range(B)]).to(dev)
+    scales = [h / lr[0] for h, _ in sizes]
+    sms = [torch.tensor([s, s], device=dev) for s in scales]
+    return p, scales, sms
+
+
+@pytest.mark.parametrize("kw", [dict(if_dmax=True, dmax_mode="fix", dmax=0.3), dict(if_dmax=True, dmax_mode="fix", dmax=0.05),
+                                dict(if_dmax=False)], ids=["dmax0.3", "dmax0.05", "unbounded"])
+def test_batched_step_equals_per_sample_steps(kw, dev):
+    """ragged sizes (not multiples of the 16-row slot granularity, different widths): every sample equals its own
+    single-image call, padding is exactly zero, gradients w.r.t. the raw parameters agree"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    sizes = [(48, 40), (36, 52), (61, 33), (48, 40), (20, 64)]
+    p, scales, sms = _batch_case(dev, sizes)
+    hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    pa = p.clone().requires_grad_(True)
+    out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, scales, sms, **kw)
+    assert out.shape == (len(sizes), 3, hm, wm)
+    wgt = torch.rand(len(sizes), 3, hm, wm, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    (out * wgt).sum().backward()
+    pb = p.clone().requires_grad_(True)
+    for b, (h, w) in enumerate(sizes):
+        ref = gsp.generate_2D_gaussian_splatting_step((h, w), pb[b], scales[b], sms[b], **kw)
+        assert float((out[b, :, :h, :w] - ref).detach().abs().max()) <= 2e-6
+        pad = out[b].clone()
+        pad[:, :h, :w] = 0
+        assert float(pad.abs().max()) == 0.0
+        (ref * wgt[b, :, :h, :w]).sum().backward()
+    assert float((pa.grad - pb.grad).abs().max()) <= 1e-5 * float(pb.grad.abs().max())
+
+
+def test_batched_step_against_oracle(dev):
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    from oracle import gs_oracle, host_ref
+    sizes = [(40, 56), (64, 64), (33, 47)]
+    p, scales, sms = _batch_case(dev, sizes, seed=130)
+    pa = p.clone().requires_grad_(True)
+    out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, scales, sms, if_dmax=True, dmax_mode="fix", dmax=0.25)
+    wgts = [synthetic.grad_image(h, w, 140 + b) for b, (h, w) in enumerate(sizes)]
+    loss = sum((out[b, :, :h, :w] * wgts[b].permute(2, 0, 1).to(dev)).sum() for b, (h, w) in enumerate(sizes))
+    loss.backward()
+    for b, (h, w) in enumerate(sizes):
+        pc = p[b].cpu()
+        sig, xy, col, dmax = host_ref.prologue(pc, (h, w), sms[b].cpu(), dmax=0.25, dmax_mode="fix")
+        ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), h, w, dmax)
+        assert np.abs(out[b, :, :h, :w].detach().permute(1, 2, 0).cpu().numpy() - ref).max() <= IMG_ATOL
+        pr = pc.clone().double().requires_grad_(True)
+        s2, x2, c2, _ = host_ref.prologue(pr, (h, w), sms[b].cpu().double(), dmax=0.25, dmax_mode="fix")
+        g = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgts[b].numpy(), dmax)
+        torch.autograd.backward([s2, x2, c2], [torch.from_numpy(a) for a in g])
+        assert _relmax(pa.grad[b].cpu().numpy(), pr.grad.numpy()) <= GRAD_RTOL
+
+
+def test_batched_config5_shape(dev):
+    """BASELINE config 5's rasterizer work: 16 samples of 48x48 LR crops x4, 16 Gaussians per LR pixel, dmax 0.5"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    B, lr, scale = 16, 48, 4.0
+    p = torch.stack([synthetic.gs_parameters(lr, lr, seed=150 + b, gpp=16) for b in range(B)]).to(dev)
+    assert p.shape == (B, 36864, 9)
+    sizes = [(192, 192)] * B
+    sm = [torch.tensor([scale, scale], device=dev)] * B
+    pa = p.clone().requires_grad_(True)
+    out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, [scale] * B, sm, if_dmax=True, dmax_mode="fix", dmax=0.5)
+    out.sum().backward()
+    for b in (0, 7, 15):
+        pb = p[b].clone().requires_grad_(True)
+        ref = gsp.generate_2D_gaussian_splatting_step((192, 192), pb, scale, sm[b], if_dmax=True, dmax_mode="fix", dmax=0.5)
+        assert float((out[b] - ref).abs().max()) <= 2e-5
+        ref.sum().backward()
+        assert float((pa.grad[b] - pb.grad).abs().max()) <= 1e-5 * float(pb.grad.abs().max())
+
+
+def test_batched_dims_are_validated(dev):
+    import ctypes
+    from gsasr_amd import _cabi
+    d = _cabi.make_batch_dims(100, [(20, 30), (16, 16)], 30, 20, 0.1)
+    assert _cabi.lib().gsasr_step_workspace_bytes(ctypes.byref(d)) > 0
+    bad = _cabi.make_batch_dims(100, [(20, 31), (16, 16)], 30, 20, 0.1)       # wider than the canvas
+    assert _cabi.lib().gsasr_step_workspace_bytes(ctypes.byref(bad)) == 0
+    bad = _cabi.make_batch_dims(100, [(20, 30), (16, 16)], 30, 20, 0.1)
+    bad.s = 201                                                                 # not a multiple of the batch
+    assert _cabi.lib().gsasr_step_workspace_bytes(ctypes.byref(bad)) == 0
+    bad = _cabi.make_batch_dims(100, [(20, 30), (16, 16)], 30, 20, 0.1)
+    bad.row0 = 16                                                               # no row bands on a canvas
+    assert _cabi.lib().gsasr_step_workspace_bytes(ctypes.byref(bad)) == 0
