@@ -37,6 +37,9 @@ CONFIGS = {
     "c2": (256, 256, 4.0, "config2: 256x256 LR -> x4 (1024^2 HR), 65536 Gaussians, fwd+bwd"),
     "c3": (512, 512, 12.0, "config3: 512x512 LR -> x12 (6144^2 HR), 262144 Gaussians, fwd only"),
     "c4": (1024, 1024, 8.0, "config4: 1024x1024 LR -> x8 (8192^2 HR), 1048576 Gaussians, fwd+bwd, row-band shard"),
+    # rasterizer work of BASELINE config 5 (the training step): 16 samples of 48x48 LR crops x4, 16 Gaussians per LR
+    # pixel (fea2gs), dmax 0.5, raw decoder parameters in, gradient w.r.t. them out -- ONE batched canvas
+    "c5": (48, 48, 4.0, "config5 rasterizer: batch 16 x (48x48 LR -> x4, 36864 Gaussians), prologue+fwd+bwd, batched canvas"),
 }
 
 
@@ -65,6 +68,10 @@ class Step:
         from gsasr_amd.shard import row_band
         self.cabi, self.dev, self.rank, self.world = _cabi, dev, rank, world
         h_lr, w_lr, scale, _ = CONFIGS[args.config]
+        self.batched = args.config == "c5"
+        if self.batched:
+            self.init_batched(args, dev, h_lr, w_lr, scale)
+            return
         self.strong = args.config == "c4"
         if world > 1 and not self.strong:
             h_lr = h_lr * world      # weak scaling: stack `world` config-sized images vertically
@@ -113,6 +120,46 @@ class Step:
             self.gpad = torch.zeros(per * world, 8, device=dev)
             self.gmine = torch.zeros(per, 8, device=dev)
 
+    def init_batched(self, args, dev, h_lr, w_lr, scale):
+        """config 5: every rank runs its own batch of 16 samples (data parallel over samples: no exchange)"""
+        import ctypes
+        from gsasr_amd import _cabi, synthetic
+        B, gpp = 16, 16
+        self.strong, self.fwd_only, self.dist, self.halo, self.ex = False, args.fwd_only, False, False, None
+        self.dmax = 0.5 if args.dmax == 0.1 else (None if args.dmax < 0 else args.dmax)   # training box unless overridden
+        self.cutoff = args.cutoff
+        H = W = int(h_lr * scale)
+        self.B, self.H, self.W = B, B * H * self.world, W     # H x W reported = all samples' pixels on all ranks
+        self.pix_rank = B * H * W
+        p = torch.stack([synthetic.gs_parameters(h_lr, w_lr, seed=b + 100 * self.rank, gpp=gpp) for b in range(B)])
+        self.p = p.to(dev)
+        self.n = self.n_rank = B * p.shape[1]
+        self.steps = torch.full((B,), 1.2 / scale, device=dev)
+        self.bdims = _cabi.make_batch_dims(p.shape[1], [(H, W)] * B, W, H, self.dmax, cutoff=self.cutoff,
+                                           flags=_cabi.FLAG_OVERWRITE_IMAGE | _cabi.FLAG_CHW_IMAGE)
+        L = _cabi.lib()
+        nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(self.bdims))
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.img = torch.empty(B, 3, self.bdims.slot, W, device=dev)
+        self.grad_img = torch.rand(B, self.bdims.slot, W, 3, device=dev)
+        self.gp = torch.empty_like(self.p)
+        self.rows = (0, self.bdims.h)
+        self.plan = _cabi.Plan(self.bdims, self.ws, dev)
+
+    def batched_forward(self):
+        import ctypes
+        c = self.cabi
+        c.check(c.lib().gsasr_step_forward(self.p.data_ptr(), self.steps.data_ptr(), ctypes.byref(self.bdims),
+                                           self.ws.data_ptr(), self.ws.numel(), self.img.data_ptr(), c._stream(self.dev)),
+                "gsasr_step_forward")
+
+    def batched_backward(self):
+        import ctypes
+        c = self.cabi
+        c.check(c.lib().gsasr_step_backward(self.p.data_ptr(), self.steps.data_ptr(), self.grad_img.data_ptr(),
+                                            self.gp.data_ptr(), ctypes.byref(self.bdims), self.ws.data_ptr(),
+                                            self.ws.numel(), c._stream(self.dev)), "gsasr_step_backward")
+
     # --- the three stages, callable separately for per-kernel timing -------------------------------------
     def do_plan(self):
         import ctypes
@@ -135,6 +182,11 @@ class Step:
         self.cabi.backward(self.plan, self.sig, self.xy, self.col, self.grad_img, *self.g, overwrite=True)
 
     def __call__(self):
+        if self.batched:
+            self.batched_forward()               # prologue + plan + forward of all 16 samples
+            if not self.fwd_only:
+                self.batched_backward()          # splat backward + prologue backward
+            return
         if self.halo:
             self.ex.exchange_forward()          # Gaussians crossing a band edge -> neighbours (P2P)
             self.do_plan()
@@ -332,8 +384,13 @@ def main():
 
     # per-kernel device time, measured live (not part of the timed region)
     kern = {}
-    for name, fn, nbytes in (("plan", step.do_plan, None), ("forward", step.do_forward, step.bytes_fwd()),
-                             ("backward", step.do_backward, step.bytes_bwd())):
+    if step.batched:   # step-level entry points: the forward stage includes the prologue and the plan
+        nb, px = 36 * step.n_rank, 12 * step.pix_rank
+        stages = (("forward", step.batched_forward, nb + px), ("backward", step.batched_backward, 2 * nb + px))
+    else:
+        stages = (("plan", step.do_plan, None), ("forward", step.do_forward, step.bytes_fwd()),
+                  ("backward", step.do_backward, step.bytes_bwd()))
+    for name, fn, nbytes in stages:
         if name == "backward" and step.fwd_only:
             continue
         avg, med = time_stage(fn, 30, dev)
@@ -360,7 +417,7 @@ def main():
         except Exception as e:
             roofline["hbm_copy_GBps_measured"] = None
             print(f"[bench] copy bandwidth probe failed: {e!r}", file=sys.stderr)
-        if not step.halo:
+        if not step.halo and not step.batched:
             tau = step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s)
             in_box, swept = window_pairs(step.sig, step.xy, step.H, step.W, step.dmax, tau, step.rows)
             valu = {"pairs_in_dmax_box": in_box, "pairs_in_swept_window": swept,
@@ -380,15 +437,17 @@ def main():
         h_lr, w_lr, scale, desc = CONFIGS[args.config]
         out = {
             "metric": ("HR Mpixels/sec fwd+bwd (x4, 1 Gaussian/LR px); achieved HBM GB/s vs roofline" if args.config == "c2"
-                       else f"HR Mpixels/sec {'fwd only' if step.fwd_only else 'fwd+bwd'} (x{scale:g}, 1 Gaussian/LR px)"),
+                       else "HR Mpixels/sec prologue+fwd+bwd (x4, 16 Gaussians/LR px, batch 16)" if step.batched else f"HR Mpixels/sec {'fwd only' if step.fwd_only else 'fwd+bwd'} (x{scale:g}, 1 Gaussian/LR px)"),
             "value": mpix, "unit": "HR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if step.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc + (f"; weak-scaled to {step.H}x{step.W} HR / {step.n} Gaussians over {world} row bands"
-                                           if world > 1 and not step.strong else ""),
-                       "H": step.H, "W": step.W, "gaussians": step.n, "dmax": args.dmax,
+                                           if world > 1 and not step.strong and not step.batched else ""),
+                       "H": step.H, "W": step.W, "gaussians": step.n, "dmax": step.dmax if step.dmax is not None else -1,
                        "cutoff_tau": round(step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 3),
-                       "launch": launch, "parallelism": f"row-band x{world}" if world > 1 else "single"},
+                       "launch": launch,
+                       "parallelism": (f"data-parallel x{world} (one batch per rank, no exchange)" if step.batched and world > 1
+                                       else f"row-band x{world}" if world > 1 else "single")},
             "roofline": roofline, "kernels": kern,
         }
         if step.dist:
