@@ -108,7 +108,17 @@ class Step:
             self.ex.own.copy_(mine)
             self.n_rank = n_local
             self.plan = _cabi.plan_packed(self.ex.records, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
-            return
+            try:    # one trial swap each way before anything is timed: a transport that cannot do grouped
+                    # send/recv shows up here, on every rank alike, and the collective pattern takes over
+                self.ex.exchange_forward()
+                self.ex.exchange_backward()
+                torch.cuda.synchronize(dev)
+                return
+            except Exception as e:
+                print(f"[bench] rank {rank}: halo exchange unavailable ({e!r}); using broadcast + reduce_scatter",
+                      file=sys.stderr)
+                self.halo, self.ex = False, None
+                self.n_rank = self.n
         self.sig, self.xy, self.col = (t.to(dev) for t in (sig, xy, col))
         self.g = [torch.zeros_like(t) for t in (self.sig, self.xy, self.col)]
         self.plan = _cabi.plan(self.sig, self.xy, self.col, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
@@ -453,7 +463,7 @@ def main():
         if step.dist:
             out["config"]["exchange"] = ("halo swap with ranks g-1/g+1 (send/recv), "
                                          f"{step.halo_records} records max per edge, capacity {step.ex.cap}"
-                                         if step.halo else "broadcast + reduce_scatter")
+                                         if step.halo else "broadcast of all Gaussians + reduce_scatter of their gradients")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
