@@ -215,8 +215,15 @@ def _resolve_dmax(dmax, dmax_mode, sr_size):
 
 
 def _sample(final_image, sample_coords):
+    """reference :214-216: `stack([img[:, c[0], c[1]] for c in sample_coords], dim=1)` -> `[3, S]`.  An `[S,2]`
+    integer tensor (what the datasets produce, continuous_bicubic_downsample_dataset.py:87-88) is gathered with
+    ONE indexing op instead of S of them (same values, same gradient scatter); anything else takes the loop."""
     if sample_coords is None:
         return final_image
+    if torch.is_tensor(sample_coords) and sample_coords.dim() == 2 and sample_coords.shape[1] == 2 \
+            and not sample_coords.dtype.is_floating_point and sample_coords.dtype != torch.bool:
+        sc = sample_coords.to(device=final_image.device, dtype=torch.long)
+        return final_image[:, sc[:, 0], sc[:, 1]]
     return torch.stack([final_image[:, c[0], c[1]] for c in sample_coords], dim=1)
 
 

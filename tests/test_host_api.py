@@ -62,6 +62,15 @@ def test_sample_coords_gather():
                                                   torch.tensor([sc, sc]), sample_coords=pts, cuda_rendering=False)
     assert out.shape == (3, 3)
     np.testing.assert_allclose(out[:, 1].numpy(), z["out"][:, 3, 7], rtol=1e-4, atol=2e-5)
+    # the datasets hand an [S,2] integer tensor (continuous_bicubic_downsample_dataset.py:87-88): one gather,
+    # same values and the same gradient scatter (repeated coordinates accumulate) as the reference's loop
+    img = torch.rand(3, 20, 30, requires_grad=True)
+    pts_t = torch.stack([torch.randint(0, 20, (50,)), torch.randint(0, 30, (50,))], dim=1)
+    pts_t[5] = pts_t[3]
+    a = gsp._sample(img, pts_t)
+    b = torch.stack([img[:, c[0], c[1]] for c in pts_t], dim=1)
+    assert torch.equal(a, b)
+    assert torch.equal(torch.autograd.grad(a.sum(), img)[0], torch.autograd.grad(b.sum(), img)[0])
 
 
 def test_cabi_exports_every_declared_symbol():
