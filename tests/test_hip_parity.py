@@ -695,7 +695,7 @@ def test_batched_step_equals_per_sample_steps(kw, dev):
     for b, (h, w) in enumerate(sizes):
         ref = gsp.generate_2D_gaussian_splatting_step((h, w), pb[b], scales[b], sms[b], **kw)
         assert float((out[b, :, :h, :w] - ref).detach().abs().max()) <= 2e-6
-        pad = out[b].clone()
+        pad = out[b].detach().clone()
         pad[:, :h, :w] = 0
         assert float(pad.abs().max()) == 0.0
         (ref * wgt[b, :, :h, :w]).sum().backward()
@@ -756,3 +756,43 @@ def test_batched_dims_are_validated(dev):
     bad = _cabi.make_batch_dims(100, [(20, 30), (16, 16)], 30, 20, 0.1)
     bad.row0 = 16                                                               # no row bands on a canvas
     assert _cabi.lib().gsasr_step_workspace_bytes(ctypes.byref(bad)) == 0
+
+
+def test_batched_canvas_through_plan_api_hwc_accumulate(dev):
+    """the same canvas through gsasr_splat_plan/forward/backward with kernel-frame inputs: HWC layout, accumulate
+    contracts (image += , gradients +=), padding left untouched"""
+    import ctypes
+    from gsasr_amd import _cabi, synthetic
+    sizes = [(40, 48), (57, 30), (16, 64)]
+    B, lr, dmax = len(sizes), (10, 12), 0.2
+    per = [synthetic.kernel_inputs(lr[0], lr[1], sizes[b][0] / lr[0], seed=160 + b, device=dev)[:3] for b in range(B)]
+    # (kernel_inputs scales sigmas for a square-ish grid; any finite inputs do: the check is against single calls)
+    sig, xy, col = (torch.cat([p[k] for p in per]).contiguous() for k in range(3))
+    n = per[0][0].shape[0]
+    hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    d = _cabi.make_batch_dims(n, sizes, wm, hm, dmax)
+    L = _cabi.lib()
+    ws = torch.empty(L.gsasr_splat_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    st = _cabi._stream(dev)
+    _cabi.check(L.gsasr_splat_plan(sig.data_ptr(), xy.data_ptr(), col.data_ptr(), ctypes.byref(d), ws.data_ptr(), ws.numel(), st), "plan")
+    img = torch.full((B * d.slot, wm, 3), 0.25, device=dev)
+    _cabi.check(L.gsasr_splat_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), img.data_ptr(), st), "fwd")
+    grad = torch.rand(B * d.slot, wm, 3, device=dev)
+    g = [torch.ones_like(t) for t in (sig, xy, col)]
+    _cabi.check(L.gsasr_splat_backward(sig.data_ptr(), xy.data_ptr(), col.data_ptr(), grad.data_ptr(), g[0].data_ptr(),
+                                       g[1].data_ptr(), g[2].data_ptr(), ctypes.byref(d), ws.data_ptr(), ws.numel(), st), "bwd")
+    img = img.view(B, d.slot, wm, 3)
+    grad = grad.view(B, d.slot, wm, 3)
+    for b, (h, w) in enumerate(sizes):
+        s1, x1, c1 = per[b]
+        plan = _cabi.plan(s1, x1, c1, h, w, dmax)
+        ref = _cabi.forward(plan, torch.full((h, w, 3), 0.25, device=dev))
+        assert float((img[b, :h, :w] - ref).abs().max()) <= 2e-6
+        rest = img[b].clone()
+        rest[:h, :w] = 0.25
+        assert float((rest - 0.25).abs().max()) == 0.0               # padding never touched in accumulate mode
+        g1 = [torch.ones_like(t) for t in (s1, x1, c1)]
+        _cabi.backward(plan, s1, x1, c1, grad[b, :h, :w].contiguous(), *g1)
+        for got, want in zip(g, g1):
+            got_b = got[b * n:(b + 1) * n]
+            assert float((got_b - want).abs().max()) <= 1e-5 * float(want.abs().max())
