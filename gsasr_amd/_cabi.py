@@ -14,7 +14,8 @@ from typing import Optional, Tuple
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libgsasr_splat.so")
+# (GSASR_SPLAT_LIB: development override, e.g. to A/B two builds of the library on the same GPU box)
+LIB_PATH = os.environ.get("GSASR_SPLAT_LIB") or os.path.join(_PKG, "lib", "libgsasr_splat.so")
 
 EXPORTS = (
     "gsasr_abi_version", "gsasr_last_error", "gsasr_splat_workspace_bytes", "gsasr_splat_plan",

@@ -54,7 +54,7 @@ constexpr int SUBY = 16;
 constexpr int SUBX_SHIFT = 3, SUBY_SHIFT = 4;
 constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is binned as "large"
 #ifndef BWD_WAVES_N
-#define BWD_WAVES_N 4
+#define BWD_WAVES_N 2
 #endif
 constexpr int BWD_WAVES = BWD_WAVES_N;  // waves (= consecutive cell-ordered Gaussians) per backward workgroup
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
