@@ -53,6 +53,10 @@ constexpr int SUBX = 8;         // forward sub-tile: 8 px wide x 16 px tall per 
 constexpr int SUBY = 16;
 constexpr int SUBX_SHIFT = 3, SUBY_SHIFT = 4;
 constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is binned as "large"
+#ifndef FWD_WAVES_N
+#define FWD_WAVES_N 4
+#endif
+constexpr int FWD_WAVES = FWD_WAVES_N;  // sub-tiles side by side per forward workgroup
 #ifndef BWD_WAVES_N
 #define BWD_WAVES_N 2
 #endif
@@ -901,7 +905,7 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nb)
 
 // Large images: a workgroup = four sub-tiles side by side (32x16 px), one wave each.
 template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float *__restrict__ img, int tiles_x,
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_render_fwd(Params P, PlanView V, float *__restrict__ img, int tiles_x,
                                                     int tiles_y)
 {
     const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -909,8 +913,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params P, PlanView V, float 
     (void)tiles_y;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id is uniform: keep it in an SGPR
-    const int sx0 = (bx * 4 + wv) * SUBX, sy0 = P.row0 + by * SUBY;
-    __shared__ float4 s_stage[4][128];  // per wave: up to 64 hit records of 32 B
+    const int sx0 = (bx * FWD_WAVES + wv) * SUBX, sy0 = P.row0 + by * SUBY;
+    __shared__ float4 s_stage[FWD_WAVES][128];  // per wave: up to 64 hit records of 32 B
     if (sx0 >= P.w) return;  // wave-uniform
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
     fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, 0u, 1u, s_stage[wv], ar, ag, ab);
@@ -1545,7 +1549,7 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, const_cast<void *>(workspace));
     const int subs_x = (dims->w + SUBX - 1) / SUBX, tiles_y = (rows + SUBY - 1) / SUBY;
-    const int tiles_x = (subs_x + 3) / 4;
+    const int tiles_x = (subs_x + FWD_WAVES - 1) / FWD_WAVES;
     hipStream_t st = (hipStream_t)stream;
     const long nsub = (long)subs_x * tiles_y;
     if (nsub < 4096) {
@@ -1559,7 +1563,7 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         else
             hipLaunchKernelGGL(k_render_fwd_split<false>, grid, block, 0, st, P, V, img, subs_x);
     } else {
-        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(256);
+        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(64 * FWD_WAVES);
         if (P.bounded)
             hipLaunchKernelGGL(k_render_fwd<true>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
         else
