@@ -529,7 +529,7 @@ def test_config4_row_band_shard_properties(dev):
         assert float((t_a + t_b - t_all).abs().max()) <= 2e-4 * float(t_all.abs().max())
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSASR_FUZZ_SEEDS", "12"))))   # more seeds: set the variable
 def test_fuzz_extreme_parameters(seed, dev):
     """random sizes and parameter ranges far outside what the decoder emits: sigma over five decades, |rho| up to
     0.9995, centres far off the image, dmax from sub-pixel to larger than the image, all three cutoff modes"""
@@ -557,7 +557,8 @@ def test_fuzz_extreme_parameters(seed, dev):
         # magnitude, and never demand more than twice the accuracy the reference arithmetic itself achieves
         tol = (5e-4 * np.abs(want).max(axis=1, keepdims=True) + 2.0 * np.abs(r32 - want) + 1e-5 * np.abs(want).max() + 1e-6)
         err = np.abs(got - want)
-        assert err.max() <= GRAD_RTOL * np.abs(want).max(), name                 # the parity bar (tensor level)
+        # the parity bar (tensor level); the floor covers cases whose whole gradient underflows fp32 (|g| < 1e-30)
+        assert err.max() <= GRAD_RTOL * np.abs(want).max() + 1e-30, name
         well = (1.0 - sig[:, 2].astype(np.float64) ** 2) >= 0.02                 # |rho| <= 0.99: fp32-well-conditioned
         bad = (err > tol) & well[:, None]
         assert not bad.any(), (name, int(np.argwhere(bad)[0][0]), float(err[bad].max()), float(np.abs(want).max()),
