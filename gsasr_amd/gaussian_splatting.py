@@ -281,6 +281,25 @@ class _FusedBatch(torch.autograd.Function):
         return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad), None, None, None
 
 
+def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
+    """`[B]` float32 device tensor of `_step_size(...)` per sample with ONE stack / division / check for the batch
+    (the per-sample form costs a kernel and, through the reference's `assert scale_modify[0] == scale_modify[1]`,
+    a host synchronisation per sample)."""
+    def col(vals):
+        if all(torch.is_tensor(v) for v in vals):
+            return torch.stack([v.reshape(()) for v in vals]).to(device=dev, dtype=torch.float32)
+        return torch.tensor([float(v) for v in vals], dtype=torch.float32, device=dev)
+    if mode == 'scale':
+        final = col(list(scales))
+    elif mode == 'scale_modify':
+        a, b = col([sm[0] for sm in scale_modifies]), col([sm[1] for sm in scale_modifies])
+        assert bool((a == b).all()), f"scale_modify is not the same-{scale_modifies}"
+        final = a
+    else:
+        raise UnboundLocalError(f"mode-{mode} must be scale or scale_modify")
+    return default_step_size / final
+
+
 def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_modifies, default_step_size=1.2,
                                          mode='scale_modify', if_dmax=True, dmax_mode='fix', dmax=25):
     """Batched `generate_2D_gaussian_splatting_step` (no `sample_coords`): `gs_parameters` `[B,N,9]`, per-sample
@@ -295,8 +314,7 @@ def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_
     uniform_dmax = (not if_dmax) or dmax_mode == 'fix' or len(set(sizes)) == 1
     if 1 < B <= 64 and gs_parameters.is_cuda and gs_parameters.dim() == 3 and gs_parameters.shape[2] == 9 and uniform_dmax:
         dev = gs_parameters.device
-        steps = torch.stack([torch.as_tensor(_step_size(scales[b], scale_modifies[b], default_step_size, mode),
-                                             dtype=torch.float32, device=dev).reshape(()) for b in range(B)])
+        steps = _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev)
         dmax_eff = _resolve_dmax(dmax, dmax_mode, sr_sizes[0]) if if_dmax else None
         return _FusedBatch.apply(gs_parameters.contiguous(), steps, tuple(sizes),
                                  None if dmax_eff is None else float(dmax_eff))
