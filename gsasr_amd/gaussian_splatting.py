@@ -22,6 +22,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from ._amp import fp32_boundary_bwd, fp32_boundary_fwd
+
 
 def _hw(sr_size):
     # sr_size arrives as list, CPU tensor or GPU int tensor (gsasr_model.py:148,202); make ints once
@@ -45,6 +47,7 @@ class _Splat(torch.autograd.Function):
     12 B/px read less.  Used only where this module itself owns the image (the non-chunked renderers)."""
 
     @staticmethod
+    @fp32_boundary_fwd
     def forward(ctx, sigmas, coords, colors, H, W, dmax):
         from . import _cabi
         plan = _cabi.plan(sigmas, coords, colors, H, W, dmax)
@@ -56,6 +59,7 @@ class _Splat(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @fp32_boundary_bwd
     def backward(ctx, grad_output):
         from . import _cabi
         sigmas, coords, colors = ctx.saved_tensors
@@ -72,6 +76,7 @@ class _FusedStep(torch.autograd.Function):
     and ~30 in backward; numerically the same expressions evaluated in fp32."""
 
     @staticmethod
+    @fp32_boundary_fwd
     def forward(ctx, gs_parameters, step, H, W, dmax):
         from . import _cabi
         img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax)   # one C call: prologue + plan + splat
@@ -81,6 +86,7 @@ class _FusedStep(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @fp32_boundary_bwd
     def backward(ctx, grad_output):
         from . import _cabi
         gs_parameters, step = ctx.saved_tensors
@@ -262,6 +268,7 @@ class _FusedBatch(torch.autograd.Function):
     become one of each."""
 
     @staticmethod
+    @fp32_boundary_fwd
     def forward(ctx, gs_parameters, steps, sizes, dmax):
         from . import _cabi
         img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax)
@@ -272,6 +279,7 @@ class _FusedBatch(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @fp32_boundary_bwd
     def backward(ctx, grad_output):
         from . import _cabi
         gs_parameters, steps = ctx.saved_tensors

@@ -11,6 +11,8 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from .._amp import fp32_boundary_bwd, fp32_boundary_fwd
+
 from .. import _cabi
 
 
@@ -18,6 +20,7 @@ class GSCUDA(Function):
     """reference: utils/gs_cuda/gswrapper.py:19-39"""
 
     @staticmethod
+    @fp32_boundary_fwd
     def forward(ctx, sigmas, coords, colors, rendered_img):
         ctx.save_for_backward(sigmas, coords, colors)
         h, w, c = rendered_img.shape
@@ -30,9 +33,10 @@ class GSCUDA(Function):
 
     @staticmethod
     @once_differentiable
+    @fp32_boundary_bwd
     def backward(ctx, grad_output):
         sigmas, coords, colors = ctx.saved_tensors
-        # (the reference zero-fills three tensors and lets the kernel add into them; the finalize kernel
+        # (the reference zero-fills three tensors and lets the kernel add into them; the backward
         # stores instead, which saves three memsets per step)
         grads_sigmas = torch.empty_like(sigmas)
         grads_coords = torch.empty_like(coords)

@@ -7,6 +7,8 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from .._amp import fp32_boundary_bwd, fp32_boundary_fwd
+
 from .. import _cabi
 
 
@@ -14,6 +16,7 @@ class GSCUDA(Function):
     """reference: utils/gs_cuda_dmax/gswrapper.py:22-44"""
 
     @staticmethod
+    @fp32_boundary_fwd
     def forward(ctx, sigmas, coords, colors, rendered_img, dmax):
         ctx.save_for_backward(sigmas, coords, colors)
         ctx.dmax = dmax
@@ -27,9 +30,10 @@ class GSCUDA(Function):
 
     @staticmethod
     @once_differentiable
+    @fp32_boundary_bwd
     def backward(ctx, grad_output):
         sigmas, coords, colors = ctx.saved_tensors
-        # (the reference zero-fills three tensors and lets the kernel add into them; the finalize kernel
+        # (the reference zero-fills three tensors and lets the kernel add into them; the backward
         # stores instead, which saves three memsets per step)
         grads_sigmas = torch.empty_like(sigmas)
         grads_coords = torch.empty_like(coords)

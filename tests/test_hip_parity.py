@@ -739,7 +739,7 @@ def test_batched_config5_shape(dev):
     for b in (0, 7, 15):
         pb = p[b].clone().requires_grad_(True)
         ref = gsp.generate_2D_gaussian_splatting_step((192, 192), pb, scale, sm[b], if_dmax=True, dmax_mode="fix", dmax=0.5)
-        assert float((out[b] - ref).abs().max()) <= 2e-5
+        assert float((out[b] - ref).detach().abs().max()) <= 2e-5
         ref.sum().backward()
         assert float((pa.grad[b] - pb.grad).abs().max()) <= 1e-5 * float(pb.grad.abs().max())
 
@@ -797,3 +797,25 @@ def test_batched_canvas_through_plan_api_hwc_accumulate(dev):
         for got, want in zip(g, g1):
             got_b = got[b * n:(b + 1) * n]
             assert float((got_b - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_autocast_boundary_runs_the_op_in_fp32(dev):
+    """row f4: under torch.autocast (GSASR's AMP configs) bf16 inputs are cast to fp32 at the Function boundary and
+    the result equals the plain fp32 call; gradients come back in the inputs' dtype"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA
+    sig, xy, col, H, W = synthetic.kernel_inputs(16, 16, 4.0, seed=190, device=dev)
+    ref = GSCUDA.apply(sig, xy, col, torch.zeros(H, W, 3, device=dev), 0.2)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = GSCUDA.apply(sig, xy, col, torch.zeros(H, W, 3, device=dev), 0.2)
+        assert out.dtype == torch.float32 and float((out - ref).abs().max()) <= 2e-6   # (summation order varies run to run)
+        cb = col.bfloat16().requires_grad_(True)                        # a bf16 producer upstream
+        out_b = GSCUDA.apply(sig, xy, cb, torch.zeros(H, W, 3, device=dev), 0.2)
+        want = GSCUDA.apply(sig, xy, cb.detach().float(), torch.zeros(H, W, 3, device=dev), 0.2)
+        assert float((out_b - want).detach().abs().max()) <= 2e-6
+        out_b.sum().backward()
+        assert cb.grad is not None and cb.grad.dtype == torch.bfloat16 and bool(torch.isfinite(cb.grad).all())
+        p = synthetic.gs_parameters(16, 16, seed=191).to(dev)
+        a = gsp.generate_2D_gaussian_splatting_step((H, W), p.bfloat16(), 4.0, torch.tensor([4.0, 4.0], device=dev))
+        b = gsp.generate_2D_gaussian_splatting_step((H, W), p.bfloat16().float(), 4.0, torch.tensor([4.0, 4.0], device=dev))
+        assert a.dtype == torch.float32 and float((a - b).abs().max()) <= 2e-6
