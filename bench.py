@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dmax", type=float, default=0.1, help="box half-size; <0 = unbounded gs_cuda op")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--cutoff", type=float, default=0.0, help="support cutoff tau (0 = library default 32)")
+    ap.add_argument("--cutoff", type=float, default=0.0, help="support cutoff tau (0 = library default: adaptive ln(N/1e-5))")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true")

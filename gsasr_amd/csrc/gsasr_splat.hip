@@ -33,6 +33,10 @@
 //                        chunk writes the gradient.
 //   prologue k_prologue_fwd/bwd  the reference's host prologue (activations + kernel frame) and its
 //                        chain rule as one kernel each.
+//   shard    k_band_select/merge  multi-GPU row bands: the Gaussians whose window crosses a band edge go to the
+//                        neighbouring rank and their partial gradients come back.
+//   batch    a batched canvas (gsasr_dims.batch > 1, row f2) runs B samples of different sizes through the same
+//                        kernels: per-sample geometry (Geo) instead of the image's.
 //
 // No MFMA: this is gather/scatter-accumulate with one transcendental per pair, not a contraction.
 #include <hip/hip_runtime.h>
