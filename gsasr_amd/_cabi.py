@@ -30,7 +30,6 @@ FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
 FLAG_OVERWRITE_GRADS = 4   # GSASR_FLAG_OVERWRITE_GRADS
 FLAG_CHW_IMAGE = 8         # GSASR_FLAG_CHW_IMAGE
 FLAG_STRIDE8 = 16          # GSASR_FLAG_STRIDE8
-FLAG_CHW_GRAD = 32         # GSASR_FLAG_CHW_GRAD
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -186,17 +185,14 @@ def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = Fal
     return img
 
 
-def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors, overwrite: bool = False,
-             chw: bool = False) -> None:
-    """g_* += gradients (reference contract: caller zero-fills), or g_* = gradients when `overwrite`.
-    `chw`: grad_img is planar `[3, rows, w]` instead of `[rows, w, 3]`."""
-    rows = p.dims.row1 - p.dims.row0
+def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors, overwrite: bool = False) -> None:
+    """g_* += gradients (reference contract: caller zero-fills), or g_* = gradients when `overwrite`."""
     ptrs = [_chk(sigmas, "sigmas", (3,)), _chk(coords, "coords", (2,)), _chk(colors, "colors", (3,)),
-            _chk(grad_img, "grads", (3, rows, p.dims.w) if chw else (p.dims.w, 3)), _chk(g_sigmas, "grads_sigmas", (3,)),
+            _chk(grad_img, "grads", (p.dims.w, 3)), _chk(g_sigmas, "grads_sigmas", (3,)),
             _chk(g_coords, "grads_coords", (2,)), _chk(g_colors, "grads_colors", (3,))]
-    if not chw and grad_img.shape[0] != rows:
+    if grad_img.shape[0] != p.dims.row1 - p.dims.row0:
         raise RuntimeError("grads does not match the plan's row band")
-    d = _dims_with(p, (FLAG_OVERWRITE_GRADS if overwrite else 0) | (FLAG_CHW_GRAD if chw else 0))
+    d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
     with torch.cuda.device(p.device):
         check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
@@ -324,17 +320,14 @@ def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int
     return img, Plan(d, ws, dev)
 
 
-def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad: torch.Tensor,
-                  chw: bool = False) -> torch.Tensor:
-    """splat backward + prologue backward in ONE call; `grad` is `[h,w,3]`, or planar `[3,h,w]` with `chw` (what
-    autograd hands back for the planar output: no permute pass); returns d/d gs_parameters `[N,9]`."""
+def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad_hwc: torch.Tensor) -> torch.Tensor:
+    """splat backward + prologue backward in ONE call; `grad_hwc` is `[h,w,3]`; returns d/d gs_parameters `[N,9]`."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(step, "step_size")
-    pg = _chk(grad, "grads", (3, p.dims.h, p.dims.w) if chw else (p.dims.h, p.dims.w, 3))
-    d = _dims_with(p, FLAG_CHW_GRAD if chw else 0)
+    pg = _chk(grad_hwc, "grads", (p.dims.h, p.dims.w, 3))
     with torch.cuda.device(p.device):
         gp = torch.empty_like(gs_parameters)
-        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(d), p.workspace.data_ptr(),
+        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
                                         p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
     return gp
 
@@ -383,16 +376,14 @@ def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax:
     return img, Plan(d, ws, dev)
 
 
-def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, grad: torch.Tensor,
-                   chw: bool = False) -> torch.Tensor:
-    """`grad` is `[B, slot, w_max, 3]`, or planar `[B, 3, slot, w_max]` with `chw`; returns d/d gs_parameters `[B,N,9]`."""
+def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, grad_bhwc: torch.Tensor) -> torch.Tensor:
+    """`grad_bhwc` is `[B, slot, w_max, 3]`; returns d/d gs_parameters `[B,N,9]`."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(steps, "step_sizes")
-    pg = _chk(grad, "grads", (p.dims.batch, 3, p.dims.slot, p.dims.w) if chw else (p.dims.batch, p.dims.slot, p.dims.w, 3))
-    d = _dims_with(p, FLAG_CHW_GRAD if chw else 0)
+    pg = _chk(grad_bhwc, "grads", (p.dims.batch, p.dims.slot, p.dims.w, 3))
     with torch.cuda.device(p.device):
         gp = torch.empty_like(gs_parameters)
-        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(d), p.workspace.data_ptr(),
+        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
                                         p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
     return gp
 

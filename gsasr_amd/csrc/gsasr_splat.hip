@@ -982,23 +982,11 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 // Two 12-byte pixels through a raw buffer resource: address = base(SGPR x4) + per-lane byte offset (VGPR,
 // constant over the sweep) + running row offset (SGPR, advanced by the scalar unit), so a trip spends no
 // VALU instruction on addressing, and reads past the end of the slab return 0 instead of faulting.
-// CHW: the gradient image is planar ([3, rows, w], what autograd hands back for a planar output): three dword loads
-// per pixel, `plane` bytes apart, instead of one 12-byte load -- no permute pass in front of the backward.
-template <bool CHW>
-__device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff_a, int soff_b, int plane)
+__device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff_a, int soff_b)
 {
-    Grad6 g;
-    if (CHW) {
-        g.a0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff_a, 0));
-        g.a1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff_a + plane, 0));
-        g.a2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff_a + 2 * plane, 0));
-        g.b0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff_b, 0));
-        g.b1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff_b + plane, 0));
-        g.b2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff_b + 2 * plane, 0));
-        return g;
-    }
     const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
     const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_b, 0);
+    Grad6 g;
     g.a0 = __uint_as_float(a.x); g.a1 = __uint_as_float(a.y); g.a2 = __uint_as_float(a.z);
     g.b0 = __uint_as_float(b.x); g.b1 = __uint_as_float(b.y); g.b2 = __uint_as_float(b.z);
     return g;
@@ -1030,18 +1018,17 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     R.k12 += (v2f){g.b1, g.b2} * v.y;
 }
 
-template <bool TEST, int LXLOG, bool UNROLL, bool CHW>
+template <bool TEST, int LXLOG, bool UNROLL>
 __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int lane, const Params &P,
                                           const float *__restrict__ pxt, const float *__restrict__ pyt,
                                           const float *__restrict__ grad, float x, float y, float cr, float cg,
                                           float cb, float cinv, float rho, float kappa, float isx, float isy,
-                                          float *spy, float (&acc)[8], size_t gend, int plane)
+                                          float *spy, float (&acc)[8])
 {
     constexpr int LX = 1 << LXLOG, RPI = 64 >> LXLOG;
     constexpr float HALF_LOG2E = 0.72134752044448170368f;
     const int col = lane & (LX - 1), rsub = lane >> LXLOG;
-    // `grad` points at canvas row P.row0 of the first (or only) colour plane; `gend` floats follow it in the tensor
-    const size_t rowpitch = (size_t)P.w * (CHW ? 1 : 3);
+    const size_t rowpitch = (size_t)P.w * 3;
     const float nK1 = -HALF_LOG2E * cinv;
     // issued together with the px load below: one round trip for both tables instead of two dependent ones
     const float py_first = pyt[min(r0 + lane, r1)];
@@ -1056,7 +1043,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
         const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;
         BwdRow R;
         R.m0 = R.m1 = R.m2 = R.k01 = R.k20 = R.k12 = (v2f){0.f, 0.f};
-        const int voff = (int)(((size_t)X * (CHW ? 1 : 3) + (size_t)rsub * rowpitch) * sizeof(float));
+        const int voff = (int)(((size_t)X * 3 + (size_t)rsub * rowpitch) * sizeof(float));
         const int halfb = (int)((size_t)RPI * rowpitch * sizeof(float));
         for (int rb = r0; rb <= r1; rb += 64) {
             const int rend = min(r1, rb + 63);
@@ -1070,7 +1057,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             const float *sp = spy + rsub;
             // buffer resource over the slab from row `rb` on (offsets stay far below 2^31 within a 64-row block)
             const float *blk = grad + (size_t)(rb - P.row0) * rowpitch;
-            const size_t left = (gend - (size_t)(rb - P.row0) * rowpitch) * sizeof(float);
+            const size_t left = (size_t)(P.row1 - rb) * rowpitch * sizeof(float);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
             int soff = 0;
@@ -1083,8 +1070,8 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             // for windows of many trips (x8 and up); costs 18 VGPRs = two waves per SIMD, which small windows
             // (x4, 6 trips) need more: the host picks the instantiation (gsasr_splat_backward).
             for (; UNROLL && Yb + 4 * RPI - 1 <= rend; Yb += 4 * RPI, soff += 4 * halfb, sp += 4 * RPI) {
-                const Grad6 g0 = bwd_load<CHW>(rsrc, voff, soff, soff + halfb, plane);
-                const Grad6 g1 = bwd_load<CHW>(rsrc, voff, soff + 2 * halfb, soff + 3 * halfb, plane);
+                const Grad6 g0 = bwd_load(rsrc, voff, soff, soff + halfb);
+                const Grad6 g1 = bwd_load(rsrc, voff, soff + 2 * halfb, soff + 3 * halfb);
                 const v2f n0 = {sp[0], sp[RPI]}, n1 = {sp[2 * RPI], sp[3 * RPI]};
                 const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0, w1 = TEST ? (v2f){sp[64 + 2 * RPI], sp[64 + 3 * RPI]} : n1;
                 bwd_trip<TEST, false>(R, g0, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
@@ -1093,7 +1080,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, soff += 2 * halfb, sp += 2 * RPI) {
                 const v2f n0 = {sp[0], sp[RPI]};
                 const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0;
-                bwd_trip<TEST, false>(R, bwd_load<CHW>(rsrc, voff, soff, soff + halfb, plane), n0, w0, true, true, K0, nK1, rho_u, cr,
+                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, soff, soff + halfb), n0, w0, true, true, K0, nK1, rho_u, cr,
                                       cg, cb, P.dmax);
             }
             if (Yb <= rend) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
@@ -1101,7 +1088,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 const int ia = min(Ya, rend) - rb, ic = min(Yc, rend) - rb;
                 const v2f n0 = {spy[ia], spy[ic]};
                 const v2f w0 = TEST ? (v2f){spy[64 + ia], spy[64 + ic]} : n0;
-                bwd_trip<TEST, true>(R, bwd_load<CHW>(rsrc, voff, soff, soff + halfb, plane), n0, w0, Ya <= rend, Yc <= rend, K0, nK1,
+                bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, soff, soff + halfb), n0, w0, Ya <= rend, Yc <= rend, K0, nK1,
                                      rho_u, cr, cg, cb, P.dmax);
             }
             }
@@ -1218,7 +1205,7 @@ __device__ __forceinline__ void bwd_fetch_first(const PlanView &V, const unsigne
                  : "memory");
 }
 
-template <bool BOUNDED, bool UNROLL, bool CHW>
+template <bool BOUNDED, bool UNROLL>
 __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk, bool atomic, int lane, const Params &P,
                                          const PlanView &V, const float *__restrict__ grad, float *spy, float *red,
                                          float *__restrict__ g_sigmas, float *__restrict__ g_coords,
@@ -1260,16 +1247,10 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
         else if (r0 - pad >= lo) r0 -= pad;
     }
     const bool test = BOUNDED && (bb.x & 0x8000u);
-    // Where this Gaussian's gradient rows live.  HWC [rows, w, 3] is the canvas itself.  Planar is [3, rows, w], and
-    // for a batched canvas [B, 3, slot, w]: sample b's first plane starts 2*b*slot rows below its canvas rows.
-    const size_t gshift = CHW && P.batch > 1 ? (size_t)2 * G.fin[6] * P.slot * P.w : 0;
-    const float *gbase = grad + gshift;
-    const size_t gend = (size_t)(P.row1 - P.row0) * P.w * 3 - gshift;          // floats from gbase to the tensor's end
-    const int plane = (P.batch > 1 ? P.slot : P.row1 - P.row0) * P.w * 4;      // bytes between colour planes
     float d = 0.f;
     if (!empty) {
 #define GSASR_SWEEP(T, L) \
-    bwd_sweep<T, L, UNROLL, CHW>(c0, bw, r0, r1, lane, P, V.px + G.fin[5], V.py, gbase, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a, gend, plane)
+    bwd_sweep<T, L, UNROLL>(c0, bw, r0, r1, lane, P, V.px + G.fin[5], V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
         if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
         else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
         else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
@@ -1294,7 +1275,7 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
     bwd_write(d, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
 }
 
-template <bool BOUNDED, bool UNROLL, bool CHW>
+template <bool BOUNDED, bool UNROLL>
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
                                                     float *__restrict__ g_sigmas, float *__restrict__ g_coords,
                                                     float *__restrict__ g_colors)
@@ -1319,9 +1300,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_render_bwd(Params P, PlanVie
     bwd_fetch_first(V, V.cell_start + P.ncells, min(gw, (unsigned)P.s - 1u), G, lim);  // speculative: class checked below
     const unsigned large_beg = lim.x, large_end = lim.y;
     if (gw < large_beg)
-        bwd_item<BOUNDED, UNROLL, CHW>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED, UNROLL>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     else if (gw < large_end)
-        bwd_item<BOUNDED, UNROLL, CHW>(gw, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED, UNROLL>(gw, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     else if (gw < (unsigned)P.s && (P.flags & GSASR_FLAG_OVERWRITE_GRADS))   // dead class: the gradient is zero
         bwd_write(0.f, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
     // remaining row chunks of the large class, spread over all waves
@@ -1330,7 +1311,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_render_bwd(Params P, PlanVie
         const unsigned j = large_beg + it / (unsigned)(NCH - 1);
         const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
         bwd_fetch(V, j, G);
-        bwd_item<BOUNDED, UNROLL, CHW>(j, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+        bwd_item<BOUNDED, UNROLL>(j, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     }
 }
 
@@ -1621,14 +1602,9 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
     // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
     // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
     const bool unroll = (double)(dims->row1 - dims->row0) * (double)dims->w >= 32.0 * (double)dims->s;
-    const bool chw = dims->flags & GSASR_FLAG_CHW_GRAD;
-    if (chw && (double)(dims->batch > 1 ? dims->slot : dims->row1 - dims->row0) * dims->w * 8.0 >= 2147483647.0)
-        return fail(GSASR_ERR_ARG, "GSASR_FLAG_CHW_GRAD: colour planes further than 2 GiB apart");
-#define GSASR_BWD3(B, U, C) hipLaunchKernelGGL((k_render_bwd<B, U, C>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
-#define GSASR_BWD(B, U) do { if (chw) GSASR_BWD3(B, U, true); else GSASR_BWD3(B, U, false); } while (0)
+#define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
     if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
     else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
-#undef GSASR_BWD3
 #undef GSASR_BWD
     HIP_TRY(hipGetLastError());
     return GSASR_OK;

@@ -90,8 +90,8 @@ class _FusedStep(torch.autograd.Function):
     def backward(ctx, grad_output):
         from . import _cabi
         gs_parameters, step = ctx.saved_tensors
-        # the gradient of a planar output is planar: the backward reads it as it is (GSASR_FLAG_CHW_GRAD), no permute pass
-        return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_output.contiguous(), chw=True), None, None, None, None
+        grad_hwc = grad_output.permute(1, 2, 0).contiguous()   # the backward kernel sweeps 12-byte HWC pixels
+        return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_hwc), None, None, None, None
 
 
 def _fused_ok(gs_parameters) -> bool:
@@ -284,12 +284,9 @@ class _FusedBatch(torch.autograd.Function):
         from . import _cabi
         gs_parameters, steps = ctx.saved_tensors
         d = ctx.plan.dims
-        if d.slot == ctx.h_max:                 # planar gradient of the planar output, read as it is
-            grad = grad_output.contiguous()
-        else:                                   # the slot is h_max rounded up to 16 rows: pad (never read by the kernel)
-            grad = grad_output.new_empty(d.batch, 3, d.slot, d.w)
-            grad[:, :, : ctx.h_max] = grad_output
-        return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad, chw=True), None, None, None
+        grad = grad_output.new_zeros(d.batch, d.slot, d.w, 3)      # [B, slot, Wmax, 3]: what the backward sweeps
+        grad[:, : ctx.h_max] = grad_output.permute(0, 2, 3, 1)
+        return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad), None, None, None
 
 
 def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):

@@ -52,9 +52,6 @@ enum gsasr_status {
                                          returns, utils/gaussian_splatting.py:129) instead of [row1-row0, w, 3] */
 #define GSASR_FLAG_OVERWRITE_GRADS 4u /* backward STORES the gradients (outputs need not be zeroed) instead
                                          of adding into them */
-#define GSASR_FLAG_CHW_GRAD 32u       /* backward reads grad_img as planar [3, row1-row0, w] ([B, 3, slot, w] for a batched
-                                         canvas) -- the layout autograd returns for a planar output -- instead of
-                                         [row1-row0, w, 3]: no permute pass in front of the backward */
 #define GSASR_FLAG_STRIDE8 16u        /* sigmas/coords/colors AND g_sigmas/g_coords/g_colors are columns of packed
                                          [s,8] records {sx,sy,rho,x,y,r,g,b}: element k of Gaussian i is at
                                          ptr[8*i+k].  Pass base, base+3, base+5 of one array; this is the wire
@@ -140,7 +137,7 @@ int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, 
  * prologue + plan + forward, and splat-backward + prologue-backward.  The workspace additionally holds the
  * kernel-frame tensors and their gradients (gsasr_step_workspace_bytes >= gsasr_splat_workspace_bytes).
  * Forward honours dims.flags (OVERWRITE_IMAGE, CHW_IMAGE); backward always stores g_parameters[n,9] and
- * expects grad_img as [row1-row0, w, 3], or planar with GSASR_FLAG_CHW_GRAD. */
+ * expects grad_img as [row1-row0, w, 3]. */
 size_t gsasr_step_workspace_bytes(const gsasr_dims *dims);
 int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
                        size_t workspace_bytes, float *img, void *stream);

@@ -819,22 +819,3 @@ def test_autocast_boundary_runs_the_op_in_fp32(dev):
         a = gsp.generate_2D_gaussian_splatting_step((H, W), p.bfloat16(), 4.0, torch.tensor([4.0, 4.0], device=dev))
         b = gsp.generate_2D_gaussian_splatting_step((H, W), p.bfloat16().float(), 4.0, torch.tensor([4.0, 4.0], device=dev))
         assert a.dtype == torch.float32 and float((a - b).abs().max()) <= 2e-6
-
-
-def test_planar_gradient_layout_equals_hwc(dev):
-    """GSASR_FLAG_CHW_GRAD: the backward reading a planar [3,rows,w] gradient == reading its HWC permutation; also on
-    a row band, with the unbounded op, and for a window wider than 64 columns (multi-strip sweep)"""
-    from gsasr_amd import _cabi, synthetic
-    for (hl, wl, sc, dmax, rows) in ((24, 20, 4.0, 0.3, None), (24, 20, 4.0, None, (17, 70)), (6, 6, 24.0, None, None)):
-        sig, xy, col, H, W = synthetic.kernel_inputs(hl, wl, sc, seed=200, device=dev)
-        plan = _cabi.plan(sig, xy, col, H, W, dmax, rows=rows)
-        r = (rows[1] - rows[0]) if rows else H
-        g_hwc = synthetic.grad_image(H, W, 201, device=dev)[(rows[0] if rows else 0):(rows[1] if rows else H)].contiguous()
-        g_chw = g_hwc.permute(2, 0, 1).contiguous()
-        a = [torch.empty_like(t) for t in (sig, xy, col)]
-        b = [torch.empty_like(t) for t in (sig, xy, col)]
-        _cabi.backward(plan, sig, xy, col, g_hwc, *a, overwrite=True)
-        _cabi.backward(plan, sig, xy, col, g_chw, *b, overwrite=True, chw=True)
-        assert g_chw.shape == (3, r, W)
-        for x, y in zip(a, b):
-            assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
