@@ -35,7 +35,8 @@ def install(also_gaussian_splatting: bool = False) -> None:
             sys.modules[f"{root}.{sub}.gswrapper"] = mod
             setattr(pkg, "gswrapper", mod)
             setattr(sys.modules[root], sub, pkg)
-        if also_gaussian_splatting:
-            from . import gaussian_splatting
-            sys.modules[f"{root}.gaussian_splatting"] = gaussian_splatting
-            setattr(sys.modules[root], "gaussian_splatting", gaussian_splatting)
+        if also_gaussian_splatting:   # the host API and the tiled-inference driver built on it
+            from . import gaussian_splatting, split_and_joint_image
+            for name, mod in (("gaussian_splatting", gaussian_splatting), ("split_and_joint_image", split_and_joint_image)):
+                sys.modules[f"{root}.{name}"] = mod
+                setattr(sys.modules[root], name, mod)

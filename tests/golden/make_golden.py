@@ -14,6 +14,9 @@ What is captured (data only -- inputs and the reference's outputs; no reference 
                       two `gswrapper` modules in sys.modules with a recorder, so the reference host code
                       runs unmodified on CPU.
  * rendering_python_*.npz  output of the `cuda_rendering=False` branch (utils/gaussian_splatting.py:11-84).
+ * tiled_*.npz        `split_and_joint_image` (utils/split_and_joint_image.py:98-232) with the deterministic
+                      stand-in encoder/decoder of tests/tiled_models.py and `cuda_rendering=False`: LR input,
+                      arguments and the stitched SR output, for an integer and a fractional scale factor.
 
 Stubs needed because this image has no torchvision / CUDA: dummy `torchvision`, `torchvision.utils`
 (imported but unused by utils/gaussian_splatting.py:7-8) and a dummy `gswrapper` (check.py:2 would
@@ -154,6 +157,20 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"rendering_python_{name}.npz"), gs_parameters=g.numpy(),
                             sr_size=np.array(sr), scale=np.float64(sc), out=out.numpy())
         print("rendering_python", name, float(out.mean()), float(out.max()))
+
+    # ---- tiled inference driver (utils/split_and_joint_image.py) -----------------------------------------
+    import utils.split_and_joint_image as reftile  # noqa: E402  (the reference, unmodified)
+    sys.path.insert(0, os.path.dirname(OUT))
+    import tiled_models  # noqa: E402
+    for name, (hl, wl), sc, split, overlap, crop in (("int_s2_20x26", (20, 26), 2.0, 8, 2, 2),
+                                                     ("frac_s2p5_18x22", (18, 22), 2.5, 8, 3, 1)):
+        torch.manual_seed(21)
+        lq = torch.rand(1, 3, hl, wl)
+        out = reftile.split_and_joint_image(lq, sc, split, overlap, tiled_models.model_g, tiled_models.model_fea2gs,
+                                            torch.tensor([sc, sc]), crop_size=crop, cuda_rendering=False)
+        np.savez_compressed(os.path.join(OUT, f"tiled_{name}.npz"), lq=lq.numpy(), scale=np.float64(sc),
+                            split_size=split, overlap_size=overlap, crop_size=crop, out=out.numpy())
+        print("tiled", name, tuple(out.shape), float(out.mean()))
 
     # BASELINE.json config 1 known answer: statistics only (the tensor is 768 KB)
     torch.manual_seed(0)
