@@ -131,5 +131,10 @@ def test_compat_install_registers_reference_module_names():
     from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA as A0
     from gsasr_amd.gs_cuda.gswrapper import GSCUDA as B0
     assert A is A0 and B is B0 and hasattr(gscuda, "gs_render") and hasattr(gscuda, "gs_render_backward")
+    compat.install(also_gaussian_splatting=True)       # host API + tiled-inference driver as well
+    from utils.gaussian_splatting import generate_2D_gaussian_splatting_step as S  # noqa: E402
+    from basicsr.utils.split_and_joint_image import split_and_joint_image as T  # noqa: E402
+    import gsasr_amd.split_and_joint_image as tiled
+    assert S is gsp.generate_2D_gaussian_splatting_step and T is tiled.split_and_joint_image
     for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "basicsr", "gscuda")]:
         del sys.modules[k]
