@@ -39,3 +39,6 @@ python bench.py --no-cpu-baseline --cutoff 32 > $OUT/bench_c2_tau32.json 2>> $OU
 python tools/e2e_time.py > $OUT/e2e_time.txt 2>&1
 for f in $OUT/bench_c*.json; do echo $f; python -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],4), {k:round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items()})"; done
 cat $OUT/e2e_time.txt | tail -5
+python bench.py --no-cpu-baseline --config c5 > $OUT/bench_c5.json 2>> $OUT/bench.err
+python tools/e2e_batch_time.py > $OUT/e2e_batch_time.txt 2>&1
+tail -c 400 $OUT/bench_c5.json; tail -2 $OUT/e2e_batch_time.txt
