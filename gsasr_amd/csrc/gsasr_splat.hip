@@ -1556,11 +1556,15 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     const int tiles_x = (subs_x + FWD_WAVES - 1) / FWD_WAVES;
     hipStream_t st = (hipStream_t)stream;
     const long nsub = (long)subs_x * tiles_y;
-    if (nsub < 4096) {
+#ifndef FWD_SPLIT_BELOW
+#define FWD_SPLIT_BELOW 4096
+#define FWD_SPLIT_TARGET 8192
+#endif
+    if (nsub < FWD_SPLIT_BELOW) {
         // fewer sub-tiles than half the chip's 8192 wave slots: split each sub-tile's Gaussian list over
         // 2..16 waves so that about one full set of waves is in flight
         int nw = 2;
-        while (nw < 16 && nsub * nw < 8192) nw *= 2;
+        while (nw < 16 && nsub * nw < FWD_SPLIT_TARGET) nw *= 2;
         const dim3 grid((unsigned)nsub), block((unsigned)nw * 64u);
         if (P.bounded)
             hipLaunchKernelGGL(k_render_fwd_split<true>, grid, block, 0, st, P, V, img, subs_x);
