@@ -9,6 +9,11 @@ but the rasterizer runs ALL tiles of up to 64 at a time as one batched canvas (e
 reference's case tree -- including its one irregularity, kept on purpose: with a fractional scale factor the
 reference does not crop the top of a last-column tile (or the left of a last-row tile) that is neither in the
 first row/column nor the corner (`:178-185`).
+
+Multi-GPU (not in the reference): with `distribute=True` inside an initialised `torch.distributed` job every rank
+runs encoder, decoder and rasterizer for the tiles `rank, rank+world, ...` only and ONE `all_gather` brings the SR
+tiles together before pasting -- tiles are independent, so this is the tile shard of SURVEY.md 8e at the level of
+the whole pipeline (the caller's models are replicated, as under DDP).
 """
 import math
 
@@ -33,7 +38,7 @@ def _paste_rule(i, j, nh, nw, crop, fractional):
 
 def split_and_joint_image(lq, scale_factor, split_size, overlap_size, model_g, model_fea2gs, scale_modify,
                           crop_size=2, default_step_size=1.2, mode='scale_modify', cuda_rendering=True,
-                          if_dmax=False, dmax_mode='fix', dmax=25):
+                          if_dmax=False, dmax_mode='fix', dmax=25, distribute=False, group=None):
     h_lq, w_lq = lq.shape[-2:]
     assert overlap_size > 0 and overlap_size < split_size // 2, f"overlap size is wrong"
     stride = split_size - overlap_size
@@ -44,21 +49,25 @@ def split_and_joint_image(lq, scale_factor, split_size, overlap_size, model_g, m
     lq_pad = F.pad(input=lq, pad=(0, pad_w, 0, pad_h), mode='reflect')
 
     size_sr = math.ceil(split_size * scale_factor)
-    # encoder + decoder per tile (the caller's models), raster order
+    n_tiles = nh * nw
+    rank, world = 0, 1
+    if distribute and torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
+    mine = list(range(rank, n_tiles, world))      # this rank's tiles (raster index)
+
+    # encoder + decoder per tile (the caller's models)
     params = []
-    for i in range(nh):
-        for j in range(nw):
-            tile = lq_pad[:, :, i * stride: i * stride + split_size, j * stride: j * stride + split_size]
-            feat = model_g(tile)
-            scale_vector = scale_modify[0].unsqueeze(0).to(feat.device)
-            params.append(model_fea2gs(feat, scale_vector)[0, :])
+    for k in mine:
+        i, j = divmod(k, nw)
+        tile = lq_pad[:, :, i * stride: i * stride + split_size, j * stride: j * stride + split_size]
+        feat = model_g(tile)
+        scale_vector = scale_modify[0].unsqueeze(0).to(feat.device)
+        params.append(model_fea2gs(feat, scale_vector)[0, :])
 
     # rasterizer: all tiles have the same size and scale -> batched canvases of up to 64 tiles
-    n_tiles = nh * nw
     tiles = []
-    fusable = cuda_rendering and params[0].is_cuda
-    if fusable and n_tiles > 1:
-        for a in range(0, n_tiles, _MAX_BATCH):
+    if cuda_rendering and params and params[0].is_cuda and len(params) > 1:
+        for a in range(0, len(params), _MAX_BATCH):
             chunk = params[a: a + _MAX_BATCH]
             if len(chunk) == 1:
                 break
@@ -67,12 +76,20 @@ def split_and_joint_image(lq, scale_factor, split_size, overlap_size, model_g, m
                                                        default_step_size=default_step_size, mode=mode, if_dmax=if_dmax,
                                                        dmax_mode=dmax_mode, dmax=dmax)
             tiles.extend(out[k] for k in range(len(chunk)))
-    for k in range(len(tiles), n_tiles):
+    for k in range(len(tiles), len(params)):
         tiles.append(generate_2D_gaussian_splatting_step(sr_size=torch.tensor([size_sr, size_sr]), gs_parameters=params[k],
                                                          scale=scale_factor, sample_coords=None, scale_modify=scale_modify,
                                                          default_step_size=default_step_size, mode=mode,
                                                          cuda_rendering=cuda_rendering, if_dmax=if_dmax,
                                                          dmax_mode=dmax_mode, dmax=dmax))
+    if world > 1:   # one all_gather of equally sized stacks (ranks with one tile less pad with zeros)
+        per = (n_tiles + world - 1) // world
+        stack = lq.new_zeros(per, lq.shape[1], size_sr, size_sr)
+        if tiles:
+            stack[: len(tiles)] = torch.stack(tiles)
+        everyone = lq.new_empty(world * per, lq.shape[1], size_sr, size_sr)
+        torch.distributed.all_gather_into_tensor(everyone, stack, group=group)
+        tiles = [everyone[(k % world) * per + k // world] for k in range(n_tiles)]
     assert tiles[0].shape[1] == size_sr and tiles[0].shape[2] == size_sr, \
         f'tile_sr_h-{tiles[0].shape[1]}, tile_sr_w-{tiles[0].shape[2]}, split_size_sr-{size_sr} is not the same'
 
