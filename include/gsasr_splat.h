@@ -21,7 +21,8 @@
  * band for the multi-GPU HR-tile shard.  INTEGRATION.md shows the reference-side
  * binding.
  *
- * Conventions: all pointers are device pointers valid on the current HIP device; `stream` is a
+ * Conventions: all pointers are device pointers valid on the current HIP device (the one exception is the small
+ * host array gsasr_dims.sample_hw of a batched canvas); `stream` is a
  * hipStream_t passed as void* (NULL = default stream); calls only enqueue work (no host sync);
  * return 0 on success or a negative gsasr_status / positive hipError_t, with a thread-local message
  * available from gsasr_last_error().  c must be 3 (the reference forward hard-codes stride 3,
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSASR_SPLAT_ABI_VERSION 2
+#define GSASR_SPLAT_ABI_VERSION 2 /* 2: gsasr_dims gained batch / slot / sample_hw */
 
 enum gsasr_status {
     GSASR_OK = 0,
