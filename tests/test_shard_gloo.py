@@ -199,7 +199,7 @@ def _exchange_worker(rank, world, port, cap, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_band_exchange_matches_single_process(world):
     from oracle import gs_oracle
     mgr = mp.Manager()
