@@ -956,6 +956,36 @@ __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V,
     }
 }
 
+// Images with fewer sub-tiles than the chip has wave slots (4096..8191, e.g. the batched canvas of config 5):
+// two waves per sub-tile, alternate candidate chunks each, fill the machine: a workgroup = two sub-tiles side by
+// side x two parts; the odd wave hands its partial sums to the even one through LDS.  (Above 8192 sub-tiles the
+// duplicated per-wave setup costs more than the finer grain gains; below 4096 k_render_fwd_split goes further.)
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) void k_render_fwd_pair(Params P, PlanView V, float *__restrict__ img, int subs_x)
+{
+    __shared__ float s_part[2][6][64];
+    __shared__ float4 s_stage[4][128];
+    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pairs_x = (subs_x + 1) >> 1;
+    const int sub = (int)(t % (unsigned)pairs_x) * 2 + (wv >> 1), part = wv & 1;
+    const int sx0 = sub * SUBX, sy0 = P.row0 + (int)(t / (unsigned)pairs_x) * SUBY;
+    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
+    const bool live = sx0 < P.w;   // wave-uniform (odd number of sub-tile columns)
+    if (live) fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, (unsigned)part, 2u, s_stage[wv], ar, ag, ab);
+    if (part) {
+        float (*o)[64] = s_part[wv >> 1];
+        o[0][lane] = ar.x; o[1][lane] = ar.y; o[2][lane] = ag.x; o[3][lane] = ag.y; o[4][lane] = ab.x; o[5][lane] = ab.y;
+    }
+    __syncthreads();
+    if (!part && live) {
+        float (*o)[64] = s_part[wv >> 1];
+        ar.x += o[0][lane]; ar.y += o[1][lane]; ag.x += o[2][lane]; ag.y += o[3][lane]; ab.x += o[4][lane]; ab.y += o[5][lane];
+        fwd_store(P, V, img, sx0, sy0, lane, ar, ag, ab);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward: one wave64 per Gaussian (cell order, so neighbouring waves read neighbouring pixels)
 // ---------------------------------------------------------------------------------------------------
@@ -1570,6 +1600,15 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
             hipLaunchKernelGGL(k_render_fwd_split<true>, grid, block, 0, st, P, V, img, subs_x);
         else
             hipLaunchKernelGGL(k_render_fwd_split<false>, grid, block, 0, st, P, V, img, subs_x);
+#ifndef FWD_PAIR_BELOW
+#define FWD_PAIR_BELOW 8192   // fewer sub-tiles than wave slots (measured: -13% at 4608 sub-tiles, +2..14% above 8192)
+#endif
+    } else if (nsub < FWD_PAIR_BELOW) {
+        const dim3 grid((unsigned)((subs_x + 1) / 2) * (unsigned)tiles_y), block(256);
+        if (P.bounded)
+            hipLaunchKernelGGL(k_render_fwd_pair<true>, grid, block, 0, st, P, V, img, subs_x);
+        else
+            hipLaunchKernelGGL(k_render_fwd_pair<false>, grid, block, 0, st, P, V, img, subs_x);
     } else {
         const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(64 * FWD_WAVES);
         if (P.bounded)

@@ -819,3 +819,11 @@ def test_autocast_boundary_runs_the_op_in_fp32(dev):
         a = gsp.generate_2D_gaussian_splatting_step((H, W), p.bfloat16(), 4.0, torch.tensor([4.0, 4.0], device=dev))
         b = gsp.generate_2D_gaussian_splatting_step((H, W), p.bfloat16().float(), 4.0, torch.tensor([4.0, 4.0], device=dev))
         assert a.dtype == torch.float32 and float((a - b).abs().max()) <= 2e-6
+
+
+def test_forward_pair_kernel_range_against_oracle(dev):
+    """4096..8191 sub-tiles (here 104 x 40 = 4160): the two-waves-per-sub-tile forward, bounded and unbounded"""
+    sig, xy, col, H, W, wgt = _synth(40, 52, 16.0, seed=210)
+    assert 4096 <= ((W + 7) // 8) * ((H + 15) // 16) < 8192
+    for dmax in (0.05, None):
+        _check(sig, xy, col, H, W, dmax, dev, wgt)
