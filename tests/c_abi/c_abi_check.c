@@ -4,7 +4,8 @@
  * Links libgsasr_splat.so (the product) through include/gsasr_splat.h exactly the way a C/C++ maintainer
  * of the reference would after swapping gs.h's launchers, and checks the
  * results against the CPU oracle's double-precision truth (oracle/libgs_ref.so), both for the
- * reference-shaped launchers and for the plan API.  Built and run by tests/test_c_abi.py on the GPU box.
+ * reference-shaped launchers, the plan API (row band), a batched canvas and the band-exchange kernels.  Built and
+ * run by tests/test_c_abi.py on the GPU box.
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -119,6 +120,100 @@ int main(void)
         printf("plan API  dmax=%g band [%d,%d): image max|err| %.3e, grad(colors) rel err %.2e\n", dmax, h / 2, h, eimg, e4);
         if (!(eimg <= 2e-4) || !(e4 <= 2e-4)) bad = 1;
         CK(hipFree(ws));
+    }
+    /* batched canvas (gsasr_dims.batch): two samples of different size from the same Gaussians, kernel-frame inputs;
+     * every sample must equal the oracle's single-image result on ITS grid, padding must be zero */
+    {
+        const int B = 2, hw[4] = {40, 56, 64, 37}, n = 400, slot = 64, wmax = 56;
+        const float dmax = 0.25f;
+        gsasr_dims d = {B * n, B * slot, wmax, 3, dmax, 0, B * slot, 0.f, GSASR_FLAG_OVERWRITE_IMAGE | GSASR_FLAG_OVERWRITE_GRADS,
+                        B, slot, hw};
+        const size_t bytes = gsasr_splat_workspace_bytes(&d);
+        if (!bytes) { fprintf(stderr, "batched dims rejected: %s\n", gsasr_last_error()); return 4; }
+        void *ws;
+        float *d_can, *d_gcan;
+        CK(hipMalloc(&ws, bytes));
+        CK(hipMalloc((void **)&d_can, sizeof(float) * 3 * B * slot * wmax));
+        CK(hipMalloc((void **)&d_gcan, sizeof(float) * 3 * B * slot * wmax));
+        CK(hipMemcpy(d_gcan, wgt, sizeof(float) * 3 * B * slot * wmax, hipMemcpyHostToDevice));   /* incl. junk in the padding */
+        /* the first 2n Gaussians of the arrays above: sample 0 = [0,n), sample 1 = [n,2n) */
+        OK(gsasr_splat_plan(d_sig, d_xy, d_col, &d, ws, bytes, st));
+        OK(gsasr_splat_forward(&d, ws, bytes, d_can, st));
+        OK(gsasr_splat_backward(d_sig, d_xy, d_col, d_gcan, d_gs, d_gc, d_gk, &d, ws, bytes, st));
+        CK(hipStreamSynchronize(st));
+        float *can = malloc(sizeof(float) * 3 * B * slot * wmax);
+        CK(hipMemcpy(can, d_can, sizeof(float) * 3 * B * slot * wmax, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gk, d_gk, sizeof(float) * 3 * B * n, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) {
+            const int hb = hw[2 * b], wb = hw[2 * b + 1];
+            gsref_forward_f64(sig + 3 * b * n, xy + 2 * b * n, col + 3 * b * n, ref, n, hb, wb, dmax, 0, hb);
+            /* the sample's gradient image: its h_b x w_b corner of slot b */
+            float *gsub = malloc(sizeof(float) * 3 * hb * wb);
+            for (int i = 0; i < hb; ++i)
+                for (int j = 0; j < 3 * wb; ++j) gsub[(size_t)i * 3 * wb + j] = wgt[((size_t)(b * slot + i) * wmax) * 3 + j];
+            gsref_backward_f64(sig + 3 * b * n, xy + 2 * b * n, col + 3 * b * n, gsub, rs, rc, rk, n, hb, wb, dmax, 0, hb);
+            double eimg = 0, epad = 0;
+            for (int i = 0; i < slot; ++i)
+                for (int j = 0; j < wmax; ++j)
+                    for (int k = 0; k < 3; ++k) {
+                        const double got = can[((size_t)(b * slot + i) * wmax + j) * 3 + k];
+                        if (i < hb && j < wb) { const double dd = fabs(got - ref[((size_t)i * wb + j) * 3 + k]); if (dd > eimg) eimg = dd; }
+                        else if (fabs(got) > epad) epad = fabs(got);
+                    }
+            const double e5 = maxrel(gk + 3 * b * n, rk, 3 * n);
+            printf("batched canvas sample %d (%dx%d): image max|err| %.3e, padding max %.1e, grad(colors) rel err %.2e\n", b, hb,
+                   wb, eimg, epad, e5);
+            if (!(eimg <= 2e-4) || epad != 0.0 || !(e5 <= 2e-4)) bad = 1;
+            free(gsub);
+        }
+        free(can);
+        CK(hipFree(ws)); CK(hipFree(d_can)); CK(hipFree(d_gcan));
+    }
+    /* band exchange: select on packed [s,8] records, NaN padding, counts; merge adds the returned rows */
+    {
+        const int n = 1000, cap = 512, hh = 200, ww = 64;
+        float *pk = malloc(sizeof(float) * 8 * n), *d_pk, *d_up, *d_dn, *d_g;
+        int *d_iu, *d_id, *d_cnt, cnt[4];
+        for (int i = 0; i < n; ++i) {
+            pk[8 * i + 0] = 0.02f; pk[8 * i + 1] = 0.02f; pk[8 * i + 2] = 0.f;
+            pk[8 * i + 3] = 1.9f * frand(&seed) - 0.95f; pk[8 * i + 4] = 1.9f * frand(&seed) - 0.95f;
+            pk[8 * i + 5] = pk[8 * i + 6] = pk[8 * i + 7] = 0.5f;
+        }
+        CK(hipMalloc((void **)&d_pk, sizeof(float) * 8 * n)); CK(hipMalloc((void **)&d_up, sizeof(float) * 8 * cap));
+        CK(hipMalloc((void **)&d_dn, sizeof(float) * 8 * cap)); CK(hipMalloc((void **)&d_g, sizeof(float) * 8 * n));
+        CK(hipMalloc((void **)&d_iu, sizeof(int) * cap)); CK(hipMalloc((void **)&d_id, sizeof(int) * cap));
+        CK(hipMalloc((void **)&d_cnt, sizeof(int) * 4));
+        CK(hipMemcpy(d_pk, pk, sizeof(float) * 8 * n, hipMemcpyHostToDevice));
+        gsasr_dims d = {n, hh, ww, 3, 0.1f, 50, 150, 0.f, GSASR_FLAG_STRIDE8};   /* this rank's band: rows [50,150) */
+        OK(gsasr_band_select(d_pk, &d, 50, 50, cap, d_up, d_dn, d_iu, d_id, d_cnt, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost));
+        /* expected: the dmax box (0.1 * 199/2 = 9.95 px, far inside the 2.6-sigma support) reaches above row 50 / below 150 */
+        int eu = 0, ed = 0;
+        for (int i = 0; i < n; ++i) {
+            const double cy = ((double)pk[8 * i + 4] + 1.0) * 0.5 * (hh - 1), ey = 0.1 * 0.5 * (hh - 1);
+            const double lo = ceil(cy - ey - 0.02), hi = floor(cy + ey + 0.02);
+            if (hi < 0 || lo > hh - 1) continue;
+            if ((lo < 0 ? 0 : lo) < 50) ++eu;
+            if ((hi > hh - 1 ? hh - 1 : hi) >= 150) ++ed;
+        }
+        printf("band select: up %d (expected %d), down %d (expected %d), far %d\n", cnt[0], eu, cnt[1], ed, cnt[2]);
+        if (cnt[0] != eu || cnt[1] != ed || cnt[2] != 0 || eu == 0 || ed == 0 || eu > cap || ed > cap) bad = 1;
+        /* merge: g[index[j]] += rows of ones */
+        float *ones = malloc(sizeof(float) * 8 * cap), *g = malloc(sizeof(float) * 8 * n);
+        int *iu = malloc(sizeof(int) * cap);
+        for (int i = 0; i < 8 * cap; ++i) ones[i] = 1.f;
+        CK(hipMemcpy(d_up, ones, sizeof(float) * 8 * cap, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_dn, ones, sizeof(float) * 8 * cap, hipMemcpyHostToDevice));
+        CK(hipMemsetAsync(d_g, 0, sizeof(float) * 8 * n, st));
+        OK(gsasr_band_merge(d_g, n, d_up, d_dn, d_iu, d_id, d_cnt, cap, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(g, d_g, sizeof(float) * 8 * n, hipMemcpyDeviceToHost));
+        double tot = 0;
+        for (int i = 0; i < 8 * n; ++i) tot += g[i];
+        printf("band merge: %.0f added (expected %d)\n", tot, 8 * (eu + ed));
+        if (tot != 8.0 * (eu + ed)) bad = 1;
+        free(pk); free(ones); free(g); free(iu);
     }
     /* error behaviour: status + message instead of a crash */
     if (gsasr_gs_render_dmax(d_sig, d_xy, d_col, d_img, s, h, w, 4, 0.1f, st) == 0) { printf("c=4 accepted\n"); bad = 1; }
