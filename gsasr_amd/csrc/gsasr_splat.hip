@@ -854,6 +854,141 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
     }
 }
 
+// ---- two-level walk (large images) ---------------------------------------------------------------------
+// Measured: finding a sub-tile's hits -- fetching the 24-byte windows of every Gaussian binned within reach and
+// testing them, 64 per wave and round trip -- is HALF of the forward's time (the candidates come from cells within
+// the class' MAXIMUM extent, 4-5x more than hit).  The four waves of a workgroup render four sub-tiles side by side,
+// and their candidate sets are almost the same, so the workgroup walks the candidates of its 32x16 tile ONCE,
+// cooperatively: each wave tests a quarter of the chunks against the whole tile (window only, 8 bytes per
+// candidate) and appends the survivors to a shared list in LDS; after a barrier every wave runs the full test
+// (window + ellipse span) over that list only.  Rounds of 1024 candidates bound the list.
+constexpr int COARSE_CHUNKS = 4;                          // coarse chunks per wave and round
+constexpr int COARSE_LIST = 4 * COARSE_CHUNKS * 64;       // candidates per round = capacity of the shared list
+
+template <bool BOUNDED>
+__device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, int bx0, int by0, int wv, int lane,
+                                          float4 *stage, unsigned *s_list, unsigned *s_cnt, v2f &ar, v2f &ag, v2f &ab)
+{
+    const int bx1 = min(bx0 + 4 * SUBX - 1, P.w - 1), by1 = min(by0 + SUBY - 1, P.row1 - 1);
+    const int sx0 = bx0 + wv * SUBX, sy0 = by0;
+    const bool live = sx0 < P.w;                              // wave-uniform (image width not a multiple of 32)
+    const int sx1 = min(sx0 + SUBX - 1, P.w - 1), sy1 = by1;
+    const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
+    const float px = V.px[(P.batch > 1 ? (sy0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
+    const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y1, P.h - 1)]};
+    const float4 *__restrict__ rec = V.rec;
+    const uint4 *__restrict__ bbox = V.bbox;
+    const unsigned *__restrict__ cs = V.cell_start;
+    const int wty = (sy0 - P.row0) >> SUBY_SHIFT, wtx = sx0 >> SUBX_SHIFT;
+
+    // segment table of the 32x16 tile (every wave builds the same one: a single vector round trip)
+    const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    int nseg = 0;
+    unsigned sbeg = 0, send = 0;
+    if (rx > 0) {
+        const int cx0 = max(bx0 - rx, 0) >> CELL_SHIFT, cx1 = min((bx1 + rx) >> CELL_SHIFT, P.ncx - 1);
+        const int cy0 = max(by0 - ry, 0) >> CELL_SHIFT, cy1 = min((by1 + ry) >> CELL_SHIFT, P.ncy - 1);
+        nseg = cy1 - cy0 + 1;
+        if (lane < nseg) {
+            sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+            send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
+        }
+    }
+    if (lane == nseg) {
+        sbeg = cs[P.ncells];
+        send = cs[P.ncells + 1];
+    }
+    ++nseg;
+    const unsigned len = send - sbeg;
+    unsigned pin = len;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)pin, o);
+        if (lane >= o) pin += v;
+    }
+    const unsigned pex = pin - len;
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+    const unsigned nchunks = (total + 63u) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rseg = 0;
+
+    for (unsigned base = 0, round = 0; base < nchunks; base += 4u * COARSE_CHUNKS, ++round) {
+        unsigned *cnt = s_cnt + (round & 1u);
+        // ---- phase A: this wave's share of the round's chunks against the whole tile -------------------
+        unsigned cj[COARSE_CHUNKS];
+        uint2 cw[COARSE_CHUNKS];
+#pragma unroll
+        for (int k = 0; k < COARSE_CHUNKS; ++k) {     // all loads of the round in flight together
+            const unsigned c = base + (unsigned)wv + 4u * (unsigned)k;
+            cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
+            cw[k] = make_uint2(0x7fffu, 0x7fffu);
+            if (cj[k] != 0xffffffffu) cw[k] = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)cj[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < COARSE_CHUNKS; ++k) {
+            const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
+            const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
+            const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                unsigned at = 0;
+                if (lane == 0) at = atomicAdd(cnt, (unsigned)__builtin_popcountll(m));
+                at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+                if (hit) s_list[at + (unsigned)__builtin_popcountll(m & below)] = cj[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0u;   // nobody touches the other counter before the next barrier
+        const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)*cnt);
+        // ---- phase B: the full test of the tile's survivors against this wave's sub-tile ----------------
+        if (live) {
+            unsigned j = lane < n ? s_list[lane] : 0xffffffffu;
+            const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);
+            uint4 bb = dead;
+            uint2 bs = make_uint2(0u, 0u);
+            if (j != 0xffffffffu) {
+                bb = bbox[2 * (size_t)j];
+                bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)j + 1);
+            }
+            for (unsigned q = 0; q < n; q += 64u) {
+                const unsigned nq = q + 64u + (unsigned)lane;
+                const unsigned nj = nq < n ? s_list[nq] : 0xffffffffu;
+                uint4 nbb = dead;
+                uint2 nbs = make_uint2(0u, 0u);
+                if (nj != 0xffffffffu) {
+                    nbb = bbox[2 * (size_t)nj];
+                    nbs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)nj + 1);
+                }
+                const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+                const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+                bool hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
+                if (bb.y & 0x8000u) {  // per-tile-row column spans (k_bin)
+                    const unsigned t = (unsigned)(wty - ((r0 - P.row0) >> SUBY_SHIFT)) & 7u, sh = (t & 3u) * 8u;
+                    const unsigned lo = t < 4u ? bb.z : bs.x, hi = t < 4u ? bb.w : bs.y;
+                    const int txr = wtx - (c0 >> SUBX_SHIFT);
+                    hit &= (txr >= (int)((lo >> sh) & 0xffu)) & (txr <= (int)((hi >> sh) & 0xffu));
+                }
+                const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
+                const unsigned long long m0 = __ballot(hit && !needs), m1 = __ballot(hit && needs);
+                const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
+                if (n0 + n1) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (hit) {
+                        const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
+                        const float4 *src = rec + 2 * (size_t)j;
+                        stage[2 * slot] = src[0];
+                        stage[2 * slot + 1] = src[1];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
+                    if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
+                }
+                j = nj; bb = nbb; bs = nbs;
+            }
+        }
+        __syncthreads();   // the list is rewritten in the next round
+    }
+}
+
 __device__ __forceinline__ void fwd_store(const Params &P, const PlanView &V, float *__restrict__ img, int sx0, int sy0,
                                           int lane, v2f ar, v2f ag, v2f ab)
 {
@@ -923,6 +1058,25 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_render_fwd(Params P, PlanVie
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
     fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, 0u, 1u, s_stage[wv], ar, ag, ab);
     fwd_store(P, V, img, sx0, sy0, lane, ar, ag, ab);
+}
+
+// Large images, two-level walk (fwd_block): same workgroup shape as k_render_fwd.
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) void k_render_fwd2(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+{
+    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float4 s_stage[4][128];
+    __shared__ unsigned s_list[COARSE_LIST];
+    __shared__ unsigned s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
+    const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
+    fwd_block<BOUNDED>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
+    if (bx0 + wv * SUBX < P.w) fwd_store(P, V, img, bx0 + wv * SUBX, by0, lane, ar, ag, ab);
 }
 
 // Small images (fewer sub-tiles than the chip has wave slots, e.g. the 192x192 training crops of
@@ -1610,6 +1764,19 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         else
             hipLaunchKernelGGL(k_render_fwd_pair<false>, grid, block, 0, st, P, V, img, subs_x);
     } else {
+#ifndef FWD_TWO_LEVEL
+#define FWD_TWO_LEVEL 1
+#endif
+        if (FWD_TWO_LEVEL) {
+            const int tx4 = (subs_x + 3) / 4;
+            const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(256);
+            if (P.bounded)
+                hipLaunchKernelGGL(k_render_fwd2<true>, grid, block, 0, st, P, V, img, tx4);
+            else
+                hipLaunchKernelGGL(k_render_fwd2<false>, grid, block, 0, st, P, V, img, tx4);
+            HIP_TRY(hipGetLastError());
+            return GSASR_OK;
+        }
         const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(64 * FWD_WAVES);
         if (P.bounded)
             hipLaunchKernelGGL(k_render_fwd<true>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
