@@ -17,11 +17,15 @@
 //                        {x, y, A, B, C, r, g, b} (A,B,C = exponent coefficients with log2(e) folded,
 //                        computed in double), backward-epilogue constants, 16-byte windows with the
 //                        per-tile-band column spans of the ellipse {exponent >= -tau}.
-//   forward  k_render_fwd  PIXEL-stationary: one wave64 = one 8x16 pixel sub-tile (2 px per lane, packed
-//                        fp32), RGB accumulators in registers.  The wave walks the cell rows within the
-//                        class' max extent in 64-candidate chunks (window + span test, one per lane), compacts
-//                        the hits' records into a per-wave LDS stage and evaluates them from broadcast
-//                        LDS reads; no atomics, one coalesced store / read-modify-write of the tile.
+//   forward  k_render_fwd2 PIXEL-stationary: one wave64 = one 8x16 pixel sub-tile (2 px per lane, packed
+//                        fp32), RGB accumulators in registers; four sub-tiles side by side per workgroup.  Two-level
+//                        walk: the workgroup tests the candidates of its 32x16 tile (cell rows within the class'
+//                        max extent, 64 per wave and chunk) ONCE, cooperatively, into a shared LDS list; each wave
+//                        then runs the full window + span test on the survivors only, compacts the hits' records
+//                        into its LDS stage and evaluates them from broadcast LDS reads; no atomics on the
+//                        image, one coalesced store / read-modify-write of the tile.
+//            k_render_fwd / k_render_fwd_pair   one-level walk per wave; the pair variant (two waves per sub-tile)
+//                        serves images with 4096..8191 sub-tiles.
 //            k_render_fwd_split   same per-wave code for small images: one sub-tile per workgroup, its
 //                        chunks dealt to 2..16 waves, partial sums combined through LDS.
 //   backward k_render_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian (its records fetched by the scalar
