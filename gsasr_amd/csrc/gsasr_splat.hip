@@ -24,8 +24,7 @@
 //                        then runs the full window + span test on the survivors only, compacts the hits' records
 //                        into its LDS stage and evaluates them from broadcast LDS reads; no atomics on the
 //                        image, one coalesced store / read-modify-write of the tile.
-//            k_render_fwd / k_render_fwd_pair   one-level walk per wave; the pair variant (two waves per sub-tile)
-//                        serves images with 4096..8191 sub-tiles.
+//                        Images with 4096..8191 sub-tiles: eight waves per workgroup, two per sub-tile.
 //            k_render_fwd_split   same per-wave code for small images: one sub-tile per workgroup, its
 //                        chunks dealt to 2..16 waves, partial sums combined through LDS.
 //   backward k_render_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian (its records fetched by the scalar
@@ -61,10 +60,6 @@ constexpr int SUBX = 8;         // forward sub-tile: 8 px wide x 16 px tall per 
 constexpr int SUBY = 16;
 constexpr int SUBX_SHIFT = 3, SUBY_SHIFT = 4;
 constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is binned as "large"
-#ifndef FWD_WAVES_N
-#define FWD_WAVES_N 4
-#endif
-constexpr int FWD_WAVES = FWD_WAVES_N;  // sub-tiles side by side per forward workgroup
 #ifndef BWD_WAVES_N
 #define BWD_WAVES_N 2
 #endif
@@ -867,14 +862,17 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
 // candidate) and appends the survivors to a shared list in LDS; after a barrier every wave runs the full test
 // (window + ellipse span) over that list only.  Rounds of 1024 candidates bound the list.
 constexpr int COARSE_CHUNKS = 4;                          // coarse chunks per wave and round
-constexpr int COARSE_LIST = 4 * COARSE_CHUNKS * 64;       // candidates per round = capacity of the shared list
+constexpr int COARSE_LIST = 4 * COARSE_CHUNKS * 64;       // candidates per round and part = capacity of the shared list
 
-template <bool BOUNDED>
+// PARTS = 2: eight waves per workgroup, two per sub-tile taking alternate chunks of the survivor list (images with
+// fewer sub-tiles than the chip has wave slots); the caller adds the two partial sums.
+template <bool BOUNDED, int PARTS>
 __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, int bx0, int by0, int wv, int lane,
                                           float4 *stage, unsigned *s_list, unsigned *s_cnt, v2f &ar, v2f &ag, v2f &ab)
 {
     const int bx1 = min(bx0 + 4 * SUBX - 1, P.w - 1), by1 = min(by0 + SUBY - 1, P.row1 - 1);
-    const int sx0 = bx0 + wv * SUBX, sy0 = by0;
+    const int sx0 = bx0 + (wv & 3) * SUBX, sy0 = by0;
+    const unsigned part = (unsigned)(wv >> 2);
     const bool live = sx0 < P.w;                              // wave-uniform (image width not a multiple of 32)
     const int sx1 = min(sx0 + SUBX - 1, P.w - 1), sy1 = by1;
     const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
@@ -915,14 +913,14 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
     const unsigned long long below = (1ull << lane) - 1ull;
     int rseg = 0;
 
-    for (unsigned base = 0, round = 0; base < nchunks; base += 4u * COARSE_CHUNKS, ++round) {
+    for (unsigned base = 0, round = 0; base < nchunks; base += 4u * PARTS * COARSE_CHUNKS, ++round) {
         unsigned *cnt = s_cnt + (round & 1u);
         // ---- phase A: this wave's share of the round's chunks against the whole tile -------------------
         unsigned cj[COARSE_CHUNKS];
         uint2 cw[COARSE_CHUNKS];
 #pragma unroll
         for (int k = 0; k < COARSE_CHUNKS; ++k) {     // all loads of the round in flight together
-            const unsigned c = base + (unsigned)wv + 4u * (unsigned)k;
+            const unsigned c = base + (unsigned)wv + 4u * PARTS * (unsigned)k;
             cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
             cw[k] = make_uint2(0x7fffu, 0x7fffu);
             if (cj[k] != 0xffffffffu) cw[k] = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)cj[k]);
@@ -945,7 +943,8 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
         const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)*cnt);
         // ---- phase B: the full test of the tile's survivors against this wave's sub-tile ----------------
         if (live) {
-            unsigned j = lane < n ? s_list[lane] : 0xffffffffu;
+            const unsigned q0 = part * 64u;
+            unsigned j = q0 + lane < n ? s_list[q0 + lane] : 0xffffffffu;
             const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);
             uint4 bb = dead;
             uint2 bs = make_uint2(0u, 0u);
@@ -953,8 +952,8 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
                 bb = bbox[2 * (size_t)j];
                 bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)j + 1);
             }
-            for (unsigned q = 0; q < n; q += 64u) {
-                const unsigned nq = q + 64u + (unsigned)lane;
+            for (unsigned q = q0; q < n; q += 64u * PARTS) {
+                const unsigned nq = q + 64u * PARTS + (unsigned)lane;
                 const unsigned nj = nq < n ? s_list[nq] : 0xffffffffu;
                 uint4 nbb = dead;
                 uint2 nbs = make_uint2(0u, 0u);
@@ -1046,41 +1045,36 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nb)
     return xcd * q + min(xcd, r) + (b >> 3);
 }
 
-// Large images: a workgroup = four sub-tiles side by side (32x16 px), one wave each.
-template <bool BOUNDED>
-__global__ __launch_bounds__(64 * FWD_WAVES) void k_render_fwd(Params P, PlanView V, float *__restrict__ img, int tiles_x,
-                                                    int tiles_y)
-{
-    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
-    (void)tiles_y;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id is uniform: keep it in an SGPR
-    const int sx0 = (bx * FWD_WAVES + wv) * SUBX, sy0 = P.row0 + by * SUBY;
-    __shared__ float4 s_stage[FWD_WAVES][128];  // per wave: up to 64 hit records of 32 B
-    if (sx0 >= P.w) return;  // wave-uniform
-    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
-    fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, 0u, 1u, s_stage[wv], ar, ag, ab);
-    fwd_store(P, V, img, sx0, sy0, lane, ar, ag, ab);
-}
-
-// Large images, two-level walk (fwd_block): same workgroup shape as k_render_fwd.
-template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_fwd2(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+// Two-level walk (fwd_block).  PARTS = 1: large images, the workgroup shape of k_render_fwd.  PARTS = 2: images
+// with fewer sub-tiles than wave slots -- eight waves, two per sub-tile, partial sums combined through LDS.
+template <bool BOUNDED, int PARTS>
+__global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView V, float *__restrict__ img, int tiles_x)
 {
     const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
     const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ float4 s_stage[4][128];
-    __shared__ unsigned s_list[COARSE_LIST];
+    __shared__ float4 s_stage[4 * PARTS][128];
+    __shared__ unsigned s_list[COARSE_LIST * PARTS];
     __shared__ unsigned s_cnt[2];
+    __shared__ float s_part[PARTS > 1 ? 4 : 1][6][64];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
     const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
-    fwd_block<BOUNDED>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
-    if (bx0 + wv * SUBX < P.w) fwd_store(P, V, img, bx0 + wv * SUBX, by0, lane, ar, ag, ab);
+    fwd_block<BOUNDED, PARTS>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
+    const int sub = wv & 3;
+    if (PARTS > 1) {   // (fwd_block ends on a barrier)
+        if (wv >= 4) {
+            float (*o)[64] = s_part[sub];
+            o[0][lane] = ar.x; o[1][lane] = ar.y; o[2][lane] = ag.x; o[3][lane] = ag.y; o[4][lane] = ab.x; o[5][lane] = ab.y;
+        }
+        __syncthreads();
+        if (wv >= 4) return;
+        float (*o)[64] = s_part[sub];
+        ar.x += o[0][lane]; ar.y += o[1][lane]; ag.x += o[2][lane]; ag.y += o[3][lane]; ab.x += o[4][lane]; ab.y += o[5][lane];
+    }
+    if (bx0 + sub * SUBX < P.w) fwd_store(P, V, img, bx0 + sub * SUBX, by0, lane, ar, ag, ab);
 }
 
 // Small images (fewer sub-tiles than the chip has wave slots, e.g. the 192x192 training crops of
@@ -1110,36 +1104,6 @@ __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V,
             ag.x += s_part[k][2][lane]; ag.y += s_part[k][3][lane];
             ab.x += s_part[k][4][lane]; ab.y += s_part[k][5][lane];
         }
-        fwd_store(P, V, img, sx0, sy0, lane, ar, ag, ab);
-    }
-}
-
-// Images with fewer sub-tiles than the chip has wave slots (4096..8191, e.g. the batched canvas of config 5):
-// two waves per sub-tile, alternate candidate chunks each, fill the machine: a workgroup = two sub-tiles side by
-// side x two parts; the odd wave hands its partial sums to the even one through LDS.  (Above 8192 sub-tiles the
-// duplicated per-wave setup costs more than the finer grain gains; below 4096 k_render_fwd_split goes further.)
-template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_fwd_pair(Params P, PlanView V, float *__restrict__ img, int subs_x)
-{
-    __shared__ float s_part[2][6][64];
-    __shared__ float4 s_stage[4][128];
-    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pairs_x = (subs_x + 1) >> 1;
-    const int sub = (int)(t % (unsigned)pairs_x) * 2 + (wv >> 1), part = wv & 1;
-    const int sx0 = sub * SUBX, sy0 = P.row0 + (int)(t / (unsigned)pairs_x) * SUBY;
-    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
-    const bool live = sx0 < P.w;   // wave-uniform (odd number of sub-tile columns)
-    if (live) fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, (unsigned)part, 2u, s_stage[wv], ar, ag, ab);
-    if (part) {
-        float (*o)[64] = s_part[wv >> 1];
-        o[0][lane] = ar.x; o[1][lane] = ar.y; o[2][lane] = ag.x; o[3][lane] = ag.y; o[4][lane] = ab.x; o[5][lane] = ab.y;
-    }
-    __syncthreads();
-    if (!part && live) {
-        float (*o)[64] = s_part[wv >> 1];
-        ar.x += o[0][lane]; ar.y += o[1][lane]; ag.x += o[2][lane]; ag.y += o[3][lane]; ab.x += o[4][lane]; ab.y += o[5][lane];
         fwd_store(P, V, img, sx0, sy0, lane, ar, ag, ab);
     }
 }
@@ -1741,51 +1705,31 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, const_cast<void *>(workspace));
     const int subs_x = (dims->w + SUBX - 1) / SUBX, tiles_y = (rows + SUBY - 1) / SUBY;
-    const int tiles_x = (subs_x + FWD_WAVES - 1) / FWD_WAVES;
     hipStream_t st = (hipStream_t)stream;
     const long nsub = (long)subs_x * tiles_y;
-#ifndef FWD_SPLIT_BELOW
-#define FWD_SPLIT_BELOW 4096
-#define FWD_SPLIT_TARGET 8192
-#endif
-    if (nsub < FWD_SPLIT_BELOW) {
+    if (nsub < 4096) {
         // fewer sub-tiles than half the chip's 8192 wave slots: split each sub-tile's Gaussian list over
         // 2..16 waves so that about one full set of waves is in flight
         int nw = 2;
-        while (nw < 16 && nsub * nw < FWD_SPLIT_TARGET) nw *= 2;
+        while (nw < 16 && nsub * nw < 8192) nw *= 2;
         const dim3 grid((unsigned)nsub), block((unsigned)nw * 64u);
         if (P.bounded)
             hipLaunchKernelGGL(k_render_fwd_split<true>, grid, block, 0, st, P, V, img, subs_x);
         else
             hipLaunchKernelGGL(k_render_fwd_split<false>, grid, block, 0, st, P, V, img, subs_x);
-#ifndef FWD_PAIR_BELOW
-#define FWD_PAIR_BELOW 8192   // fewer sub-tiles than wave slots (measured: -13% at 4608 sub-tiles, +2..14% above 8192)
-#endif
-    } else if (nsub < FWD_PAIR_BELOW) {
-        const dim3 grid((unsigned)((subs_x + 1) / 2) * (unsigned)tiles_y), block(256);
-        if (P.bounded)
-            hipLaunchKernelGGL(k_render_fwd_pair<true>, grid, block, 0, st, P, V, img, subs_x);
-        else
-            hipLaunchKernelGGL(k_render_fwd_pair<false>, grid, block, 0, st, P, V, img, subs_x);
     } else {
-#ifndef FWD_TWO_LEVEL
-#define FWD_TWO_LEVEL 1
-#endif
-        if (FWD_TWO_LEVEL) {
-            const int tx4 = (subs_x + 3) / 4;
-            const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(256);
-            if (P.bounded)
-                hipLaunchKernelGGL(k_render_fwd2<true>, grid, block, 0, st, P, V, img, tx4);
-            else
-                hipLaunchKernelGGL(k_render_fwd2<false>, grid, block, 0, st, P, V, img, tx4);
-            HIP_TRY(hipGetLastError());
-            return GSASR_OK;
+        // two-level walk; images with fewer sub-tiles than the chip has wave slots (4096..8191, e.g. the batched canvas
+        // of config 5) get two waves per sub-tile (measured -13% at 4608 sub-tiles, +2..14% above 8192)
+        const int tx4 = (subs_x + 3) / 4;
+        const bool two = nsub < 8192;
+        const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
+        if (P.bounded) {
+            if (two) hipLaunchKernelGGL((k_render_fwd2<true, 2>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd2<true, 1>), grid, block, 0, st, P, V, img, tx4);
+        } else {
+            if (two) hipLaunchKernelGGL((k_render_fwd2<false, 2>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd2<false, 1>), grid, block, 0, st, P, V, img, tx4);
         }
-        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(64 * FWD_WAVES);
-        if (P.bounded)
-            hipLaunchKernelGGL(k_render_fwd<true>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
-        else
-            hipLaunchKernelGGL(k_render_fwd<false>, grid, block, 0, st, P, V, img, tiles_x, tiles_y);
     }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
