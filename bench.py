@@ -371,6 +371,23 @@ def main():
             print(f"[bench] graph capture unavailable ({e!r}); timing eager launches", file=sys.stderr)
             graph = None
     run = (lambda: graph.replay()) if graph is not None else step
+    if graph is not None:
+        # replaying the graph is not always the faster way to enqueue a step: on this stack the five-node graph costs
+        # ~7 us per replay more than plain stream launches, which the GPU pipelines back to back.  Time both, keep the
+        # faster (the choice is reported as config.launch).
+        def quick(fn, n=20):
+            fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / n
+        t_graph, t_eager = quick(run), quick(step)
+        if t_eager < t_graph:
+            run, launch = step, "eager (faster than hipgraph replay: %.1f vs %.1f us/step)" % (t_eager * 1e6, t_graph * 1e6)
+        else:
+            launch = "hipgraph (faster than eager: %.1f vs %.1f us/step)" % (t_graph * 1e6, t_eager * 1e6)
 
     for _ in range(args.warmup):
         run()
