@@ -827,3 +827,26 @@ def test_forward_pair_kernel_range_against_oracle(dev):
     assert 4096 <= ((W + 7) // 8) * ((H + 15) // 16) < 8192
     for dmax in (0.05, None):
         _check(sig, xy, col, H, W, dmax, dev, wgt)
+
+
+def test_batched_canvas_large_enough_for_the_two_level_forward(dev):
+    """a canvas with >= 8192 sub-tiles (16 slots of 256 rows x 256 columns) goes through the two-level forward with
+    per-sample px tables; ragged sizes, compared with single-image calls"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    sizes = [(256, 256), (250, 199), (256, 256), (131, 256)] * 4
+    p, scales, sms = _batch_case(dev, sizes, lr=(16, 16), seed=220)
+    kw = dict(if_dmax=True, dmax_mode="fix", dmax=0.2)
+    pa = p.clone().requires_grad_(True)
+    out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, scales, sms, **kw)
+    assert out.shape == (16, 3, 256, 256)
+    wgt = torch.rand(out.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    (out * wgt).sum().backward()
+    for b in (0, 1, 3, 9, 15):
+        h, w = sizes[b]
+        pb = p[b].clone().requires_grad_(True)
+        ref = gsp.generate_2D_gaussian_splatting_step((h, w), pb, scales[b], sms[b], **kw)
+        assert float((out[b, :, :h, :w] - ref).detach().abs().max()) <= 2e-6
+        o = out[b].detach()
+        assert float(o[:, h:, :].abs().max() if h < 256 else 0.0) == 0.0 and float(o[:, :, w:].abs().max() if w < 256 else 0.0) == 0.0
+        (ref * wgt[b, :, :h, :w]).sum().backward()
+        assert float((pa.grad[b] - pb.grad).abs().max()) <= 1e-5 * float(pb.grad.abs().max())
