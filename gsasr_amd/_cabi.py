@@ -124,6 +124,24 @@ def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _Nop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOP = _Nop()
+
+
+def _on(device: torch.device):
+    """`torch.cuda.device(device)` only when it is not the current device already (the context manager costs ~10 us,
+    a third of a call's host time on the single-GPU-per-process layout this package is meant for)"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _NOP if idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+
 @dataclass
 class Plan:
     """Binning workspace of one (sigmas, coords, colors, dims): shared by forward and backward."""
@@ -156,7 +174,7 @@ def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
     if nbytes == 0:
         check(-1, "gsasr_splat_workspace_bytes")
     dev = sigmas.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(L.gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), ws.data_ptr(), nbytes, _stream(dev)),
               "gsasr_splat_plan")
@@ -179,7 +197,7 @@ def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = Fal
     if (img.shape[0] != (3 if chw else rows)) or img.dim() != 3 or img.device != p.device:
         raise RuntimeError("rendered_img does not match the plan (shape / device)")
     d = _dims_with(p, (FLAG_OVERWRITE_IMAGE if overwrite else 0) | (FLAG_CHW_IMAGE if chw else 0))
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         check(lib().gsasr_splat_forward(ctypes.byref(d), p.workspace.data_ptr(), p.workspace.numel(), pi,
                                         _stream(p.device)), "gsasr_splat_forward")
     return img
@@ -193,7 +211,7 @@ def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_co
     if grad_img.shape[0] != p.dims.row1 - p.dims.row0:
         raise RuntimeError("grads does not match the plan's row band")
     d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
 
@@ -218,7 +236,7 @@ def plan_packed(packed: torch.Tensor, h: int, w: int, dmax: Optional[float],
     if nbytes == 0:
         check(-1, "gsasr_splat_workspace_bytes")
     dev = packed.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if ws.numel() < nbytes:
             raise RuntimeError("workspace smaller than gsasr_splat_workspace_bytes()")
@@ -238,7 +256,7 @@ def backward_packed(p: Plan, packed: torch.Tensor, grad_img: torch.Tensor, g_pac
     if grad_img.shape[0] != p.dims.row1 - p.dims.row0 or g_packed.shape[0] != p.dims.s or packed.shape[0] != p.dims.s:
         raise RuntimeError("grads / g_packed do not match the plan")
     d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         check(lib().gsasr_splat_backward(ps, pc, pk, pg, gs, gc, gk, ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
 
@@ -258,7 +276,7 @@ def band_select(packed: torch.Tensor, h: int, w: int, dmax: Optional[float], row
     if down.shape[0] != cap:
         raise RuntimeError("up and down must have the same capacity")
     d = make_dims(packed.shape[0], h, w, dmax, rows, cutoff, FLAG_STRIDE8)
-    with torch.cuda.device(packed.device):
+    with _on(packed.device):
         check(lib().gsasr_band_select(base, ctypes.byref(d), int(rows_above), int(rows_below), cap,
                                       _chk(up, "up", (8,)), _chk(down, "down", (8,)), _chk_i32(up_index, "up_index", cap),
                                       _chk_i32(down_index, "down_index", cap), _chk_i32(counts, "counts", 4),
@@ -269,7 +287,7 @@ def band_merge(g_packed: torch.Tensor, g_up: torch.Tensor, g_down: torch.Tensor,
                down_index: torch.Tensor, counts: torch.Tensor) -> None:
     """gsasr_band_merge: g_packed[index] += the gradients the neighbours returned for the selected records."""
     cap = g_up.shape[0]
-    with torch.cuda.device(g_packed.device):
+    with _on(g_packed.device):
         check(lib().gsasr_band_merge(_chk(g_packed, "g_packed", (8,)), g_packed.shape[0], _chk(g_up, "g_up", (8,)),
                                      _chk(g_down, "g_down", (8,)), _chk_i32(up_index, "up_index", cap),
                                      _chk_i32(down_index, "down_index", cap), _chk_i32(counts, "counts", 4), cap,
@@ -282,7 +300,7 @@ def prologue_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w:
     ps = _chk(step, "step_size")
     n, dev = gs_parameters.shape[0], gs_parameters.device
     out = (torch.empty(n, 3, device=dev), torch.empty(n, 2, device=dev), torch.empty(n, 3, device=dev))
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().gsasr_prologue_forward(pp, ps, n, int(h), int(w), out[0].data_ptr(), out[1].data_ptr(),
                                            out[2].data_ptr(), _stream(dev)), "gsasr_prologue_forward")
     return out
@@ -294,7 +312,7 @@ def prologue_backward(gs_parameters, step, h: int, w: int, g_sigmas, g_coords, g
     ptrs = [_chk(g_sigmas, "g_sigmas", (3,)), _chk(g_coords, "g_coords", (2,)), _chk(g_colors, "g_colors", (3,))]
     n, dev = gs_parameters.shape[0], gs_parameters.device
     gp = torch.empty(n, 9, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().gsasr_prologue_backward(pp, ps, n, int(h), int(w), *ptrs, gp.data_ptr(), _stream(dev)),
               "gsasr_prologue_backward")
     return gp
@@ -312,7 +330,7 @@ def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int
     nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
         check(-1, "gsasr_step_workspace_bytes")
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         img = torch.empty(3, int(h), int(w), dtype=torch.float32, device=dev)
         check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), _stream(dev)),
@@ -325,7 +343,7 @@ def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(step, "step_size")
     pg = _chk(grad_hwc, "grads", (p.dims.h, p.dims.w, 3))
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         gp = torch.empty_like(gs_parameters)
         check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
                                         p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
@@ -368,7 +386,7 @@ def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax:
     if nbytes == 0:
         check(-1, "gsasr_step_workspace_bytes")
     dev = gs_parameters.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         img = torch.empty(B, 3, d.slot, w_max, dtype=torch.float32, device=dev)
         check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), _stream(dev)),
@@ -381,7 +399,7 @@ def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, gr
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(steps, "step_sizes")
     pg = _chk(grad_bhwc, "grads", (p.dims.batch, p.dims.slot, p.dims.w, 3))
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         gp = torch.empty_like(gs_parameters)
         check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
                                         p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
