@@ -850,3 +850,17 @@ def test_batched_canvas_large_enough_for_the_two_level_forward(dev):
         assert float(o[:, h:, :].abs().max() if h < 256 else 0.0) == 0.0 and float(o[:, :, w:].abs().max() if w < 256 else 0.0) == 0.0
         (ref * wgt[b, :, :h, :w]).sum().backward()
         assert float((pa.grad[b] - pb.grad).abs().max()) <= 1e-5 * float(pb.grad.abs().max())
+
+
+def test_large_image_many_rounds_against_oracle(dev):
+    """a large image (4090 x 2048 px: 512 x 128 sub-tiles, eight rounds of waves) against the oracle -- sparse
+    Gaussians so that the oracle stays cheap; box active / support inside the box; width not a multiple of 8"""
+    rng = np.random.default_rng(230)
+    H, W, s = 2048, 4090, 1500
+    assert ((W + 7) // 8) * ((H + 15) // 16) >= 65536
+    sig = np.stack([10 ** rng.uniform(-3.0, -1.7, s), 10 ** rng.uniform(-3.0, -1.7, s), rng.uniform(-0.9, 0.9, s)], 1).astype(np.float32)
+    xy = rng.uniform(-1.02, 1.02, (s, 2)).astype(np.float32)
+    col = rng.uniform(0, 1, (s, 3)).astype(np.float32)
+    wgt = rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)
+    for dmax in (0.004, 0.05):
+        _check(sig, xy, col, H, W, dmax, dev, wgt)
