@@ -1427,8 +1427,10 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
     bwd_write(d, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
 }
 
+// (occupancy targets: the unrolled sweep fits 6 waves per SIMD at the price of five spilled dwords, -2.7% at config 4;
+// forcing the plain sweep to 8 costs more in spills than it gains)
 template <bool BOUNDED, bool UNROLL>
-__global__ __launch_bounds__(64 * BWD_WAVES) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
+__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(UNROLL ? 6 : 7))) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
                                                     float *__restrict__ g_sigmas, float *__restrict__ g_coords,
                                                     float *__restrict__ g_colors)
 {
