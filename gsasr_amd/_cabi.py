@@ -24,6 +24,8 @@ EXPORTS = (
     "gsasr_get_default_cutoff", "gsasr_prologue_forward", "gsasr_prologue_backward",
     "gsasr_step_workspace_bytes", "gsasr_step_forward", "gsasr_step_backward",
     "gsasr_band_select", "gsasr_band_merge", "gsasr_resolve_cutoff",
+    "gsasr_sample_workspace_bytes", "gsasr_splat_sample_forward", "gsasr_splat_sample_backward",
+    "gsasr_step_sample_forward", "gsasr_step_sample_backward",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -88,6 +90,16 @@ def lib():
         L.gsasr_band_select.argtypes = [vp, dp, i, i, i, vp, vp, vp, vp, vp, vp]
         L.gsasr_band_merge.restype = i
         L.gsasr_band_merge.argtypes = [vp, i, vp, vp, vp, vp, vp, i, vp]
+        L.gsasr_sample_workspace_bytes.restype = sz
+        L.gsasr_sample_workspace_bytes.argtypes = [dp, i]
+        L.gsasr_splat_sample_forward.restype = i
+        L.gsasr_splat_sample_forward.argtypes = [dp, vp, sz, vp, i, vp, vp, sz, vp]
+        L.gsasr_splat_sample_backward.restype = i
+        L.gsasr_splat_sample_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, dp, vp, sz, vp, i, vp, sz, vp]
+        L.gsasr_step_sample_forward.restype = i
+        L.gsasr_step_sample_forward.argtypes = [vp, vp, dp, vp, sz, vp, i, vp, vp, sz, vp]
+        L.gsasr_step_sample_backward.restype = i
+        L.gsasr_step_sample_backward.argtypes = [vp, vp, vp, vp, dp, vp, sz, vp, i, vp, sz, vp]
         L.gsasr_set_default_cutoff.restype = None
         L.gsasr_set_default_cutoff.argtypes = [f]
         L.gsasr_get_default_cutoff.restype = f
@@ -403,6 +415,113 @@ def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, gr
         gp = torch.empty_like(gs_parameters)
         check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
                                         p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
+    return gp
+
+
+# ---- sampled pixels ----------------------------------------------------------------
+def _points(points: torch.Tensor, batch: int, device) -> Tuple[torch.Tensor, int]:
+    """`[S,2]` (one image) or `[B,S,2]` (batched canvas) integer (row, column) pairs -> contiguous int32 on `device`."""
+    if not (isinstance(points, torch.Tensor) and not points.dtype.is_floating_point and points.dtype != torch.bool
+            and points.shape[-1:] == (2,) and points.dim() == (3 if batch > 1 else 2)
+            and (batch <= 1 or points.shape[0] == batch)):
+        raise RuntimeError("points must be an integer tensor [S,2] (or [B,S,2] for a batched canvas)")
+    return points.to(device=device, dtype=torch.int32).contiguous(), int(points.shape[-2])
+
+
+def _sample_ws(d: Dims, n_points: int, dev) -> torch.Tensor:
+    nbytes = lib().gsasr_sample_workspace_bytes(ctypes.byref(d), n_points)
+    if nbytes == 0:
+        check(-1, "gsasr_sample_workspace_bytes")
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
+def sample_forward(p: Plan, points: torch.Tensor):
+    """values of the splat at `points` only: `[3,S]` (`[B,3,S]` on a batched canvas) + the state for `sample_backward`."""
+    B = max(int(p.dims.batch), 1)
+    pts, n = _points(points, B, p.device)
+    with _on(p.device):
+        sws = _sample_ws(p.dims, n, p.device)
+        out = torch.empty((B, 3, n) if B > 1 else (3, n), dtype=torch.float32, device=p.device)
+        check(lib().gsasr_splat_sample_forward(ctypes.byref(p.dims), p.workspace.data_ptr(), p.workspace.numel(),
+                                               pts.data_ptr(), n, out.data_ptr(), sws.data_ptr(), sws.numel(),
+                                               _stream(p.device)), "gsasr_splat_sample_forward")
+    return out, (pts, n, sws)
+
+
+def sample_backward(p: Plan, state, sigmas, coords, colors, grad_out, g_sigmas, g_coords, g_colors,
+                    overwrite: bool = False, resort: bool = False) -> None:
+    """g_* (+)= gradient of sum(grad_out * sample_forward(...)); `state` is what `sample_forward` returned."""
+    pts, n, sws = state
+    B = max(int(p.dims.batch), 1)
+    ptrs = [_chk(sigmas, "sigmas", (3,)), _chk(coords, "coords", (2,)), _chk(colors, "colors", (3,)),
+            _chk(grad_out, "grad_out", (3, n)), _chk(g_sigmas, "grads_sigmas", (3,)),
+            _chk(g_coords, "grads_coords", (2,)), _chk(g_colors, "grads_colors", (3,))]
+    if grad_out.numel() != B * 3 * n:
+        raise RuntimeError("grad_out does not match the points")
+    d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
+    with _on(p.device):
+        check(lib().gsasr_splat_sample_backward(*ptrs, ctypes.byref(d), p.workspace.data_ptr(), p.workspace.numel(),
+                                                pts.data_ptr() if resort else None, n, sws.data_ptr(), sws.numel(),
+                                                _stream(p.device)), "gsasr_splat_sample_backward")
+
+
+def step_sample_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float],
+                        points: torch.Tensor):
+    """prologue + plan + sampled forward in ONE call: raw `gs_parameters[N,9]` -> `[3,S]`."""
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(step, "step_size")
+    if dmax is not None and not (float(dmax) >= 0.0):
+        raise RuntimeError("dmax must be >= 0")
+    dev = gs_parameters.device
+    d = make_dims(gs_parameters.shape[0], h, w, dmax)
+    return _step_sample_forward(d, pp, ps, points, dev)
+
+
+def batch_sample_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax: Optional[float],
+                         points: torch.Tensor):
+    """the same for a whole batch: `gs_parameters` [B,N,9], `points` [B,S,2] on each sample's own grid -> `[B,3,S]`."""
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(steps, "step_sizes")
+    if gs_parameters.dim() != 3 or steps.numel() != gs_parameters.shape[0] or len(sizes) != gs_parameters.shape[0]:
+        raise RuntimeError("gs_parameters must be [B,N,9] with one step size and one (h,w) per sample")
+    if dmax is not None and not (float(dmax) >= 0.0):
+        raise RuntimeError("dmax must be >= 0")
+    h_max, w_max = max(h for h, _ in sizes), max(w for _, w in sizes)
+    d = make_batch_dims(gs_parameters.shape[1], sizes, w_max, h_max, dmax)
+    return _step_sample_forward(d, pp, ps, points, gs_parameters.device)
+
+
+def _step_sample_forward(d: Dims, pp: int, ps: int, points: torch.Tensor, dev):
+    L = lib()
+    B = max(int(d.batch), 1)
+    pts, n = _points(points, B, dev)
+    nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        check(-1, "gsasr_step_workspace_bytes")
+    with _on(dev):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sws = _sample_ws(d, n, dev)
+        out = torch.empty((B, 3, n) if B > 1 else (3, n), dtype=torch.float32, device=dev)
+        check(L.gsasr_step_sample_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, pts.data_ptr(), n,
+                                          out.data_ptr(), sws.data_ptr(), sws.numel(), _stream(dev)),
+              "gsasr_step_sample_forward")
+    return out, Plan(d, ws, dev), (pts, n, sws)
+
+
+def step_sample_backward(p: Plan, state, gs_parameters: torch.Tensor, step: torch.Tensor,
+                         grad_out: torch.Tensor) -> torch.Tensor:
+    """sampled backward + prologue backward in ONE call; returns d/d gs_parameters (`[N,9]` or `[B,N,9]`)."""
+    pts, n, sws = state
+    pp = _chk(gs_parameters, "gs_parameters", (9,))
+    ps = _chk(step, "step_size")
+    pg = _chk(grad_out, "grad_out", (3, n))
+    if grad_out.numel() != max(int(p.dims.batch), 1) * 3 * n:
+        raise RuntimeError("grad_out does not match the points")
+    with _on(p.device):
+        gp = torch.empty_like(gs_parameters)
+        check(lib().gsasr_step_sample_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
+                                               p.workspace.numel(), None, n, sws.data_ptr(), sws.numel(),
+                                               _stream(p.device)), "gsasr_step_sample_backward")
     return gp
 
 

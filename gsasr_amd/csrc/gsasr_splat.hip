@@ -1470,6 +1470,382 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// sampled pixels.  The reference renders the whole image and then picks `sample_coords`
+// out of it (utils/gaussian_splatting.py:214-216); here only the requested points are evaluated.
+//   k_pts_sort    one workgroup: counting sort of the points into point-cells (at most 64 x 64 of them, the
+//                 histogram and its scan live in LDS); out-of-range points go to a last bucket.
+//   k_sample_fwd  POINT-stationary: one wave64 = one point, its lanes spread over the Gaussians binned within
+//                 reach (the forward's candidate walk with a 1x1 tile); no atomics, one wave reduction.
+//   k_sample_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian, its lanes spread over the sorted points of the
+//                 point-cells its window touches; same epilogue as k_render_bwd.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PT_CELLS = 12288;                    // point-cells at most: their histogram + scan live in LDS (48 KB)
+constexpr int PT_MAX_SHIFT = 9;                    // point-cells are 16..512 px a side
+
+struct PtView {
+    unsigned *start;   // [ncx*ncy + 2] exclusive scan of the points per point-cell; [ncx*ncy] = first invalid point
+    float4 *sorted;    // [n] {px, py, X | canvas row << 16, original index}: everything a kernel needs about a point
+    int shx, shy, ncx, ncy;
+};
+
+constexpr int PT_BATCH = 8;
+
+__device__ __forceinline__ int2 point_rc(int2 raw, const Geo &g)
+{
+    int r = raw.x, c = raw.y;
+    if (r < 0) r += g.h;   // Python's wrap-around of negative indices
+    if (c < 0) c += g.w;
+    return make_int2(r, c);
+}
+
+__global__ __launch_bounds__(1024) void k_pts_sort(Params P, PlanView V, PtView S, const int *__restrict__ pts,
+                                                   int n_total, int n_per)
+{
+    __shared__ unsigned s_cell[PT_CELLS + 1], s_wave[16];   // histogram, then (scanned in place) the fill cursors
+    __shared__ int4 s_geo[GSASR_MAX_BATCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int npc = S.ncx * S.ncy;
+    for (int k = tid; k <= npc; k += 1024) s_cell[k] = 0u;
+    if (tid < P.batch) s_geo[tid] = P.batch > 1 ? V.geo[tid] : make_int4(P.h, P.w, 0, 0);
+    __syncthreads();
+    // (one workgroup: its run time is the length of its dependent chains, so the loads of PT_BATCH points are issued
+    // together)
+    for (int i0 = tid; i0 < n_total; i0 += 1024 * PT_BATCH) {
+        int2 raw[PT_BATCH];
+#pragma unroll
+        for (int k = 0; k < PT_BATCH; ++k) {
+            const int i = i0 + 1024 * k;
+            raw[k] = i < n_total ? reinterpret_cast<const int2 *>(pts)[i] : make_int2(0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < PT_BATCH; ++k) {
+            const int i = i0 + 1024 * k;
+            if (i >= n_total) continue;
+            const int4 gg = s_geo[i / n_per];
+            const Geo g{gg.x, gg.y, gg.z, gg.w};
+            const int2 rc = point_rc(raw[k], g);
+            const bool ok = rc.x >= 0 && rc.x < g.h && rc.y >= 0 && rc.y < g.w;
+            atomicAdd(&s_cell[ok ? ((g.base + rc.x) >> S.shy) * S.ncx + (rc.y >> S.shx) : npc], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of npc + 1 counts: consecutive entries per thread, wave scan, 16 wave totals
+    constexpr int PER = (PT_CELLS + 1 + 1023) / 1024;
+    unsigned loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = tid * PER + k;
+        loc[k] = e <= npc ? s_cell[e] : 0u;
+        sum += loc[k];
+    }
+    unsigned inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < wv; ++k) base += s_wave[k];
+    unsigned run = base + inc - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = tid * PER + k;
+        if (e <= npc) {
+            s_cell[e] = run;
+            S.start[e] = run;
+        }
+        run += loc[k];
+    }
+    if (tid == 0) S.start[npc + 1] = (unsigned)n_total;
+    __syncthreads();
+    for (int i0 = tid; i0 < n_total; i0 += 1024 * PT_BATCH) {
+        int2 raw[PT_BATCH];
+#pragma unroll
+        for (int k = 0; k < PT_BATCH; ++k) {
+            const int i = i0 + 1024 * k;
+            raw[k] = i < n_total ? reinterpret_cast<const int2 *>(pts)[i] : make_int2(0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < PT_BATCH; ++k) {
+            const int i = i0 + 1024 * k;
+            if (i >= n_total) continue;
+            const int4 gg = s_geo[i / n_per];
+            const Geo g{gg.x, gg.y, gg.z, gg.w};
+            const int2 rc = point_rc(raw[k], g);
+            const bool ok = rc.x >= 0 && rc.x < g.h && rc.y >= 0 && rc.y < g.w;
+            const int Y = g.base + rc.x;
+            const unsigned pos = atomicAdd(&s_cell[ok ? (Y >> S.shy) * S.ncx + (rc.y >> S.shx) : npc], 1u);
+            S.sorted[pos] = ok ? make_float4(V.px[g.pxo + rc.y], V.py[Y], __uint_as_float((unsigned)rc.y | ((unsigned)Y << 16)),
+                                             __uint_as_float((unsigned)i))
+                               : make_float4(0.f, 0.f, 0.f, __uint_as_float((unsigned)i));
+        }
+    }
+}
+
+// wave64 sum without LDS traffic: four DPP row shifts leave each row's total in its lane 0
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v += dpp_row_shl<8>(v);
+    v += dpp_row_shl<4>(v);
+    v += dpp_row_shl<2>(v);
+    v += dpp_row_shl<1>(v);
+    const int i = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
+}
+
+// Forward at the points of ONE point-cell per workgroup, as a two-level walk (cf. fwd_block): the four waves test the
+// Gaussians binned within reach of the cell's rectangle once, cooperatively, into a survivor list in LDS (rounds of
+// SAMPLE_LIST candidates: one batch of loads per wave); then every lane takes a survivor, loads it ONCE and evaluates
+// it at SAMPLE_GROUP points at a time (the cell's points sit in LDS, read as broadcasts); the per-point colour sums
+// are reduced over the wave with DPP and over the waves in LDS.  Everything here is a short dependent chain, so the
+// kernel is built to keep many workgroups resident (64 VGPRs, 10 KB of LDS).  Block ncx*ncy zeroes the outputs of
+// the out-of-range points.
+constexpr int SAMPLE_WAVES = 4;
+constexpr int SAMPLE_CHUNKS = 8;                                  // coarse chunks per wave and batch of loads
+constexpr int SAMPLE_BATCHES = 4;                                 // batches per round (no barrier between them)
+constexpr int SAMPLE_LIST = SAMPLE_WAVES * SAMPLE_CHUNKS * SAMPLE_BATCHES * 64;   // candidates per round = capacity of the list
+constexpr int SAMPLE_BLOCK = 24;   // points of a cell evaluated per walk: their sums stay in registers (72 VGPRs; 32 spills at 4 waves per SIMD)
+
+// One Gaussian per lane against the points staged in LDS (broadcast reads), two points per packed-fp32 operation.
+template <bool TEST>
+__device__ __forceinline__ void sample_eval(const float4 *s_pt, int npb, const float4 a, const float4 b, float dmax,
+                                            v2f (&acc)[SAMPLE_BLOCK / 2][3])
+{
+#pragma unroll
+    for (int k = 0; k < SAMPLE_BLOCK / 2; ++k) {
+        if (2 * k >= npb) continue;   // (uniform; an odd last point pairs with a stale entry that is never written out)
+        const float4 p0 = s_pt[2 * k], p1 = s_pt[2 * k + 1];
+        const v2f dx = (v2f){p0.x, p1.x} - a.x, dy = (v2f){p0.y, p1.y} - a.y;
+        const v2f adx = a.z * dx, bdx = a.w * dx;
+        const v2f t = b.x * dy + bdx;
+        const v2f pw = dy * t + adx * dx;
+        v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+        if (TEST) {   // (dmax = +inf for the lanes whose Gaussian needs no test)
+            v.x = fmaxf(fabsf(dx.x), fabsf(dy.x)) <= dmax ? v.x : 0.f;
+            v.y = fmaxf(fabsf(dx.y), fabsf(dy.y)) <= dmax ? v.y : 0.f;
+        }
+        acc[k][0] += v * b.y;
+        acc[k][1] += v * b.z;
+        acc[k][2] += v * b.w;
+    }
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_sample_fwd(Params P, PlanView V, PtView S, int n_per,
+                                                                 float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cell = blockIdx.x, npc = S.ncx * S.ncy;
+    const unsigned pbeg = S.start[cell], pend = S.start[cell + 1];
+    if (pbeg == pend) return;
+    if (cell == npc) {   // out of range: nothing is rendered there
+        for (unsigned i = pbeg + threadIdx.x; i < pend; i += 64 * SAMPLE_WAVES) {
+            const int idx = (int)__float_as_uint(S.sorted[i].w), smp = idx / n_per;
+            float *o = out + (size_t)smp * 3 * n_per + (idx - smp * n_per);
+            o[0] = 0.f; o[(size_t)n_per] = 0.f; o[2 * (size_t)n_per] = 0.f;
+        }
+        return;
+    }
+    __shared__ unsigned s_list[SAMPLE_LIST];
+    __shared__ unsigned s_cnt[2];
+    __shared__ float4 s_pt[SAMPLE_BLOCK];      // {px, py, X | Y << 16, original index}
+    __shared__ float s_acc[3 * SAMPLE_BLOCK];
+    const int bx0 = (cell % S.ncx) << S.shx, by0 = (cell / S.ncx) << S.shy;
+    const int bx1 = min(bx0 + (1 << S.shx), P.w) - 1, by1 = min(by0 + (1 << S.shy), P.h) - 1;
+    const float4 *__restrict__ rec = V.rec;
+    const uint4 *__restrict__ bbox = V.bbox;
+    const unsigned *__restrict__ cs = V.cell_start;
+
+    // segment table of the rectangle (every wave builds the same one)
+    const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    int nseg = 0;
+    unsigned sbeg = 0, send = 0;
+    if (rx > 0) {
+        const int cx0 = max(bx0 - rx, 0) >> CELL_SHIFT, cx1 = min((bx1 + rx) >> CELL_SHIFT, P.ncx - 1);
+        const int cy0 = max(by0 - ry, 0) >> CELL_SHIFT, cy1 = min((by1 + ry) >> CELL_SHIFT, P.ncy - 1);
+        nseg = cy1 - cy0 + 1;     // <= (512 + 2*128)/16 + 1 = 49
+        if (lane < nseg) {
+            sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+            send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
+        }
+    }
+    if (lane == nseg) {
+        sbeg = cs[P.ncells];
+        send = cs[P.ncells + 1];
+    }
+    ++nseg;
+    const unsigned len = send - sbeg;
+    unsigned pin = len;
+    for (int k = 1; k < 64; k <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)pin, k);
+        if (lane >= k) pin += v;
+    }
+    const unsigned pex = pin - len;
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+    const unsigned nchunks = (total + 63u) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    for (unsigned pb = pbeg; pb < pend; pb += SAMPLE_BLOCK) {   // (more than SAMPLE_BLOCK points in a cell: walk again)
+        const int npb = (int)min((unsigned)SAMPLE_BLOCK, pend - pb);
+        if ((int)threadIdx.x < npb) s_pt[threadIdx.x] = S.sorted[pb + threadIdx.x];
+        if (threadIdx.x < 3 * SAMPLE_BLOCK) s_acc[threadIdx.x] = 0.f;
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        int rseg = 0;
+        v2f acc[SAMPLE_BLOCK / 2][3];   // per lane: colour sums of the block's points, two points per register pair
+#pragma unroll
+        for (int k = 0; k < SAMPLE_BLOCK / 2; ++k) acc[k][0] = acc[k][1] = acc[k][2] = (v2f){0.f, 0.f};
+        for (unsigned base = 0, round = 0; base < nchunks; base += SAMPLE_WAVES * SAMPLE_CHUNKS * SAMPLE_BATCHES, ++round) {
+            unsigned *cnt = s_cnt + (round & 1u);
+            // ---- level 1: this wave's chunks of the round against the cell's rectangle, 8 loads in flight ----
+            for (unsigned bb0 = base; bb0 < min(nchunks, base + SAMPLE_WAVES * SAMPLE_CHUNKS * SAMPLE_BATCHES);
+                 bb0 += SAMPLE_WAVES * SAMPLE_CHUNKS) {
+                unsigned cj[SAMPLE_CHUNKS];
+                uint2 cw[SAMPLE_CHUNKS];
+#pragma unroll
+                for (int k = 0; k < SAMPLE_CHUNKS; ++k) {
+                    const unsigned c = bb0 + (unsigned)wv + SAMPLE_WAVES * (unsigned)k;
+                    cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
+                    cw[k] = make_uint2(0x7fffu, 0x7fffu);
+                    if (cj[k] != 0xffffffffu) cw[k] = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)cj[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < SAMPLE_CHUNKS; ++k) {
+                    const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
+                    const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
+                    const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
+                    const unsigned long long m = __ballot(hit);
+                    if (m) {
+                        unsigned at = 0;
+                        if (lane == 0) at = atomicAdd(cnt, (unsigned)__builtin_popcountll(m));
+                        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+                        if (hit) s_list[at + (unsigned)__builtin_popcountll(m & below)] = cj[k];
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0u;
+            const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)*cnt);
+            // ---- level 2: a survivor per lane, loaded once, evaluated at every point of the block -------------
+            // No window test per point: a Gaussian's terms outside its window are below exp(-tau) (that is what the
+            // window means), so adding them is as exact as skipping them; only the dmax box must be honoured.
+            // (the next survivor's record is in flight while the current one is evaluated)
+            unsigned q = (unsigned)wv * 64u;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;   // {x, y, A, B}, {C, r, g, b}; dead lanes add 0 * v
+            bool test = false;
+            if (q + (unsigned)lane < n) {
+                const unsigned j = s_list[q + lane];
+                a = rec[2 * (size_t)j];
+                b = rec[2 * (size_t)j + 1];
+                if (BOUNDED) test = (bbox[2 * (size_t)j].x & 0x8000u) != 0u;
+            }
+            while (q < n) {
+                asm volatile("" ::: "memory");   // re-read the points from LDS every trip: hoisted, they cost 96 VGPRs
+                const unsigned nq = q + 64u * SAMPLE_WAVES;
+                float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+                bool ntest = false;
+                if (nq + (unsigned)lane < n) {
+                    const unsigned j = s_list[nq + lane];
+                    na = rec[2 * (size_t)j];
+                    nb = rec[2 * (size_t)j + 1];
+                    if (BOUNDED) ntest = (bbox[2 * (size_t)j].x & 0x8000u) != 0u;
+                }
+                // (one code path: an `if (any lane needs the test)` around two instantiations makes the compiler keep
+                // two copies of the accumulators -- 200 spilled dwords; the test is 3 instructions per point)
+                sample_eval<BOUNDED>(s_pt, npb, a, b, test ? P.dmax : INFINITY, acc);
+                q = nq; a = na; b = nb; test = ntest;
+            }
+            __syncthreads();   // the list is rewritten in the next round
+        }
+        // one reduction per block: over the lanes with DPP, over the waves in LDS
+#pragma unroll
+        for (int k = 0; k < SAMPLE_BLOCK / 2; ++k) {
+            if (2 * k >= npb) continue;   // (uniform)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t0 = wave_sum_dpp(acc[k][c].x), t1 = wave_sum_dpp(acc[k][c].y);
+                if (lane == 0) {
+                    atomicAdd(&s_acc[3 * (2 * k) + c], t0);
+                    atomicAdd(&s_acc[3 * (2 * k + 1) + c], t1);
+                }
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 3 * npb) {
+            const int k = threadIdx.x / 3, c = threadIdx.x - 3 * k;
+            const int idx = (int)__float_as_uint(s_pt[k].w), smp = idx / n_per;
+            out[((size_t)smp * 3 + c) * n_per + (idx - smp * n_per)] = s_acc[threadIdx.x];   // [B, 3, n_per]
+        }
+        __syncthreads();   // s_pt / s_acc are rewritten for the next block of points
+    }
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) void k_sample_bwd(Params P, PlanView V, PtView S, int n_per,
+                                                    const float *__restrict__ grad_out, float *__restrict__ g_sigmas,
+                                                    float *__restrict__ g_coords, float *__restrict__ g_colors)
+{
+    constexpr float HALF_LOG2E = 0.72134752044448170368f;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned gw = blockIdx.x * 4u + (unsigned)wv;
+    if (gw >= (unsigned)P.s) return;
+    __shared__ __attribute__((aligned(16))) float s_red[4][512];
+    BwdRec G;
+    bwd_fetch(V, gw, G);
+    const u4v bb = G.bb;
+    const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+    const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+    const bool dead = c0 > c1;
+    if (dead && !(P.flags & GSASR_FLAG_OVERWRITE_GRADS)) return;
+    const float x = __uint_as_float(G.rec[0]), y = __uint_as_float(G.rec[1]);
+    const float cr = __uint_as_float(G.rec[5]), cg = __uint_as_float(G.rec[6]), cb = __uint_as_float(G.rec[7]);
+    const float cinv = __uint_as_float(G.fin[0]), kappa = __uint_as_float(G.fin[1]), rho = __uint_as_float(G.fin[2]);
+    const float isx = __uint_as_float(G.fin[3]), isy = __uint_as_float(G.fin[4]);
+    const int smp = (int)G.fin[6];
+    const float *__restrict__ go = grad_out + (size_t)smp * 3 * n_per - (size_t)smp * n_per;   // + original index
+    const bool test = BOUNDED && (bb.x & 0x8000u);
+    const float nK1 = -HALF_LOG2E * cinv;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!dead) {
+        const int pcx0 = c0 >> S.shx, pcx1 = c1 >> S.shx, pcy1 = r1 >> S.shy;
+        for (int pcy0 = r0 >> S.shy; pcy0 <= pcy1; pcy0 += 64) {   // (more than 64 rows of point-cells: large class only)
+        const int nrows = min(pcy1 - pcy0 + 1, 64);
+        unsigned sbeg = 0, send = 0;
+        if (lane < nrows) {
+            sbeg = S.start[(pcy0 + lane) * S.ncx + pcx0];
+            send = S.start[(pcy0 + lane) * S.ncx + pcx1 + 1];
+        }
+        for (int r = 0; r < nrows; ++r) {
+            const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)send, r);
+            for (unsigned i = (unsigned)__builtin_amdgcn_readlane((int)sbeg, r) + (unsigned)lane; i < e; i += 64u) {
+                const float4 pt = S.sorted[i];
+                const unsigned pxy = __float_as_uint(pt.z);
+                const int X = (int)(pxy & 0xffffu), Y = (int)(pxy >> 16);
+                if (X < c0 || X > c1 || Y < r0 || Y > r1) continue;
+                const float *gp3 = go + __float_as_uint(pt.w);
+                const float g0 = gp3[0], g1 = gp3[(size_t)n_per], g2 = gp3[2 * (size_t)n_per];
+                const float dx = pt.x - x, dy = pt.y - y;
+                const float u = dx * isx, vy = dy * isy, B = vy - rho * u;   // see bwd_trip
+                float v = __builtin_amdgcn_exp2f((B * nK1) * B - HALF_LOG2E * u * u);
+                if (test) v = (fabsf(dx) <= P.dmax && fabsf(dy) <= P.dmax) ? v : 0.f;
+                const float q = fmaf(g2, cb, fmaf(g1, cg, g0 * cr)) * v;
+                const float A = u * kappa - rho * B, qA = q * A, qB = q * B;
+                a[0] += qA; a[1] += qB; a[2] += qA * u; a[3] += qB * vy; a[4] += qA * B;
+                a[5] += v * g0; a[6] += v * g1; a[7] += v * g2;
+            }
+        }
+        }
+        bwd_scale(a, cinv, isx, isy);
+    }
+    const float d = wave_sum8(a, lane, s_red[wv]);
+    bwd_write(d, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // fused host prologue (reference utils/gaussian_splatting.py:174-180 and :121-123) and its backward
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
@@ -1827,28 +2203,39 @@ size_t gsasr_step_workspace_bytes(const gsasr_dims *dims)
     return make_step_layout(dims).total;
 }
 
-int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
-                       size_t workspace_bytes, float *img, void *stream)
+namespace {
+// prologue (per-sample sizes and step sizes step_size[b] on a batched canvas) + plan of a whole-step call
+int step_prologue_plan(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+                       size_t workspace_bytes, void *stream, StepLayout &S)
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
     if (dims->flags & GSASR_FLAG_STRIDE8) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 does not apply to the step entry points");
-    const StepLayout S = make_step_layout(dims);
+    S = make_step_layout(dims);
     if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
     char *b = (char *)workspace;
     float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
-    if (dims->batch > 1) {  // per-sample sizes and step sizes (step_size[b]); the geometry must be in place first
-        if (dims->s == 0) return GSASR_OK;
-        if (!gs_parameters || !step_size) return fail(GSASR_ERR_ARG, "null pointer");
-        const PlanView V = make_view(make_layout(dims), workspace);
-        if (int rc = launch_batch_geo(dims, V, (hipStream_t)stream)) return rc;
-        hipLaunchKernelGGL(k_prologue_fwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           gs_parameters, step_size, dims->s, 0, 0, sig, xy, col, dims->s / dims->batch,
-                           (const int4 *)V.geo);
-        HIP_TRY(hipGetLastError());
+    if (dims->batch > 1) {  // the geometry must be in place before the prologue reads it
+        if (dims->s > 0) {
+            if (!gs_parameters || !step_size) return fail(GSASR_ERR_ARG, "null pointer");
+            const PlanView V = make_view(make_layout(dims), workspace);
+            if (int rc = launch_batch_geo(dims, V, (hipStream_t)stream)) return rc;
+            hipLaunchKernelGGL(k_prologue_fwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               gs_parameters, step_size, dims->s, 0, 0, sig, xy, col, dims->s / dims->batch,
+                               (const int4 *)V.geo);
+            HIP_TRY(hipGetLastError());
+        }
     } else if (int rc = gsasr_prologue_forward(gs_parameters, step_size, dims->s, dims->h, dims->w, sig, xy, col, stream))
         return rc;
-    if (int rc = gsasr_splat_plan(sig, xy, col, dims, workspace, S.plan_bytes, stream)) return rc;
+    return gsasr_splat_plan(sig, xy, col, dims, workspace, S.plan_bytes, stream);
+}
+}  // namespace
+
+int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+                       size_t workspace_bytes, float *img, void *stream)
+{
+    StepLayout S;
+    if (int rc = step_prologue_plan(gs_parameters, step_size, dims, workspace, workspace_bytes, stream, S)) return rc;
     return gsasr_splat_forward(dims, workspace, S.plan_bytes, img, stream);
 }
 
@@ -1870,6 +2257,155 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
     if (dims->batch > 1) {
         if (dims->s == 0) return GSASR_OK;
         if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
+        const PlanView V = make_view(make_layout(dims), workspace);
+        hipLaunchKernelGGL(k_prologue_bwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           gs_parameters, step_size, dims->s, 0, 0, gs, gc, gk, g_parameters, dims->s / dims->batch,
+                           (const int4 *)V.geo);
+        HIP_TRY(hipGetLastError());
+        return GSASR_OK;
+    }
+    return gsasr_prologue_backward(gs_parameters, step_size, dims->s, dims->h, dims->w, gs, gc, gk, g_parameters, stream);
+}
+
+
+// ---- sampled pixels --------------------------------------------------------------------------------
+namespace {
+struct PtLayout {
+    size_t off_start, off_sorted, total;
+};
+PtLayout make_pt_layout(long n_total)
+{
+    PtLayout L;
+    L.off_start = 0;
+    L.off_sorted = align_up((size_t)(PT_CELLS + 2) * 4, 256);
+    L.total = L.off_sorted + align_up((size_t)(n_total > 0 ? n_total : 1) * 16, 256);
+    return L;
+}
+PtView make_pt_view(const gsasr_dims *d, void *ws, long n_total)
+{
+    const PtLayout L = make_pt_layout(n_total);
+    PtView S;
+    S.start = (unsigned *)((char *)ws + L.off_start);
+    S.sorted = (float4 *)((char *)ws + L.off_sorted);
+    // 16x16-px point-cells (the plan's cells) while their number fits the sort's LDS table; else coarser ones
+    S.shx = S.shy = CELL_SHIFT;
+    for (;;) {
+        S.ncx = ((d->w - 1) >> S.shx) + 1;
+        S.ncy = ((d->h - 1) >> S.shy) + 1;
+        if ((long)S.ncx * S.ncy <= PT_CELLS) break;
+        if (S.ncy >= S.ncx && S.shy < PT_MAX_SHIFT) ++S.shy; else ++S.shx;
+    }
+    return S;
+}
+int check_points(const gsasr_dims *dims, int n_points, const void *sample_ws, size_t sample_ws_bytes, long &n_total)
+{
+    if (dims->row0 != 0 || dims->row1 != dims->h) return fail(GSASR_ERR_ARG, "sampled pixels need the whole image (row0 = 0, row1 = h)");
+    if (n_points < 0) return fail(GSASR_ERR_ARG, "n_points < 0");
+    n_total = (long)n_points * batch_of(dims);
+    if (n_total > 0x7fffffffL) return fail(GSASR_ERR_ARG, "too many points");
+    if (!sample_ws || ((uintptr_t)sample_ws & 255u) || sample_ws_bytes < make_pt_layout(n_total).total)
+        return fail(GSASR_ERR_WORKSPACE, "sample workspace null, misaligned or smaller than gsasr_sample_workspace_bytes()");
+    return GSASR_OK;
+}
+}  // namespace
+
+size_t gsasr_sample_workspace_bytes(const gsasr_dims *dims, int n_points)
+{
+    if (!dims_ok(dims) || n_points < 0) {
+        fail(GSASR_ERR_ARG, "bad dims");
+        return 0;
+    }
+    return make_pt_layout((long)n_points * batch_of(dims)).total;
+}
+
+int gsasr_splat_sample_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, const int *points,
+                               int n_points, float *out, void *sample_ws, size_t sample_ws_bytes, void *stream)
+{
+    Layout L;
+    if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
+    long n_total = 0;
+    if (int rc = check_points(dims, n_points, sample_ws, sample_ws_bytes, n_total)) return rc;
+    if (n_total == 0) return GSASR_OK;
+    if (!points || !out) return fail(GSASR_ERR_ARG, "null pointer");
+    const Params P = make_params(dims, L);
+    const PlanView V = make_view(L, const_cast<void *>(workspace));
+    const PtView S = make_pt_view(dims, sample_ws, n_total);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_pts_sort, dim3(1), dim3(1024), 0, st, P, V, S, points, (int)n_total, n_points);
+    const dim3 grid((unsigned)(S.ncx * S.ncy + 1)), block(64 * SAMPLE_WAVES);   // one workgroup per point-cell (+ the invalid bucket)
+    if (P.bounded) hipLaunchKernelGGL(k_sample_fwd<true>, grid, block, 0, st, P, V, S, n_points, out);
+    else hipLaunchKernelGGL(k_sample_fwd<false>, grid, block, 0, st, P, V, S, n_points, out);
+    HIP_TRY(hipGetLastError());
+    return GSASR_OK;
+}
+
+int gsasr_splat_sample_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_out,
+                                float *g_sigmas, float *g_coords, float *g_colors, const gsasr_dims *dims,
+                                const void *workspace, size_t workspace_bytes, const int *points, int n_points,
+                                void *sample_ws, size_t sample_ws_bytes, void *stream)
+{
+    Layout L;
+    if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
+    long n_total = 0;
+    if (int rc = check_points(dims, n_points, sample_ws, sample_ws_bytes, n_total)) return rc;
+    if (dims->s == 0) return GSASR_OK;
+    if (!g_sigmas || !g_coords || !g_colors) return fail(GSASR_ERR_ARG, "null pointer");
+    (void)sigmas; (void)coords; (void)colors;   // (everything the kernel needs is in the plan)
+    hipStream_t st = (hipStream_t)stream;
+    if (n_total == 0) {  // no points: the gradient is zero
+        if (dims->flags & GSASR_FLAG_OVERWRITE_GRADS) {
+            const size_t k3 = (dims->flags & GSASR_FLAG_STRIDE8) ? 0 : 3, k2 = (dims->flags & GSASR_FLAG_STRIDE8) ? 0 : 2;
+            if (!k3) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 with zero points");
+            HIP_TRY(hipMemsetAsync(g_sigmas, 0, sizeof(float) * k3 * (size_t)dims->s, st));
+            HIP_TRY(hipMemsetAsync(g_coords, 0, sizeof(float) * k2 * (size_t)dims->s, st));
+            HIP_TRY(hipMemsetAsync(g_colors, 0, sizeof(float) * k3 * (size_t)dims->s, st));
+        }
+        return GSASR_OK;
+    }
+    if (!grad_out) return fail(GSASR_ERR_ARG, "null pointer");
+    const Params P = make_params(dims, L);
+    const PlanView V = make_view(L, const_cast<void *>(workspace));
+    const PtView S = make_pt_view(dims, sample_ws, n_total);
+    if (points)   // NULL: sample_ws still holds the sorted points of the forward call
+        hipLaunchKernelGGL(k_pts_sort, dim3(1), dim3(1024), 0, st, P, V, S, points, (int)n_total, n_points);
+    const dim3 grid((unsigned)((dims->s + 3) / 4)), block(256);
+    if (P.bounded)
+        hipLaunchKernelGGL(k_sample_bwd<true>, grid, block, 0, st, P, V, S, n_points, grad_out, g_sigmas, g_coords, g_colors);
+    else
+        hipLaunchKernelGGL(k_sample_bwd<false>, grid, block, 0, st, P, V, S, n_points, grad_out, g_sigmas, g_coords, g_colors);
+    HIP_TRY(hipGetLastError());
+    return GSASR_OK;
+}
+
+int gsasr_step_sample_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+                              size_t workspace_bytes, const int *points, int n_points, float *out, void *sample_ws,
+                              size_t sample_ws_bytes, void *stream)
+{
+    StepLayout S;
+    if (int rc = step_prologue_plan(gs_parameters, step_size, dims, workspace, workspace_bytes, stream, S)) return rc;
+    return gsasr_splat_sample_forward(dims, workspace, S.plan_bytes, points, n_points, out, sample_ws, sample_ws_bytes, stream);
+}
+
+int gsasr_step_sample_backward(const float *gs_parameters, const float *step_size, const float *grad_out,
+                               float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
+                               const int *points, int n_points, void *sample_ws, size_t sample_ws_bytes, void *stream)
+{
+    if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
+    if (dims->flags & GSASR_FLAG_STRIDE8) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 does not apply to the step entry points");
+    const StepLayout S = make_step_layout(dims);
+    if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
+        return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
+    char *b = (char *)workspace;
+    float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
+    float *gs = (float *)(b + S.off_gsig), *gc = (float *)(b + S.off_gxy), *gk = (float *)(b + S.off_gcol);
+    gsasr_dims d = *dims;
+    d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
+    if (int rc = gsasr_splat_sample_backward(sig, xy, col, grad_out, gs, gc, gk, &d, workspace, S.plan_bytes, points, n_points,
+                                             sample_ws, sample_ws_bytes, stream))
+        return rc;
+    if (dims->s == 0) return GSASR_OK;
+    if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
+    if (dims->batch > 1) {
         const PlanView V = make_view(make_layout(dims), workspace);
         hipLaunchKernelGGL(k_prologue_bwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            gs_parameters, step_size, dims->s, 0, 0, gs, gc, gk, g_parameters, dims->s / dims->batch,

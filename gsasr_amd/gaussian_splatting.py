@@ -94,19 +94,85 @@ class _FusedStep(torch.autograd.Function):
         return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_hwc), None, None, None, None
 
 
+class _FusedStepSampled(torch.autograd.Function):
+    """`_FusedStep` for `sample_coords`: only the requested pixels are evaluated (`[3,S]`), instead of rendering
+    `[3,H,W]` and indexing it once per point as the reference does (:214-216).  The backward is
+    the sampled one too: each Gaussian visits the points inside its window, not every pixel of it."""
+
+    @staticmethod
+    @fp32_boundary_fwd
+    def forward(ctx, gs_parameters, step, H, W, dmax, points):
+        from . import _cabi
+        out, plan, state = _cabi.step_sample_forward(gs_parameters, step, H, W, dmax, points)
+        ctx.save_for_backward(gs_parameters, step)
+        ctx.plan, ctx.state = plan, state
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    @fp32_boundary_bwd
+    def backward(ctx, grad_output):
+        from . import _cabi
+        gs_parameters, step = ctx.saved_tensors
+        return (_cabi.step_sample_backward(ctx.plan, ctx.state, gs_parameters, step, grad_output.contiguous()),
+                None, None, None, None, None)
+
+
+class _FusedBatchSampled(torch.autograd.Function):
+    """`_FusedBatch` for `sample_coords[B,S,2]` -> `[B,3,S]`."""
+
+    @staticmethod
+    @fp32_boundary_fwd
+    def forward(ctx, gs_parameters, steps, sizes, dmax, points):
+        from . import _cabi
+        out, plan, state = _cabi.batch_sample_forward(gs_parameters, steps, sizes, dmax, points)
+        ctx.save_for_backward(gs_parameters, steps)
+        ctx.plan, ctx.state = plan, state
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    @fp32_boundary_bwd
+    def backward(ctx, grad_output):
+        from . import _cabi
+        gs_parameters, steps = ctx.saved_tensors
+        return (_cabi.step_sample_backward(ctx.plan, ctx.state, gs_parameters, steps, grad_output.contiguous()),
+                None, None, None, None)
+
+
+# The sampled path costs one wave per point and one candidate walk per point: it wins while the points are a
+# fraction of the image (measured break-even near 1/2 of the pixels, DESIGN.md 3b); denser requests render the image.
+SAMPLED_MAX_FRACTION = 0.25
+
+
+def _as_points(sample_coords):
+    """`sample_coords` as an integer `[S,2]` tensor, or None if it is not a plain list/tensor of (row, column) pairs"""
+    sc = sample_coords
+    if not torch.is_tensor(sc):
+        try:
+            sc = torch.as_tensor(sc)
+        except Exception:
+            return None
+    if sc.dim() != 2 or sc.shape[1] != 2 or sc.dtype.is_floating_point or sc.dtype == torch.bool:
+        return None
+    return sc
+
+
 def _fused_ok(gs_parameters) -> bool:
     return gs_parameters.is_cuda and gs_parameters.dtype == torch.float32 and gs_parameters.dim() == 2 \
         and gs_parameters.shape[1] == 9
 
 
+def _step_tensor(step_size, dev):
+    if torch.is_tensor(step_size):
+        return step_size.detach().to(device=dev, dtype=torch.float32).reshape(1)   # stays on the device: no sync
+    return torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
+
+
 def _fused_render(gs_parameters, sr_size, step_size, dmax):
     """[3,H,W] through the fused prologue; `step_size` may be a python number or a (GPU) tensor."""
     H, W = _hw(sr_size)
-    dev = gs_parameters.device
-    if torch.is_tensor(step_size):
-        step = step_size.detach().to(device=dev, dtype=torch.float32).reshape(1)   # stays on the device: no sync
-    else:
-        step = torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
+    step = _step_tensor(step_size, gs_parameters.device)
     return _FusedStep.apply(gs_parameters.contiguous(), step, H, W, None if dmax is None else float(dmax))
 
 
@@ -243,6 +309,11 @@ def generate_2D_gaussian_splatting_step(sr_size, gs_parameters, scale, scale_mod
     if cuda_rendering and _fused_ok(gs_parameters):
         # fused prologue + splat (same maths as the unfused branch below, one kernel instead of ~15)
         dmax_eff = _resolve_dmax(dmax, dmax_mode, sr_size) if if_dmax else None
+        pts = _as_points(sample_coords) if sample_coords is not None else None
+        H, W = _hw(sr_size)
+        if pts is not None and 0 < pts.shape[0] <= SAMPLED_MAX_FRACTION * H * W:
+            return _FusedStepSampled.apply(gs_parameters.contiguous(), _step_tensor(step_size, gs_parameters.device), H, W,
+                                           None if dmax_eff is None else float(dmax_eff), pts)
         return _sample(_fused_render(gs_parameters, sr_size, step_size, dmax_eff), sample_coords)
     sigma_x, sigma_y, rho, coords, colours_with_alpha = _activate(gs_parameters)
     dev = sigma_x.device
@@ -309,10 +380,12 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
 
 
 def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_modifies, default_step_size=1.2,
-                                         mode='scale_modify', if_dmax=True, dmax_mode='fix', dmax=25):
-    """Batched `generate_2D_gaussian_splatting_step` (no `sample_coords`): `gs_parameters` `[B,N,9]`, per-sample
+                                         mode='scale_modify', if_dmax=True, dmax_mode='fix', dmax=25, sample_coords=None):
+    """Batched `generate_2D_gaussian_splatting_step`: `gs_parameters` `[B,N,9]`, per-sample
     `sr_sizes[b]`, `scales[b]`, `scale_modifies[b]`; returns `[B,3,Hmax,Wmax]` with every sample zero-padded to
-    the largest size -- exactly `torch.stack([F.pad(step(...), ...)])` of the reference's loop."""
+    the largest size -- exactly `torch.stack([F.pad(step(...), ...)])` of the reference's loop.  With
+    `sample_coords` `[B,S,2]` (row, column on each sample's own grid; gsasr_model.py:196-197) it returns the
+    `[B,3,S]` stack of the per-sample `[3,S]` results instead."""
     B = gs_parameters.shape[0]
     sizes = [_hw(s) for s in sr_sizes]
     if not (len(sizes) == B == len(scales) == len(scale_modifies)):
@@ -324,16 +397,24 @@ def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_
         dev = gs_parameters.device
         steps = _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev)
         dmax_eff = _resolve_dmax(dmax, dmax_mode, sr_sizes[0]) if if_dmax else None
-        return _FusedBatch.apply(gs_parameters.contiguous(), steps, tuple(sizes),
-                                 None if dmax_eff is None else float(dmax_eff))
+        dm = None if dmax_eff is None else float(dmax_eff)
+        if sample_coords is None:
+            return _FusedBatch.apply(gs_parameters.contiguous(), steps, tuple(sizes), dm)
+        pts = sample_coords if torch.is_tensor(sample_coords) else torch.as_tensor(sample_coords)
+        if pts.dim() == 3 and pts.shape[0] == B and pts.shape[2] == 2 and not pts.dtype.is_floating_point \
+                and 0 < pts.shape[1] <= SAMPLED_MAX_FRACTION * min(h * w for h, w in sizes):
+            return _FusedBatchSampled.apply(gs_parameters.contiguous(), steps, tuple(sizes), dm, pts)
     # per-sample path (single sample, > 64 samples, or a per-sample dmax): same kernels, one sample at a time
     h_max, w_max = max(h for h, _ in sizes), max(w for _, w in sizes)
     outs = []
     for b in range(B):
         o = generate_2D_gaussian_splatting_step(sr_sizes[b], gs_parameters[b], scales[b], scale_modifies[b],
+                                                sample_coords=None if sample_coords is None else sample_coords[b],
                                                 default_step_size=default_step_size, mode=mode, if_dmax=if_dmax,
                                                 dmax_mode=dmax_mode, dmax=dmax)
-        outs.append(torch.nn.functional.pad(o, (0, w_max - sizes[b][1], 0, h_max - sizes[b][0])))
+        if sample_coords is None:
+            o = torch.nn.functional.pad(o, (0, w_max - sizes[b][1], 0, h_max - sizes[b][0]))
+        outs.append(o)
     return torch.stack(outs)
 
 

@@ -146,6 +146,38 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
                         float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* Sampled pixels.  With `sample_coords` the reference renders the whole [3,H,W] image and
+ * then picks the S requested pixels out of it, one indexing op per point (utils/gaussian_splatting.py:214-216;
+ * the points come from basicsr/data/continuous_bicubic_downsample_dataset.py:86-88).  These entry points evaluate
+ * only those pixels: forward = the values out[3, n_points] at the points (one wave per point, its lanes spread over
+ * the Gaussians binned within reach), backward = the gradient of sum(grad_out * out) (one wave per Gaussian, its
+ * lanes spread over the points inside its window, found through a counting sort of the points).
+ *
+ *   points    device int32 [n_points, 2] = (row, column) on the image's own grid; negative values wrap once like
+ *             Python indices; a point that is still out of range yields 0 and takes no part in the backward
+ *             (the reference raises IndexError -- checking would cost a host synchronisation).  Repeated points
+ *             are evaluated independently, as the reference's gather does.
+ *   out / grad_out   [3, n_points], written (not accumulated).
+ *   batched canvas (dims.batch = B): points [B, n_points, 2] on each sample's own grid, out [B, 3, n_points].
+ *   workspace a plan of the same dims (gsasr_splat_plan, or the step entry point below); the whole image
+ *             (row0 = 0, row1 = h).  Flags: OVERWRITE_GRADS / STRIDE8 as for gsasr_splat_backward.
+ *   sample_ws scratch of gsasr_sample_workspace_bytes(dims, n_points) bytes, 256-byte aligned: the sorted points.
+ *             The backward re-sorts `points`, or, given points = NULL, uses what the forward call left there.
+ * The step variants fuse the host prologue exactly as gsasr_step_forward / gsasr_step_backward do. */
+size_t gsasr_sample_workspace_bytes(const gsasr_dims *dims, int n_points);
+int gsasr_splat_sample_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, const int *points,
+                               int n_points, float *out, void *sample_ws, size_t sample_ws_bytes, void *stream);
+int gsasr_splat_sample_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_out,
+                                float *g_sigmas, float *g_coords, float *g_colors, const gsasr_dims *dims,
+                                const void *workspace, size_t workspace_bytes, const int *points, int n_points,
+                                void *sample_ws, size_t sample_ws_bytes, void *stream);
+int gsasr_step_sample_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+                              size_t workspace_bytes, const int *points, int n_points, float *out, void *sample_ws,
+                              size_t sample_ws_bytes, void *stream);
+int gsasr_step_sample_backward(const float *gs_parameters, const float *step_size, const float *grad_out,
+                               float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
+                               const int *points, int n_points, void *sample_ws, size_t sample_ws_bytes, void *stream);
+
 /* Reference-shaped launchers (allocate their scratch stream-ordered, plan, run, free). */
 int gsasr_gs_render(const float *sigmas, const float *coords, const float *colors,
                     float *rendered_img, int s, int h, int w, int c, void *stream);
