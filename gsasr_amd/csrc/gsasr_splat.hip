@@ -106,6 +106,7 @@ struct PlanView {
     unsigned *done;         // [s] row chunks of a large Gaussian finished so far (backward)
     uint4 *bbox;            // [2*s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[0..3], span_hi[0..3]},
                             //       {span_lo[4..7], span_hi[4..7], -, -}
+    uint2 *win;             // [s] the first two words of bbox again, densely: what the coarse tests stream through
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -118,7 +119,7 @@ __device__ __forceinline__ Geo sample_geo(const Params &P, const PlanView &V, in
 }
 
 struct Layout {
-    size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox;
+    size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox, off_win;
     size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
     size_t total;
     int ncx, ncy, ncells;
@@ -174,6 +175,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_sums = o;   o += align_up(s * 32, 256);
     L.off_done = o;   o += align_up(s * 4, 256);
     L.off_bbox = o;   o += align_up(s * 32, 256);
+    L.off_win = o;    o += align_up(s * 8, 256);
     L.total = o;
     return L;
 }
@@ -197,6 +199,7 @@ PlanView make_view(const Layout &L, void *ws)
     V.sums = (float *)(b + L.off_sums);
     V.done = (unsigned *)(b + L.off_done);
     V.bbox = (uint4 *)(b + L.off_bbox);
+    V.win = (uint2 *)(b + L.off_win);
     return V;
 }
 
@@ -668,6 +671,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     V.fin[2 * j + 1] = finB;
     V.bbox[2 * j] = bb;
     V.bbox[2 * j + 1] = bc;
+    V.win[j] = make_uint2(bb.x, bb.y);
     if (large) {  // large Gaussians accumulate their row chunks atomically: start from zero
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -923,7 +927,7 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
             const unsigned c = base + (unsigned)wv + 4u * PARTS * (unsigned)k;
             cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
             cw[k] = make_uint2(0x7fffu, 0x7fffu);
-            if (cj[k] != 0xffffffffu) cw[k] = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)cj[k]);
+            if (cj[k] != 0xffffffffu) cw[k] = V.win[cj[k]];
         }
 #pragma unroll
         for (int k = 0; k < COARSE_CHUNKS; ++k) {
@@ -1480,15 +1484,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 //                 point-cells its window touches; same epilogue as k_render_bwd.
 // ---------------------------------------------------------------------------------------------------
 constexpr int PT_CELLS = 12288;                    // point-cells at most: their histogram + scan live in LDS (48 KB)
-constexpr int PT_MAX_SHIFT = 9;                    // point-cells are 16..512 px a side
+constexpr int PT_MIN_SHIFT = 3, PT_MAX_SHIFT = 9;  // point-cells are 8..512 px a side
 
 struct PtView {
     unsigned *start;   // [ncx*ncy + 2] exclusive scan of the points per point-cell; [ncx*ncy] = first invalid point
+    unsigned *cursor;  // [ncx*ncy + 1] fill positions of the counting sort
     float4 *sorted;    // [n] {px, py, X | canvas row << 16, original index}: everything a kernel needs about a point
+    float4 *grads;     // [n] {g_r, g_g, g_b, -} of the sorted points (backward)
     int shx, shy, ncx, ncy;
 };
-
-constexpr int PT_BATCH = 8;
 
 __device__ __forceinline__ int2 point_rc(int2 raw, const Geo &g)
 {
@@ -1498,44 +1502,38 @@ __device__ __forceinline__ int2 point_rc(int2 raw, const Geo &g)
     return make_int2(r, c);
 }
 
-__global__ __launch_bounds__(1024) void k_pts_sort(Params P, PlanView V, PtView S, const int *__restrict__ pts,
+// The counting sort as three launches (the histogram is zeroed by a memset): count, scan (one workgroup), place.
+__device__ __forceinline__ int point_cell(const Params &P, const PlanView &V, const PtView &S, const int *__restrict__ pts,
+                                          int i, int n_per, int &X, int &Y, int &pxo)
+{
+    const Geo g = sample_geo(P, V, i / n_per);
+    const int2 rc = point_rc(reinterpret_cast<const int2 *>(pts)[i], g);
+    const bool ok = rc.x >= 0 && rc.x < g.h && rc.y >= 0 && rc.y < g.w;
+    X = rc.y; Y = g.base + rc.x; pxo = g.pxo;
+    return ok ? (Y >> S.shy) * S.ncx + (X >> S.shx) : S.ncx * S.ncy;
+}
+
+__global__ __launch_bounds__(256) void k_pts_count(Params P, PlanView V, PtView S, const int *__restrict__ pts,
                                                    int n_total, int n_per)
 {
-    __shared__ unsigned s_cell[PT_CELLS + 1], s_wave[16];   // histogram, then (scanned in place) the fill cursors
-    __shared__ int4 s_geo[GSASR_MAX_BATCH];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    int X, Y, pxo;
+    atomicAdd(&S.start[point_cell(P, V, S, pts, i, n_per, X, Y, pxo)], 1u);
+}
+
+__global__ __launch_bounds__(1024) void k_pts_scan(PtView S, int n_total)
+{
+    __shared__ unsigned s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int npc = S.ncx * S.ncy;
-    for (int k = tid; k <= npc; k += 1024) s_cell[k] = 0u;
-    if (tid < P.batch) s_geo[tid] = P.batch > 1 ? V.geo[tid] : make_int4(P.h, P.w, 0, 0);
-    __syncthreads();
-    // (one workgroup: its run time is the length of its dependent chains, so the loads of PT_BATCH points are issued
-    // together)
-    for (int i0 = tid; i0 < n_total; i0 += 1024 * PT_BATCH) {
-        int2 raw[PT_BATCH];
-#pragma unroll
-        for (int k = 0; k < PT_BATCH; ++k) {
-            const int i = i0 + 1024 * k;
-            raw[k] = i < n_total ? reinterpret_cast<const int2 *>(pts)[i] : make_int2(0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < PT_BATCH; ++k) {
-            const int i = i0 + 1024 * k;
-            if (i >= n_total) continue;
-            const int4 gg = s_geo[i / n_per];
-            const Geo g{gg.x, gg.y, gg.z, gg.w};
-            const int2 rc = point_rc(raw[k], g);
-            const bool ok = rc.x >= 0 && rc.x < g.h && rc.y >= 0 && rc.y < g.w;
-            atomicAdd(&s_cell[ok ? ((g.base + rc.x) >> S.shy) * S.ncx + (rc.y >> S.shx) : npc], 1u);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of npc + 1 counts: consecutive entries per thread, wave scan, 16 wave totals
+    // exclusive scan of npc + 1 counts in place: consecutive entries per thread, wave scan, 16 wave totals
     constexpr int PER = (PT_CELLS + 1 + 1023) / 1024;
     unsigned loc[PER], sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int e = tid * PER + k;
-        loc[k] = e <= npc ? s_cell[e] : 0u;
+        loc[k] = e <= npc ? S.start[e] : 0u;
         sum += loc[k];
     }
     unsigned inc = sum;
@@ -1552,35 +1550,36 @@ __global__ __launch_bounds__(1024) void k_pts_sort(Params P, PlanView V, PtView 
     for (int k = 0; k < PER; ++k) {
         const int e = tid * PER + k;
         if (e <= npc) {
-            s_cell[e] = run;
             S.start[e] = run;
+            S.cursor[e] = run;
         }
         run += loc[k];
     }
     if (tid == 0) S.start[npc + 1] = (unsigned)n_total;
-    __syncthreads();
-    for (int i0 = tid; i0 < n_total; i0 += 1024 * PT_BATCH) {
-        int2 raw[PT_BATCH];
-#pragma unroll
-        for (int k = 0; k < PT_BATCH; ++k) {
-            const int i = i0 + 1024 * k;
-            raw[k] = i < n_total ? reinterpret_cast<const int2 *>(pts)[i] : make_int2(0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < PT_BATCH; ++k) {
-            const int i = i0 + 1024 * k;
-            if (i >= n_total) continue;
-            const int4 gg = s_geo[i / n_per];
-            const Geo g{gg.x, gg.y, gg.z, gg.w};
-            const int2 rc = point_rc(raw[k], g);
-            const bool ok = rc.x >= 0 && rc.x < g.h && rc.y >= 0 && rc.y < g.w;
-            const int Y = g.base + rc.x;
-            const unsigned pos = atomicAdd(&s_cell[ok ? (Y >> S.shy) * S.ncx + (rc.y >> S.shx) : npc], 1u);
-            S.sorted[pos] = ok ? make_float4(V.px[g.pxo + rc.y], V.py[Y], __uint_as_float((unsigned)rc.y | ((unsigned)Y << 16)),
-                                             __uint_as_float((unsigned)i))
-                               : make_float4(0.f, 0.f, 0.f, __uint_as_float((unsigned)i));
-        }
-    }
+}
+
+__global__ __launch_bounds__(256) void k_pts_place(Params P, PlanView V, PtView S, const int *__restrict__ pts,
+                                                   int n_total, int n_per)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    int X, Y, pxo;
+    const int cell = point_cell(P, V, S, pts, i, n_per, X, Y, pxo);
+    const bool ok = cell < S.ncx * S.ncy;
+    const float px = ok ? V.px[pxo + X] : 0.f, py = ok ? V.py[Y] : 0.f;
+    const unsigned pos = atomicAdd(&S.cursor[cell], 1u);
+    S.sorted[pos] = make_float4(px, py, ok ? __uint_as_float((unsigned)X | ((unsigned)Y << 16)) : 0.f, __uint_as_float((unsigned)i));
+}
+
+// backward: the upstream gradient [B, 3, n_per] gathered into the sorted order, so that a candidate is two
+// 16-byte loads at one index
+__global__ __launch_bounds__(256) void k_pts_grads(PtView S, const float *__restrict__ grad_out, int n_total, int n_per)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    const int idx = (int)__float_as_uint(S.sorted[i].w), smp = idx / n_per;
+    const float *g = grad_out + (size_t)smp * 3 * n_per + (idx - smp * n_per);
+    S.grads[i] = make_float4(g[0], g[(size_t)n_per], g[2 * (size_t)n_per], 0.f);
 }
 
 // wave64 sum without LDS traffic: four DPP row shifts leave each row's total in its lane 0
@@ -1603,9 +1602,8 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
 // kernel is built to keep many workgroups resident (64 VGPRs, 10 KB of LDS).  Block ncx*ncy zeroes the outputs of
 // the out-of-range points.
 constexpr int SAMPLE_WAVES = 4;
-constexpr int SAMPLE_CHUNKS = 8;                                  // coarse chunks per wave and batch of loads
-constexpr int SAMPLE_BATCHES = 4;                                 // batches per round (no barrier between them)
-constexpr int SAMPLE_LIST = SAMPLE_WAVES * SAMPLE_CHUNKS * SAMPLE_BATCHES * 64;   // candidates per round = capacity of the list
+constexpr int SAMPLE_CHUNKS = 8;      // candidate windows in flight per lane (level 1)
+constexpr int SAMPLE_LIST = 8192;     // capacity of the survivor list = candidates tested between two level-2 passes
 constexpr int SAMPLE_BLOCK = 24;   // points of a cell evaluated per walk: their sums stay in registers (72 VGPRs; 32 spills at 4 waves per SIMD)
 
 // One Gaussian per lane against the points staged in LDS (broadcast reads), two points per packed-fp32 operation.
@@ -1638,10 +1636,12 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cell = blockIdx.x, npc = S.ncx * S.ncy;
-    const unsigned pbeg = S.start[cell], pend = S.start[cell + 1];
-    if (pbeg == pend) return;
-    if (cell == npc) {   // out of range: nothing is rendered there
+    // the workgroup's block of point-cells: 16x16 px (2x2 cells of 8 px), or one coarser cell
+    const int fsx = max(S.shx, CELL_SHIFT), fsy = max(S.shy, CELL_SHIFT);
+    const int nbx = ((P.w - 1) >> fsx) + 1, nby = ((P.h - 1) >> fsy) + 1, npc = S.ncx * S.ncy;
+    const int blk = blockIdx.x;
+    if (blk == nbx * nby) {   // the out-of-range points: nothing is rendered there
+        const unsigned pbeg = S.start[npc], pend = S.start[npc + 1];
         for (unsigned i = pbeg + threadIdx.x; i < pend; i += 64 * SAMPLE_WAVES) {
             const int idx = (int)__float_as_uint(S.sorted[i].w), smp = idx / n_per;
             float *o = out + (size_t)smp * 3 * n_per + (idx - smp * n_per);
@@ -1649,14 +1649,21 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
         }
         return;
     }
+    const int bxi = blk % nbx, byi = blk / nbx;
+    const int px0 = bxi << (fsx - S.shx), px1 = min(px0 + (1 << (fsx - S.shx)), S.ncx);   // point-cell columns [px0, px1)
+    const int py0 = byi << (fsy - S.shy), two = (fsy > S.shy && py0 + 1 < S.ncy) ? 1 : 0;  // one or two rows of them
+    const unsigned beg0 = S.start[py0 * S.ncx + px0], n0 = S.start[py0 * S.ncx + px1] - beg0;
+    const unsigned beg1 = two ? S.start[(py0 + 1) * S.ncx + px0] : 0u;
+    const unsigned n1 = two ? S.start[(py0 + 1) * S.ncx + px1] - beg1 : 0u;
+    const unsigned pbeg = 0u, pend = n0 + n1;   // the block's points, numbered through both rows
+    if (pend == 0u) return;
     __shared__ unsigned s_list[SAMPLE_LIST];
     __shared__ unsigned s_cnt[2];
     __shared__ float4 s_pt[SAMPLE_BLOCK];      // {px, py, X | Y << 16, original index}
     __shared__ float s_acc[3 * SAMPLE_BLOCK];
-    const int bx0 = (cell % S.ncx) << S.shx, by0 = (cell / S.ncx) << S.shy;
-    const int bx1 = min(bx0 + (1 << S.shx), P.w) - 1, by1 = min(by0 + (1 << S.shy), P.h) - 1;
+    const int bx0 = bxi << fsx, by0 = byi << fsy;
+    const int bx1 = min(bx0 + (1 << fsx), P.w) - 1, by1 = min(by0 + (1 << fsy), P.h) - 1;
     const float4 *__restrict__ rec = V.rec;
-    const uint4 *__restrict__ bbox = V.bbox;
     const unsigned *__restrict__ cs = V.cell_start;
 
     // segment table of the rectangle (every wave builds the same one)
@@ -1666,7 +1673,7 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
     if (rx > 0) {
         const int cx0 = max(bx0 - rx, 0) >> CELL_SHIFT, cx1 = min((bx1 + rx) >> CELL_SHIFT, P.ncx - 1);
         const int cy0 = max(by0 - ry, 0) >> CELL_SHIFT, cy1 = min((by1 + ry) >> CELL_SHIFT, P.ncy - 1);
-        nseg = cy1 - cy0 + 1;     // <= (512 + 2*128)/16 + 1 = 49
+        nseg = cy1 - cy0 + 1;     // <= (512 + 2*128)/16 + 1 = 49 rows of plan cells
         if (lane < nseg) {
             sbeg = cs[(cy0 + lane) * P.ncx + cx0];
             send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
@@ -1677,43 +1684,48 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
         send = cs[P.ncells + 1];
     }
     ++nseg;
-    const unsigned len = send - sbeg;
-    unsigned pin = len;
-    for (int k = 1; k < 64; k <<= 1) {
-        const unsigned v = (unsigned)__shfl_up((int)pin, k);
-        if (lane >= k) pin += v;
-    }
-    const unsigned pex = pin - len;
-    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
-    const unsigned nchunks = (total + 63u) >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
 
     for (unsigned pb = pbeg; pb < pend; pb += SAMPLE_BLOCK) {   // (more than SAMPLE_BLOCK points in a cell: walk again)
         const int npb = (int)min((unsigned)SAMPLE_BLOCK, pend - pb);
-        if ((int)threadIdx.x < npb) s_pt[threadIdx.x] = S.sorted[pb + threadIdx.x];
+        if ((int)threadIdx.x < npb) {
+            const unsigned pi = pb + threadIdx.x;
+            s_pt[threadIdx.x] = S.sorted[pi < n0 ? beg0 + pi : beg1 + (pi - n0)];
+        }
         if (threadIdx.x < 3 * SAMPLE_BLOCK) s_acc[threadIdx.x] = 0.f;
         if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
         __syncthreads();
-        int rseg = 0;
         v2f acc[SAMPLE_BLOCK / 2][3];   // per lane: colour sums of the block's points, two points per register pair
 #pragma unroll
         for (int k = 0; k < SAMPLE_BLOCK / 2; ++k) acc[k][0] = acc[k][1] = acc[k][2] = (v2f){0.f, 0.f};
-        for (unsigned base = 0, round = 0; base < nchunks; base += SAMPLE_WAVES * SAMPLE_CHUNKS * SAMPLE_BATCHES, ++round) {
+        // Level 1 fills the survivor list with the candidates row by row (cell rows within reach, then the large
+        // class) until the next batch might overflow it or the candidates are exhausted; level 2 empties it.  (One
+        // level-2 site in the code: inlined twice it spills 22 accumulator registers.)
+        int r = 0;
+        unsigned i0 = (unsigned)__builtin_amdgcn_readlane((int)sbeg, 0), se = (unsigned)__builtin_amdgcn_readlane((int)send, 0);
+        constexpr unsigned BATCH = 64u * SAMPLE_WAVES * SAMPLE_CHUNKS;
+        for (unsigned round = 0;; ++round) {
             unsigned *cnt = s_cnt + (round & 1u);
-            // ---- level 1: this wave's chunks of the round against the cell's rectangle, 8 loads in flight ----
-            for (unsigned bb0 = base; bb0 < min(nchunks, base + SAMPLE_WAVES * SAMPLE_CHUNKS * SAMPLE_BATCHES);
-                 bb0 += SAMPLE_WAVES * SAMPLE_CHUNKS) {
-                unsigned cj[SAMPLE_CHUNKS];
+            // ---- level 1: the workgroup strides through a row, SAMPLE_CHUNKS windows in flight per lane, against
+            // the block's rectangle
+            for (unsigned proc = 0; r < nseg && proc + BATCH <= (unsigned)SAMPLE_LIST;) {
+                if (i0 >= se) {
+                    if (++r < nseg) {
+                        i0 = (unsigned)__builtin_amdgcn_readlane((int)sbeg, r);
+                        se = (unsigned)__builtin_amdgcn_readlane((int)send, r);
+                    }
+                    continue;
+                }
                 uint2 cw[SAMPLE_CHUNKS];
 #pragma unroll
                 for (int k = 0; k < SAMPLE_CHUNKS; ++k) {
-                    const unsigned c = bb0 + (unsigned)wv + SAMPLE_WAVES * (unsigned)k;
-                    cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
-                    cw[k] = make_uint2(0x7fffu, 0x7fffu);
-                    if (cj[k] != 0xffffffffu) cw[k] = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)cj[k]);
+                    const unsigned i = i0 + 64u * SAMPLE_WAVES * (unsigned)k + (unsigned)threadIdx.x;
+                    cw[k] = make_uint2(0x7fffu, 0x7fffu);   // a window that overlaps nothing
+                    if (i < se) cw[k] = V.win[i];
                 }
 #pragma unroll
                 for (int k = 0; k < SAMPLE_CHUNKS; ++k) {
+                    if (i0 + 64u * SAMPLE_WAVES * (unsigned)k >= se) continue;   // (uniform)
                     const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
                     const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
                     const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
@@ -1722,9 +1734,13 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
                         unsigned at = 0;
                         if (lane == 0) at = atomicAdd(cnt, (unsigned)__builtin_popcountll(m));
                         at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
-                        if (hit) s_list[at + (unsigned)__builtin_popcountll(m & below)] = cj[k];
+                        // entry = index | "needs the dmax test" (window word bit 15) << 31
+                        if (hit) s_list[at + (unsigned)__builtin_popcountll(m & below)] =
+                            (i0 + 64u * SAMPLE_WAVES * (unsigned)k + (unsigned)threadIdx.x) | ((cw[k].x & 0x8000u) << 16);
                     }
                 }
+                i0 += BATCH;
+                proc += BATCH;
             }
             __syncthreads();
             if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0u;
@@ -1737,10 +1753,10 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;   // {x, y, A, B}, {C, r, g, b}; dead lanes add 0 * v
             bool test = false;
             if (q + (unsigned)lane < n) {
-                const unsigned j = s_list[q + lane];
+                const unsigned e = s_list[q + lane], j = e & 0x7fffffffu;
                 a = rec[2 * (size_t)j];
                 b = rec[2 * (size_t)j + 1];
-                if (BOUNDED) test = (bbox[2 * (size_t)j].x & 0x8000u) != 0u;
+                test = (e >> 31) != 0u;
             }
             while (q < n) {
                 asm volatile("" ::: "memory");   // re-read the points from LDS every trip: hoisted, they cost 96 VGPRs
@@ -1748,17 +1764,18 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
                 float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
                 bool ntest = false;
                 if (nq + (unsigned)lane < n) {
-                    const unsigned j = s_list[nq + lane];
+                    const unsigned e = s_list[nq + lane], j = e & 0x7fffffffu;
                     na = rec[2 * (size_t)j];
                     nb = rec[2 * (size_t)j + 1];
-                    if (BOUNDED) ntest = (bbox[2 * (size_t)j].x & 0x8000u) != 0u;
+                    ntest = (e >> 31) != 0u;
                 }
                 // (one code path: an `if (any lane needs the test)` around two instantiations makes the compiler keep
                 // two copies of the accumulators -- 200 spilled dwords; the test is 3 instructions per point)
                 sample_eval<BOUNDED>(s_pt, npb, a, b, test ? P.dmax : INFINITY, acc);
                 q = nq; a = na; b = nb; test = ntest;
             }
-            __syncthreads();   // the list is rewritten in the next round
+            if (r >= nseg) break;   // (uniform)
+            __syncthreads();        // the list is rewritten by the next round
         }
         // one reduction per block: over the lanes with DPP, over the waves in LDS
 #pragma unroll
@@ -1783,66 +1800,88 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
     }
 }
 
+// Backward at the points: GAUSSIAN-stationary, SB_LANES lanes per Gaussian, i.e. eight Gaussians per wave64.  (With one
+// wave per Gaussian the ~200 instructions of per-wave bookkeeping -- fetch, reduction, epilogue -- at 4 cycles each were
+// the whole run time: 232 us for the 590 k Gaussians of config 5; 16 lanes: 104 us, 8: 85 us, 4: 80 us but a
+// large-class Gaussian then walks every point with 4 lanes.)  A Gaussian's lanes stride over the sorted points of the
+// point-cells its window touches, SB_ROWS rows of cells as one run of indices; DPP reduction inside the 16-lane row;
+// the Gaussian's first lane writes the gradient.
+constexpr int SB_LANES = 8;
+constexpr int SB_ROWS = 4;
+
 template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_sample_bwd(Params P, PlanView V, PtView S, int n_per,
-                                                    const float *__restrict__ grad_out, float *__restrict__ g_sigmas,
-                                                    float *__restrict__ g_coords, float *__restrict__ g_colors)
+__global__ __launch_bounds__(256) void k_sample_bwd(Params P, PlanView V, PtView S,
+                                                    float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                                    float *__restrict__ g_colors)
 {
     constexpr float HALF_LOG2E = 0.72134752044448170368f;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned gw = blockIdx.x * 4u + (unsigned)wv;
-    if (gw >= (unsigned)P.s) return;
-    __shared__ __attribute__((aligned(16))) float s_red[4][512];
-    BwdRec G;
-    bwd_fetch(V, gw, G);
-    const u4v bb = G.bb;
+    const int lane = threadIdx.x & 63, sl = lane & (SB_LANES - 1);
+    const unsigned j = (blockIdx.x * 256u + threadIdx.x) / SB_LANES;   // this lane's Gaussian (cell order)
+    const bool valid = j < (unsigned)P.s;
+    const size_t jj = valid ? j : (size_t)P.s - 1;
+    const uint2 bb = *reinterpret_cast<const uint2 *>(V.bbox + 2 * jj);
+    const float4 ra = V.rec[2 * jj], rb = V.rec[2 * jj + 1], fa = V.fin[2 * jj], fb = V.fin[2 * jj + 1];
     const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
     const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
-    const bool dead = c0 > c1;
-    if (dead && !(P.flags & GSASR_FLAG_OVERWRITE_GRADS)) return;
-    const float x = __uint_as_float(G.rec[0]), y = __uint_as_float(G.rec[1]);
-    const float cr = __uint_as_float(G.rec[5]), cg = __uint_as_float(G.rec[6]), cb = __uint_as_float(G.rec[7]);
-    const float cinv = __uint_as_float(G.fin[0]), kappa = __uint_as_float(G.fin[1]), rho = __uint_as_float(G.fin[2]);
-    const float isx = __uint_as_float(G.fin[3]), isy = __uint_as_float(G.fin[4]);
-    const int smp = (int)G.fin[6];
-    const float *__restrict__ go = grad_out + (size_t)smp * 3 * n_per - (size_t)smp * n_per;   // + original index
-    const bool test = BOUNDED && (bb.x & 0x8000u);
+    const bool dead = !valid || c0 > c1;
+    const float x = ra.x, y = ra.y, cr = rb.y, cg = rb.z, cb = rb.w;
+    const float cinv = fa.x, kappa = fa.y, rho = fa.z, isx = fa.w, isy = fb.x;
     const float nK1 = -HALF_LOG2E * cinv;
+    const float dmax = (BOUNDED && (bb.x & 0x8000u)) ? P.dmax : INFINITY;
+    const unsigned orig = __float_as_uint(fb.w);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!dead) {
-        const int pcx0 = c0 >> S.shx, pcx1 = c1 >> S.shx, pcy1 = r1 >> S.shy;
-        for (int pcy0 = r0 >> S.shy; pcy0 <= pcy1; pcy0 += 64) {   // (more than 64 rows of point-cells: large class only)
-        const int nrows = min(pcy1 - pcy0 + 1, 64);
-        unsigned sbeg = 0, send = 0;
-        if (lane < nrows) {
-            sbeg = S.start[(pcy0 + lane) * S.ncx + pcx0];
-            send = S.start[(pcy0 + lane) * S.ncx + pcx1 + 1];
+    // The candidates: every point of the point-cells the window touches, SB_ROWS rows of cells at a time as ONE run
+    // of indices (no per-row padding).  No window test per point: a point of a touched cell outside the window
+    // carries a term below exp(-tau), and cells never straddle two samples of a batched canvas (make_pt_view).
+    const int pcx0 = c0 >> S.shx, pcx1 = c1 >> S.shx, pcy1 = dead ? -1 : r1 >> S.shy;
+    for (int row = dead ? 0 : r0 >> S.shy; row <= pcy1; row += SB_ROWS) {
+        unsigned beg[SB_ROWS], cum[SB_ROWS];   // first point of row k; points in rows 0..k
+#pragma unroll
+        for (int k = 0; k < SB_ROWS; ++k) {
+            const bool ok = row + k <= pcy1;
+            const unsigned *p = S.start + (size_t)(ok ? row + k : row) * S.ncx;
+            beg[k] = p[pcx0];
+            cum[k] = ok ? p[pcx1 + 1] - beg[k] : 0u;
         }
-        for (int r = 0; r < nrows; ++r) {
-            const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)send, r);
-            for (unsigned i = (unsigned)__builtin_amdgcn_readlane((int)sbeg, r) + (unsigned)lane; i < e; i += 64u) {
-                const float4 pt = S.sorted[i];
-                const unsigned pxy = __float_as_uint(pt.z);
-                const int X = (int)(pxy & 0xffffu), Y = (int)(pxy >> 16);
-                if (X < c0 || X > c1 || Y < r0 || Y > r1) continue;
-                const float *gp3 = go + __float_as_uint(pt.w);
-                const float g0 = gp3[0], g1 = gp3[(size_t)n_per], g2 = gp3[2 * (size_t)n_per];
-                const float dx = pt.x - x, dy = pt.y - y;
-                const float u = dx * isx, vy = dy * isy, B = vy - rho * u;   // see bwd_trip
-                float v = __builtin_amdgcn_exp2f((B * nK1) * B - HALF_LOG2E * u * u);
-                if (test) v = (fabsf(dx) <= P.dmax && fabsf(dy) <= P.dmax) ? v : 0.f;
-                const float q = fmaf(g2, cb, fmaf(g1, cg, g0 * cr)) * v;
-                const float A = u * kappa - rho * B, qA = q * A, qB = q * B;
-                a[0] += qA; a[1] += qB; a[2] += qA * u; a[3] += qB * vy; a[4] += qA * B;
-                a[5] += v * g0; a[6] += v * g1; a[7] += v * g2;
-            }
+#pragma unroll
+        for (int k = 1; k < SB_ROWS; ++k) cum[k] += cum[k - 1];
+        for (unsigned f = (unsigned)sl; f < cum[SB_ROWS - 1]; f += SB_LANES) {
+            unsigned i = beg[0] + f;
+#pragma unroll
+            for (int k = 1; k < SB_ROWS; ++k) i = f >= cum[k - 1] ? beg[k] + (f - cum[k - 1]) : i;
+            const float4 pt = S.sorted[i], gr = S.grads[i];
+            const float dx = pt.x - x, dy = pt.y - y;
+            const float u = dx * isx, vy = dy * isy, B = vy - rho * u;   // see bwd_trip
+            float v = __builtin_amdgcn_exp2f((B * nK1) * B - HALF_LOG2E * u * u);
+            if (BOUNDED) v = fmaxf(fabsf(dx), fabsf(dy)) <= dmax ? v : 0.f;
+            const float q = fmaf(gr.z, cb, fmaf(gr.y, cg, gr.x * cr)) * v;
+            const float A = u * kappa - rho * B, qA = q * A, qB = q * B;
+            a[0] += qA; a[1] += qB; a[2] += qA * u; a[3] += qB * vy; a[4] += qA * B;
+            a[5] += v * gr.x; a[6] += v * gr.y; a[7] += v * gr.z;
         }
-        }
-        bwd_scale(a, cinv, isx, isy);
     }
-    const float d = wave_sum8(a, lane, s_red[wv]);
-    bwd_write(d, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
+    if (!dead) bwd_scale(a, cinv, isx, isy);
+    // sum over the Gaussian's lanes (within one DPP row of 16): its first lane gets the totals
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = a[k];
+        if (SB_LANES > 8) v += dpp_row_shl<8>(v);
+        if (SB_LANES > 4) v += dpp_row_shl<4>(v);
+        v += dpp_row_shl<2>(v);
+        v += dpp_row_shl<1>(v);
+        a[k] = v;
+    }
+    if (sl != 0 || !valid) return;
+    const bool store = (P.flags & GSASR_FLAG_OVERWRITE_GRADS) != 0u;
+    if (dead && !store) return;
+    float *pc = g_coords + (size_t)orig * stride2(P), *ps = g_sigmas + (size_t)orig * stride3(P),
+          *pk = g_colors + (size_t)orig * stride3(P);
+    if (store) {
+        pc[0] = a[0]; pc[1] = a[1]; ps[0] = a[2]; ps[1] = a[3]; ps[2] = a[4]; pk[0] = a[5]; pk[1] = a[6]; pk[2] = a[7];
+    } else {
+        atomicAdd(pc, a[0]); atomicAdd(pc + 1, a[1]); atomicAdd(ps, a[2]); atomicAdd(ps + 1, a[3]); atomicAdd(ps + 2, a[4]);
+        atomicAdd(pk, a[5]); atomicAdd(pk + 1, a[6]); atomicAdd(pk + 2, a[7]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2271,14 +2310,17 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
 // ---- sampled pixels --------------------------------------------------------------------------------
 namespace {
 struct PtLayout {
-    size_t off_start, off_sorted, total;
+    size_t off_start, off_cursor, off_sorted, off_grads, total;
 };
 PtLayout make_pt_layout(long n_total)
 {
     PtLayout L;
     L.off_start = 0;
-    L.off_sorted = align_up((size_t)(PT_CELLS + 2) * 4, 256);
-    L.total = L.off_sorted + align_up((size_t)(n_total > 0 ? n_total : 1) * 16, 256);
+    const size_t pts_bytes = align_up((size_t)(n_total > 0 ? n_total : 1) * 16, 256);
+    L.off_cursor = align_up((size_t)(PT_CELLS + 2) * 4, 256);
+    L.off_sorted = 2 * L.off_cursor;
+    L.off_grads = L.off_sorted + pts_bytes;
+    L.total = L.off_grads + pts_bytes;
     return L;
 }
 PtView make_pt_view(const gsasr_dims *d, void *ws, long n_total)
@@ -2286,16 +2328,29 @@ PtView make_pt_view(const gsasr_dims *d, void *ws, long n_total)
     const PtLayout L = make_pt_layout(n_total);
     PtView S;
     S.start = (unsigned *)((char *)ws + L.off_start);
+    S.cursor = (unsigned *)((char *)ws + L.off_cursor);
     S.sorted = (float4 *)((char *)ws + L.off_sorted);
-    // 16x16-px point-cells (the plan's cells) while their number fits the sort's LDS table; else coarser ones
-    S.shx = S.shy = CELL_SHIFT;
+    S.grads = (float4 *)((char *)ws + L.off_grads);
+    // 8x8-px point-cells while their number fits the sort's LDS table; else coarser ones.  On a batched canvas a
+    // cell must not straddle two slots (multiples of 16 rows): it grows in height to 16 rows at most, then in width.
+    S.shx = S.shy = PT_MIN_SHIFT;
+    const int max_shy = d->batch > 1 ? CELL_SHIFT : PT_MAX_SHIFT;
     for (;;) {
         S.ncx = ((d->w - 1) >> S.shx) + 1;
         S.ncy = ((d->h - 1) >> S.shy) + 1;
-        if ((long)S.ncx * S.ncy <= PT_CELLS) break;
-        if (S.ncy >= S.ncx && S.shy < PT_MAX_SHIFT) ++S.shy; else ++S.shx;
+        if ((long)S.ncx * S.ncy <= PT_CELLS || (S.shx >= PT_MAX_SHIFT && S.shy >= max_shy)) break;
+        if ((S.ncy >= S.ncx || S.shx >= PT_MAX_SHIFT) && S.shy < max_shy) ++S.shy; else ++S.shx;
     }
     return S;
+}
+int sort_points(const Params &P, const PlanView &V, const PtView &S, const int *points, int n_total, int n_per, hipStream_t st)
+{
+    HIP_TRY(hipMemsetAsync(S.start, 0, (size_t)(S.ncx * S.ncy + 2) * 4, st));
+    const dim3 grid((unsigned)((n_total + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_pts_count, grid, block, 0, st, P, V, S, points, n_total, n_per);
+    hipLaunchKernelGGL(k_pts_scan, dim3(1), dim3(1024), 0, st, S, n_total);
+    hipLaunchKernelGGL(k_pts_place, grid, block, 0, st, P, V, S, points, n_total, n_per);
+    return GSASR_OK;
 }
 int check_points(const gsasr_dims *dims, int n_points, const void *sample_ws, size_t sample_ws_bytes, long &n_total)
 {
@@ -2303,6 +2358,10 @@ int check_points(const gsasr_dims *dims, int n_points, const void *sample_ws, si
     if (n_points < 0) return fail(GSASR_ERR_ARG, "n_points < 0");
     n_total = (long)n_points * batch_of(dims);
     if (n_total > 0x7fffffffL) return fail(GSASR_ERR_ARG, "too many points");
+    {
+        const PtView S = make_pt_view(dims, const_cast<void *>(sample_ws), 0);
+        if ((long)S.ncx * S.ncy > PT_CELLS) return fail(GSASR_ERR_ARG, "batched canvas too large for the sampled-pixel path");
+    }
     if (!sample_ws || ((uintptr_t)sample_ws & 255u) || sample_ws_bytes < make_pt_layout(n_total).total)
         return fail(GSASR_ERR_WORKSPACE, "sample workspace null, misaligned or smaller than gsasr_sample_workspace_bytes()");
     return GSASR_OK;
@@ -2331,8 +2390,10 @@ int gsasr_splat_sample_forward(const gsasr_dims *dims, const void *workspace, si
     const PlanView V = make_view(L, const_cast<void *>(workspace));
     const PtView S = make_pt_view(dims, sample_ws, n_total);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_pts_sort, dim3(1), dim3(1024), 0, st, P, V, S, points, (int)n_total, n_points);
-    const dim3 grid((unsigned)(S.ncx * S.ncy + 1)), block(64 * SAMPLE_WAVES);   // one workgroup per point-cell (+ the invalid bucket)
+    if (int rc = sort_points(P, V, S, points, (int)n_total, n_points, st)) return rc;
+    // one workgroup per 16x16-px block of point-cells (or per coarser cell) + one for the out-of-range bucket
+    const int fsx = S.shx > CELL_SHIFT ? S.shx : CELL_SHIFT, fsy = S.shy > CELL_SHIFT ? S.shy : CELL_SHIFT;
+    const dim3 grid((unsigned)((((dims->w - 1) >> fsx) + 1) * (((dims->h - 1) >> fsy) + 1) + 1)), block(64 * SAMPLE_WAVES);
     if (P.bounded) hipLaunchKernelGGL(k_sample_fwd<true>, grid, block, 0, st, P, V, S, n_points, out);
     else hipLaunchKernelGGL(k_sample_fwd<false>, grid, block, 0, st, P, V, S, n_points, out);
     HIP_TRY(hipGetLastError());
@@ -2367,12 +2428,11 @@ int gsasr_splat_sample_backward(const float *sigmas, const float *coords, const 
     const PlanView V = make_view(L, const_cast<void *>(workspace));
     const PtView S = make_pt_view(dims, sample_ws, n_total);
     if (points)   // NULL: sample_ws still holds the sorted points of the forward call
-        hipLaunchKernelGGL(k_pts_sort, dim3(1), dim3(1024), 0, st, P, V, S, points, (int)n_total, n_points);
-    const dim3 grid((unsigned)((dims->s + 3) / 4)), block(256);
-    if (P.bounded)
-        hipLaunchKernelGGL(k_sample_bwd<true>, grid, block, 0, st, P, V, S, n_points, grad_out, g_sigmas, g_coords, g_colors);
-    else
-        hipLaunchKernelGGL(k_sample_bwd<false>, grid, block, 0, st, P, V, S, n_points, grad_out, g_sigmas, g_coords, g_colors);
+        if (int rc = sort_points(P, V, S, points, (int)n_total, n_points, st)) return rc;
+    hipLaunchKernelGGL(k_pts_grads, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, st, S, grad_out, (int)n_total, n_points);
+    const dim3 grid((unsigned)(((size_t)dims->s * SB_LANES + 255) / 256)), block(256);   // SB_LANES lanes per Gaussian
+    if (P.bounded) hipLaunchKernelGGL(k_sample_bwd<true>, grid, block, 0, st, P, V, S, g_sigmas, g_coords, g_colors);
+    else hipLaunchKernelGGL(k_sample_bwd<false>, grid, block, 0, st, P, V, S, g_sigmas, g_coords, g_colors);
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
 }

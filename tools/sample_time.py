@@ -38,8 +38,8 @@ def run(frac, batched):
         pa = p.detach().requires_grad_(True)
         if batched:
             out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, [scale] * B, sm, dmax=dmax, sample_coords=pts)
-            if out.dim() == 4:      # full render: gather here as the reference's loop would
-                out = torch.stack([out[b][:, pts[b, :, 0], pts[b, :, 1]] for b in range(B)])
+            if out.dim() == 4:      # full render: ONE vectorised gather of the whole batch (the reference indexes per point)
+                out = out[torch.arange(B, device=dev)[:, None], :, pts[:, :, 0], pts[:, :, 1]].permute(0, 2, 1)
             (out * wgt).sum().backward()
         else:
             loss = 0
