@@ -16,7 +16,8 @@
 //            k_bin       counting-sort placement (cell start + rank) fused with packing: 32-byte records
 //                        {x, y, A, B, C, r, g, b} (A,B,C = exponent coefficients with log2(e) folded,
 //                        computed in double), backward-epilogue constants, 16-byte windows with the
-//                        per-tile-band column spans of the ellipse {exponent >= -tau}.
+//                        per-tile-band column spans of the ellipse {exponent >= -tau}, and the first 8 bytes of the
+//                        windows once more as a dense array for the coarse tests.
 //   forward  k_render_fwd2 PIXEL-stationary: one wave64 = one 8x16 pixel sub-tile (2 px per lane, packed
 //                        fp32), RGB accumulators in registers; four sub-tiles side by side per workgroup.  Two-level
 //                        walk: the workgroup tests the candidates of its 32x16 tile (cell rows within the class'
@@ -40,6 +41,9 @@
 //                        neighbouring rank and their partial gradients come back.
 //   batch    a batched canvas (gsasr_dims.batch > 1, row f2) runs B samples of different sizes through the same
 //                        kernels: per-sample geometry (Geo) instead of the image's.
+//   sampled  k_pts_count/scan/place, k_sample_fwd, k_pts_grads, k_sample_bwd   values and gradients at a list of
+//                        pixels only (the reference's `sample_coords`, row f4): point-stationary two-level walk forward,
+//                        Gaussian-stationary backward with eight Gaussians per wave.
 //
 // No MFMA: this is gather/scatter-accumulate with one transcendental per pair, not a contraction.
 #include <hip/hip_runtime.h>

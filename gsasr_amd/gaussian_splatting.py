@@ -140,9 +140,10 @@ class _FusedBatchSampled(torch.autograd.Function):
                 None, None, None, None)
 
 
-# The sampled path costs one wave per point and one candidate walk per point: it wins while the points are a
-# fraction of the image (measured break-even near 1/2 of the pixels); denser requests render the image.
-SAMPLED_MAX_FRACTION = 0.25
+# Kernel time of the sampled path equals the full render's at about a quarter of the pixels, but the alternative ends
+# in a torch advanced-indexing gather whose backward (index_put_ with accumulate) takes longer than either rasterizer
+# (DESIGN.md 3b): the sampled kernels are used unless the points outnumber the pixels.
+SAMPLED_MAX_FRACTION = 1.0
 
 
 def _as_points(sample_coords):
