@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- HR Mpixels/s of the rasterizer hot path (forward + backward) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dmax 0.1] [--config c2|c3|c4|profile-log]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dmax 0.1] [--config c2|c3|c4|c5|c5s]
 
 A "step" is one pass of the hot path over one batch of synthetic Gaussians already resident in HBM:
 plan (bin) -> forward splat into a fresh [H,W,3] image -> backward to {sigmas, coords, colors}, exactly what
@@ -40,6 +40,9 @@ CONFIGS = {
     # rasterizer work of BASELINE config 5 (the training step): 16 samples of 48x48 LR crops x4, 16 Gaussians per LR
     # pixel (fea2gs), dmax 0.5, raw decoder parameters in, gradient w.r.t. them out -- ONE batched canvas
     "c5": (48, 48, 4.0, "config5 rasterizer: batch 16 x (48x48 LR -> x4, 36864 Gaussians), prologue+fwd+bwd, batched canvas"),
+    # the same batch trained on `sample_coords` (sample_size = 2304 = 48^2 of the 192^2 pixels per sample): only those
+    # pixels are evaluated; value = SAMPLED pixels per second
+    "c5s": (48, 48, 4.0, "config5 rasterizer with sample_coords: batch 16 x (36864 Gaussians, 2304 of 192^2 pixels), prologue+fwd+bwd, sampled-pixel kernels"),
 }
 
 
@@ -68,7 +71,8 @@ class Step:
         from gsasr_amd.shard import row_band
         self.cabi, self.dev, self.rank, self.world = _cabi, dev, rank, world
         h_lr, w_lr, scale, _ = CONFIGS[args.config]
-        self.batched = args.config == "c5"
+        self.batched = args.config in ("c5", "c5s")
+        self.sampled = args.config == "c5s"
         if self.batched:
             self.init_batched(args, dev, h_lr, w_lr, scale)
             return
@@ -155,10 +159,27 @@ class Step:
         self.gp = torch.empty_like(self.p)
         self.rows = (0, self.bdims.h)
         self.plan = _cabi.Plan(self.bdims, self.ws, dev)
+        if self.sampled:
+            S = h_lr * w_lr                    # sample_size: as many points as one LR crop has pixels
+            g = torch.Generator().manual_seed(1234 + self.rank)
+            self.pts = torch.stack([torch.randint(0, H, (B, S), generator=g), torch.randint(0, W, (B, S), generator=g)],
+                                   dim=2).to(device=dev, dtype=torch.int32).contiguous()
+            self.S = S
+            self.out = torch.empty(B, 3, S, device=dev)
+            self.grad_out = torch.rand(B, 3, S, device=dev)
+            self.sws = torch.empty(L.gsasr_sample_workspace_bytes(ctypes.byref(self.bdims), S), dtype=torch.uint8, device=dev)
+            self.H, self.W = B * S * self.world, 1     # "pixels" reported = the sampled ones
+            self.pix_rank = B * S
 
     def batched_forward(self):
         import ctypes
         c = self.cabi
+        if self.sampled:
+            c.check(c.lib().gsasr_step_sample_forward(self.p.data_ptr(), self.steps.data_ptr(), ctypes.byref(self.bdims),
+                                                      self.ws.data_ptr(), self.ws.numel(), self.pts.data_ptr(), self.S,
+                                                      self.out.data_ptr(), self.sws.data_ptr(), self.sws.numel(),
+                                                      c._stream(self.dev)), "gsasr_step_sample_forward")
+            return
         c.check(c.lib().gsasr_step_forward(self.p.data_ptr(), self.steps.data_ptr(), ctypes.byref(self.bdims),
                                            self.ws.data_ptr(), self.ws.numel(), self.img.data_ptr(), c._stream(self.dev)),
                 "gsasr_step_forward")
@@ -166,6 +187,12 @@ class Step:
     def batched_backward(self):
         import ctypes
         c = self.cabi
+        if self.sampled:    # (points = NULL: the sorted points of the forward call are still in the scratch)
+            c.check(c.lib().gsasr_step_sample_backward(self.p.data_ptr(), self.steps.data_ptr(), self.grad_out.data_ptr(),
+                                                       self.gp.data_ptr(), ctypes.byref(self.bdims), self.ws.data_ptr(),
+                                                       self.ws.numel(), None, self.S, self.sws.data_ptr(), self.sws.numel(),
+                                                       c._stream(self.dev)), "gsasr_step_sample_backward")
+            return
         c.check(c.lib().gsasr_step_backward(self.p.data_ptr(), self.steps.data_ptr(), self.grad_img.data_ptr(),
                                             self.gp.data_ptr(), ctypes.byref(self.bdims), self.ws.data_ptr(),
                                             self.ws.numel(), c._stream(self.dev)), "gsasr_step_backward")
@@ -432,7 +459,9 @@ def main():
             traffic = json.load(open(pmc)).get({"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom], {}).get("hbm_bytes")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
+    kname = {"forward": "k_sample_fwd", "backward": "k_sample_bwd"} if getattr(step, "sampled", False) else \
+        {"forward": "k_render_fwd", "backward": "k_render_bwd"}
+    roofline = {"bound": "hbm", "kernel": kname[dom],
                 "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                 "note": "stage times from events on the launch stream; outputs are stored, not accumulated (no memsets)"}
@@ -464,6 +493,7 @@ def main():
         h_lr, w_lr, scale, desc = CONFIGS[args.config]
         out = {
             "metric": ("HR Mpixels/sec fwd+bwd (x4, 1 Gaussian/LR px); achieved HBM GB/s vs roofline" if args.config == "c2"
+                       else "sampled HR Mpixels/sec prologue+fwd+bwd (x4, 16 Gaussians/LR px, batch 16, sample_coords)" if getattr(step, "sampled", False)
                        else "HR Mpixels/sec prologue+fwd+bwd (x4, 16 Gaussians/LR px, batch 16)" if step.batched else f"HR Mpixels/sec {'fwd only' if step.fwd_only else 'fwd+bwd'} (x{scale:g}, 1 Gaussian/LR px)"),
             "value": mpix, "unit": "HR Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if step.strong else "weak",

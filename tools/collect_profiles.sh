@@ -42,3 +42,9 @@ cat $OUT/e2e_time.txt | tail -5
 python bench.py --no-cpu-baseline --config c5 > $OUT/bench_c5.json 2>> $OUT/bench.err
 python tools/e2e_batch_time.py > $OUT/e2e_batch_time.txt 2>&1
 tail -c 400 $OUT/bench_c5.json; tail -2 $OUT/e2e_batch_time.txt
+# 5. the sampled-pixel path: bench line, host-API timing, per-kernel device times
+python bench.py --no-cpu-baseline --config c5s > $OUT/bench_c5s.json 2>> $OUT/bench.err
+python tools/sample_time.py > $OUT/sample_time.txt 2>&1
+(cd /tmp && SAMPLE_TIME_HOST=0 rocprofv3 --kernel-trace --stats -d /tmp/kts_$TAG -o kt -- python $R/tools/sample_time.py > /dev/null 2> $OUT/kts.err
+ python $R/tools/rocpd_summary.py /tmp/kts_$TAG/kt_results.db --skip 2 > $OUT/sampled_kernel_stats.txt)
+tail -c 600 $OUT/bench_c5s.json; cat $OUT/sample_time.txt | tail -7; head -14 $OUT/sampled_kernel_stats.txt
