@@ -2417,23 +2417,17 @@ int gsasr_splat_sample_backward(const float *sigmas, const float *coords, const 
     if (!g_sigmas || !g_coords || !g_colors) return fail(GSASR_ERR_ARG, "null pointer");
     (void)sigmas; (void)coords; (void)colors;   // (everything the kernel needs is in the plan)
     hipStream_t st = (hipStream_t)stream;
-    if (n_total == 0) {  // no points: the gradient is zero
-        if (dims->flags & GSASR_FLAG_OVERWRITE_GRADS) {
-            const size_t k3 = (dims->flags & GSASR_FLAG_STRIDE8) ? 0 : 3, k2 = (dims->flags & GSASR_FLAG_STRIDE8) ? 0 : 2;
-            if (!k3) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 with zero points");
-            HIP_TRY(hipMemsetAsync(g_sigmas, 0, sizeof(float) * k3 * (size_t)dims->s, st));
-            HIP_TRY(hipMemsetAsync(g_coords, 0, sizeof(float) * k2 * (size_t)dims->s, st));
-            HIP_TRY(hipMemsetAsync(g_colors, 0, sizeof(float) * k3 * (size_t)dims->s, st));
-        }
-        return GSASR_OK;
-    }
-    if (!grad_out) return fail(GSASR_ERR_ARG, "null pointer");
+    if (n_total > 0 && !grad_out) return fail(GSASR_ERR_ARG, "null pointer");
     const Params P = make_params(dims, L);
     const PlanView V = make_view(L, const_cast<void *>(workspace));
     const PtView S = make_pt_view(dims, sample_ws, n_total);
-    if (points)   // NULL: sample_ws still holds the sorted points of the forward call
-        if (int rc = sort_points(P, V, S, points, (int)n_total, n_points, st)) return rc;
-    hipLaunchKernelGGL(k_pts_grads, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, st, S, grad_out, (int)n_total, n_points);
+    if (n_total == 0) {   // no points: empty point-cells, the kernel below writes (or adds) zeros
+        HIP_TRY(hipMemsetAsync(S.start, 0, (size_t)(S.ncx * S.ncy + 2) * 4, st));
+    } else {
+        if (points)   // NULL: sample_ws still holds the sorted points of the forward call
+            if (int rc = sort_points(P, V, S, points, (int)n_total, n_points, st)) return rc;
+        hipLaunchKernelGGL(k_pts_grads, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, st, S, grad_out, (int)n_total, n_points);
+    }
     const dim3 grid((unsigned)(((size_t)dims->s * SB_LANES + 255) / 256)), block(256);   // SB_LANES lanes per Gaussian
     if (P.bounded) hipLaunchKernelGGL(k_sample_bwd<true>, grid, block, 0, st, P, V, S, g_sigmas, g_coords, g_colors);
     else hipLaunchKernelGGL(k_sample_bwd<false>, grid, block, 0, st, P, V, S, g_sigmas, g_coords, g_colors);

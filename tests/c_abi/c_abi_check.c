@@ -215,6 +215,60 @@ int main(void)
         if (tot != 8.0 * (eu + ed)) bad = 1;
         free(pk); free(ones); free(g); free(iu);
     }
+    /* sampled pixels: values and gradients at a list of points only == gather of the full image / backward of a
+       gradient image that is zero except at the points (repeats accumulate) */
+    {
+        const int np = 777;
+        const float dmax = 0.3f;
+        int *pts = malloc(sizeof(int) * 2 * np), *d_pts;
+        float *go = malloc(sizeof(float) * 3 * np), *out = malloc(sizeof(float) * 3 * np), *d_go, *d_out;
+        float *wsp = calloc((size_t)3 * h * w, sizeof(float));
+        for (int i = 0; i < np; ++i) {
+            pts[2 * i] = (int)(frand(&seed) * h) % h;
+            pts[2 * i + 1] = (int)(frand(&seed) * w) % w;
+        }
+        pts[2] = pts[0]; pts[3] = pts[1];            /* a repeated point */
+        pts[4] = -1; pts[5] = -w;                    /* wraps to (h-1, 0) */
+        for (int i = 0; i < 3 * np; ++i) go[i] = frand(&seed);
+        for (int i = 0; i < np; ++i) {
+            const int r = pts[2 * i] < 0 ? pts[2 * i] + h : pts[2 * i], c = pts[2 * i + 1] < 0 ? pts[2 * i + 1] + w : pts[2 * i + 1];
+            for (int k = 0; k < 3; ++k) wsp[((size_t)r * w + c) * 3 + k] += go[(size_t)k * np + i];
+        }
+        gsasr_dims d = {s, h, w, 3, dmax, 0, h, 0.f, GSASR_FLAG_OVERWRITE_GRADS};
+        const size_t bytes = gsasr_splat_workspace_bytes(&d), sbytes = gsasr_sample_workspace_bytes(&d, np);
+        void *ws, *sws;
+        CK(hipMalloc(&ws, bytes)); CK(hipMalloc(&sws, sbytes));
+        CK(hipMalloc((void **)&d_pts, sizeof(int) * 2 * np)); CK(hipMalloc((void **)&d_go, sizeof(float) * 3 * np));
+        CK(hipMalloc((void **)&d_out, sizeof(float) * 3 * np));
+        CK(hipMemcpy(d_pts, pts, sizeof(int) * 2 * np, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_go, go, sizeof(float) * 3 * np, hipMemcpyHostToDevice));
+        OK(gsasr_splat_plan(d_sig, d_xy, d_col, &d, ws, bytes, st));
+        OK(gsasr_splat_sample_forward(&d, ws, bytes, d_pts, np, d_out, sws, sbytes, st));
+        OK(gsasr_splat_sample_backward(d_sig, d_xy, d_col, d_go, d_gs, d_gc, d_gk, &d, ws, bytes, NULL, np, sws, sbytes, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(out, d_out, sizeof(float) * 3 * np, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gs, d_gs, sizeof(float) * 3 * s, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gc, d_gc, sizeof(float) * 2 * s, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gk, d_gk, sizeof(float) * 3 * s, hipMemcpyDeviceToHost));
+        gsref_forward_f64(sig, xy, col, ref, s, h, w, dmax, 0, h);
+        gsref_backward_f64(sig, xy, col, wsp, rs, rc, rk, s, h, w, dmax, 0, h);
+        double eo = 0;
+        for (int i = 0; i < np; ++i) {
+            const int r = pts[2 * i] < 0 ? pts[2 * i] + h : pts[2 * i], c = pts[2 * i + 1] < 0 ? pts[2 * i + 1] + w : pts[2 * i + 1];
+            for (int k = 0; k < 3; ++k) {
+                const double dd = fabs((double)out[(size_t)k * np + i] - ref[((size_t)r * w + c) * 3 + k]);
+                if (dd > eo) eo = dd;
+            }
+        }
+        const double e1 = maxrel(gs, rs, 3 * s), e2 = maxrel(gc, rc, 2 * s), e3 = maxrel(gk, rk, 3 * s);
+        printf("sampled pixels (%d points): value max|err| %.3e, grad rel err %.2e %.2e %.2e\n", np, eo, e1, e2, e3);
+        if (!(eo <= 2e-4) || !(e1 <= 2e-4) || !(e2 <= 2e-4) || !(e3 <= 2e-4)) bad = 1;
+        gsasr_dims band = d;
+        band.row0 = 10;
+        if (gsasr_splat_sample_forward(&band, ws, bytes, d_pts, np, d_out, sws, sbytes, st) == 0) { printf("row band accepted by the sampled path\n"); bad = 1; }
+        CK(hipFree(ws)); CK(hipFree(sws)); CK(hipFree(d_pts)); CK(hipFree(d_go)); CK(hipFree(d_out));
+        free(pts); free(go); free(out); free(wsp);
+    }
     /* error behaviour: status + message instead of a crash */
     if (gsasr_gs_render_dmax(d_sig, d_xy, d_col, d_img, s, h, w, 4, 0.1f, st) == 0) { printf("c=4 accepted\n"); bad = 1; }
     printf("%s\n", bad ? "C-ABI CHECK FAILED" : "C-ABI CHECK OK");

@@ -219,3 +219,22 @@ def test_batched_sampled_equals_per_sample(dev):
     (o2 * wgt).sum().backward()
     assert float((o1 - o2).abs().max()) <= 2e-5
     assert _relmax(p1.grad.cpu().numpy(), p2.grad.cpu().numpy()) <= GRAD_RTOL
+
+
+def test_sampled_path_errors_are_runtimeerrors(dev):
+    """bad points, a row band, a mismatching gradient: RuntimeError (the reference's failure mode), never a crash"""
+    from gsasr_amd import _cabi
+    sig, xy, col, H, W = _synth(16, 16, 4.0, seed=1)
+    a, b, c = (t.to(dev).contiguous() for t in (sig, xy, col))
+    plan = _cabi.plan(a, b, c, H, W, 0.2)
+    with pytest.raises(RuntimeError, match="points"):
+        _cabi.sample_forward(plan, torch.zeros(5, 3, dtype=torch.int64, device=dev))
+    with pytest.raises(RuntimeError, match="points"):
+        _cabi.sample_forward(plan, torch.zeros(5, 2, device=dev))            # floating point
+    band = _cabi.plan(a, b, c, H, W, 0.2, rows=(16, 32))
+    with pytest.raises(RuntimeError, match="whole image"):
+        _cabi.sample_forward(band, torch.zeros(5, 2, dtype=torch.int64, device=dev))
+    out, st = _cabi.sample_forward(plan, torch.zeros(5, 2, dtype=torch.int64, device=dev))
+    g = (torch.empty_like(a), torch.empty_like(b), torch.empty_like(c))
+    with pytest.raises(RuntimeError, match="grad_out"):
+        _cabi.sample_backward(plan, st, a, b, c, torch.zeros(3, 4, device=dev), *g)
