@@ -634,15 +634,17 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         unsigned sum = 0;
 #pragma unroll
         for (int k = 0; k < FUSED_PER_THREAD; ++k) sum += c[k];
-        s_part[t] = sum;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const unsigned v = t >= o ? s_part[t - o] : 0u;
-            __syncthreads();
-            s_part[t] += v;
-            __syncthreads();
+        // block scan of the 256 partial sums: inside the waves with shuffles, across the four waves through LDS
+        // (one barrier instead of the sixteen of a Hillis-Steele loop over s_part)
+        unsigned inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = (unsigned)__shfl_up((int)inc, o);
+            if ((t & 63) >= o) inc += v;
         }
-        unsigned run = s_part[t] - sum;
+        if ((t & 63) == 63) s_part[t >> 6] = inc;
+        __syncthreads();
+        unsigned run = inc - sum;
+        for (int k = 0; k < (t >> 6); ++k) run += s_part[k];
 #pragma unroll
         for (int k = 0; k < FUSED_PER_THREAD; ++k) {
             if (b0 + k <= ncls) s_start[b0 + k] = run;
