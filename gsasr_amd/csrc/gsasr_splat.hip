@@ -1645,7 +1645,9 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
     // the workgroup's block of point-cells: 16x16 px (2x2 cells of 8 px), or one coarser cell
     const int fsx = max(S.shx, CELL_SHIFT), fsy = max(S.shy, CELL_SHIFT);
     const int nbx = ((P.w - 1) >> fsx) + 1, nby = ((P.h - 1) >> fsy) + 1, npc = S.ncx * S.ncy;
-    const int blk = blockIdx.x;
+    // (XCD-aware order, as in the full forward: each XCD takes a contiguous band of blocks, whose survivors' records then
+    // sit in ONE L2; the last workgroup handles the out-of-range points)
+    const int blk = (int)blockIdx.x == nbx * nby ? nbx * nby : (int)xcd_swizzle(blockIdx.x, (unsigned)(nbx * nby));
     if (blk == nbx * nby) {   // the out-of-range points: nothing is rendered there
         const unsigned pbeg = S.start[npc], pend = S.start[npc + 1];
         for (unsigned i = pbeg + threadIdx.x; i < pend; i += 64 * SAMPLE_WAVES) {
@@ -1822,7 +1824,8 @@ __global__ __launch_bounds__(256) void k_sample_bwd(Params P, PlanView V, PtView
 {
     constexpr float HALF_LOG2E = 0.72134752044448170368f;
     const int lane = threadIdx.x & 63, sl = lane & (SB_LANES - 1);
-    const unsigned j = (blockIdx.x * 256u + threadIdx.x) / SB_LANES;   // this lane's Gaussian (cell order)
+    // (XCD-banded order as in k_render_bwd: an XCD sweeps a contiguous run of the cell-ordered Gaussians = a band of points)
+    const unsigned j = (xcd_swizzle(blockIdx.x, gridDim.x) * 256u + threadIdx.x) / SB_LANES;   // this lane's Gaussian (cell order)
     const bool valid = j < (unsigned)P.s;
     const size_t jj = valid ? j : (size_t)P.s - 1;
     const uint2 bb = *reinterpret_cast<const uint2 *>(V.bbox + 2 * jj);
