@@ -1530,16 +1530,19 @@ __global__ __launch_bounds__(256) void k_pts_count(Params P, PlanView V, PtView 
 
 __global__ __launch_bounds__(1024) void k_pts_scan(PtView S, int n_total)
 {
-    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_c[PT_CELLS + 1], s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int npc = S.ncx * S.ncy;
-    // exclusive scan of npc + 1 counts in place: consecutive entries per thread, wave scan, 16 wave totals
+    // exclusive scan of npc + 1 counts in place, through LDS so that global memory is read and written coalesced:
+    // consecutive entries per thread, wave scan, 16 wave totals
+    for (int e = tid; e <= npc; e += 1024) s_c[e] = S.start[e];
+    __syncthreads();
     constexpr int PER = (PT_CELLS + 1 + 1023) / 1024;
     unsigned loc[PER], sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int e = tid * PER + k;
-        loc[k] = e <= npc ? S.start[e] : 0u;
+        loc[k] = e <= npc ? s_c[e] : 0u;
         sum += loc[k];
     }
     unsigned inc = sum;
@@ -1549,17 +1552,19 @@ __global__ __launch_bounds__(1024) void k_pts_scan(PtView S, int n_total)
     }
     if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
-    unsigned base = 0;
-    for (int k = 0; k < wv; ++k) base += s_wave[k];
-    unsigned run = base + inc - sum;
+    unsigned run = inc - sum;
+    for (int k = 0; k < wv; ++k) run += s_wave[k];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int e = tid * PER + k;
-        if (e <= npc) {
-            S.start[e] = run;
-            S.cursor[e] = run;
-        }
+        if (e <= npc) s_c[e] = run;
         run += loc[k];
+    }
+    __syncthreads();
+    for (int e = tid; e <= npc; e += 1024) {
+        const unsigned v = s_c[e];
+        S.start[e] = v;
+        S.cursor[e] = v;
     }
     if (tid == 0) S.start[npc + 1] = (unsigned)n_total;
 }
