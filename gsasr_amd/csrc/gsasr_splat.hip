@@ -1482,12 +1482,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 // ---------------------------------------------------------------------------------------------------
 // sampled pixels.  The reference renders the whole image and then picks `sample_coords`
 // out of it (utils/gaussian_splatting.py:214-216); here only the requested points are evaluated.
-//   k_pts_sort    one workgroup: counting sort of the points into point-cells (at most 64 x 64 of them, the
-//                 histogram and its scan live in LDS); out-of-range points go to a last bucket.
-//   k_sample_fwd  POINT-stationary: one wave64 = one point, its lanes spread over the Gaussians binned within
-//                 reach (the forward's candidate walk with a 1x1 tile); no atomics, one wave reduction.
-//   k_sample_bwd  GAUSSIAN-stationary: one wave64 = one Gaussian, its lanes spread over the sorted points of the
-//                 point-cells its window touches; same epilogue as k_render_bwd.
+//   k_pts_count / k_pts_scan / k_pts_place   counting sort of the points into point-cells (8x8 px; coarser when the
+//                 image has more than PT_CELLS of those); a sorted point carries its px, py; out-of-range points go to
+//                 a last bucket.  k_pts_grads (backward) gathers the upstream gradient into the same order.
+//   k_sample_fwd  POINT-stationary two-level walk: one workgroup = the points of a 16x16-px block; level 1 lists the
+//                 Gaussians whose window meets the block, level 2 evaluates each of them (one per lane, loaded once) at
+//                 all the block's points; no atomics on the output.
+//   k_sample_bwd  GAUSSIAN-stationary, eight Gaussians per wave64: a Gaussian's 8 lanes stride over the sorted points
+//                 of the point-cells its window touches; same sums and epilogue as k_render_bwd.
 // ---------------------------------------------------------------------------------------------------
 constexpr int PT_CELLS = 12288;                    // point-cells at most: their histogram + scan live in LDS (48 KB)
 constexpr int PT_MIN_SHIFT = 3, PT_MAX_SHIFT = 9;  // point-cells are 8..512 px a side
@@ -1605,17 +1607,18 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
 }
 
-// Forward at the points of ONE point-cell per workgroup, as a two-level walk (cf. fwd_block): the four waves test the
-// Gaussians binned within reach of the cell's rectangle once, cooperatively, into a survivor list in LDS (rounds of
-// SAMPLE_LIST candidates: one batch of loads per wave); then every lane takes a survivor, loads it ONCE and evaluates
-// it at SAMPLE_GROUP points at a time (the cell's points sit in LDS, read as broadcasts); the per-point colour sums
-// are reduced over the wave with DPP and over the waves in LDS.  Everything here is a short dependent chain, so the
-// kernel is built to keep many workgroups resident (64 VGPRs, 10 KB of LDS).  Block ncx*ncy zeroes the outputs of
-// the out-of-range points.
+// Forward at the points of ONE 16x16-px block of point-cells per workgroup, as a two-level walk (cf. fwd_block).
+// Level 1: the four waves stride through the Gaussians binned within reach of the block's rectangle (row of plan cells by
+// row, SAMPLE_CHUNKS dense windows in flight per lane) and append those whose window meets the rectangle to a survivor
+// list in LDS.  Level 2: every lane takes a survivor, loads its record ONCE (the next one prefetched) and evaluates it at
+// all the block's points -- staged in LDS, read as broadcasts, two points per packed-fp32 instruction -- into per-lane
+// accumulators that live in registers across the whole walk; one DPP reduction over the wave and an LDS combine over
+// the waves at the end.  128 VGPRs (the accumulators), 33 KB of LDS (the list): four workgroups per CU.  The last
+// workgroup zeroes the outputs of the out-of-range points.
 constexpr int SAMPLE_WAVES = 4;
 constexpr int SAMPLE_CHUNKS = 8;      // candidate windows in flight per lane (level 1)
 constexpr int SAMPLE_LIST = 8192;     // capacity of the survivor list = candidates tested between two level-2 passes
-constexpr int SAMPLE_BLOCK = 24;   // points of a cell evaluated per walk: their sums stay in registers (72 VGPRs; 32 spills at 4 waves per SIMD)
+constexpr int SAMPLE_BLOCK = 24;      // points evaluated per walk: 72 accumulator VGPRs (28: 22 spills at 4 waves per SIMD; 16: 45% of the blocks walk twice)
 
 // One Gaussian per lane against the points staged in LDS (broadcast reads), two points per packed-fp32 operation.
 template <bool TEST>
