@@ -112,17 +112,24 @@ class Step:
             self.ex.own.copy_(mine)
             self.n_rank = n_local
             self.plan = _cabi.plan_packed(self.ex.records, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
+            ok = 1.0
             try:    # one trial swap each way before anything is timed: a transport that cannot do grouped
-                    # send/recv shows up here, on every rank alike, and the collective pattern takes over
+                    # send/recv shows up here and the collective pattern takes over
                 self.ex.exchange_forward()
                 self.ex.exchange_backward()
                 torch.cuda.synchronize(dev)
-                return
             except Exception as e:
+                ok = 0.0
                 print(f"[bench] rank {rank}: halo exchange unavailable ({e!r}); using broadcast + reduce_scatter",
                       file=sys.stderr)
-                self.halo, self.ex = False, None
-                self.n_rank = self.n
+            if world > 1:   # every rank takes the same data path: if one of them could not swap, none does
+                flag = torch.tensor([ok], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = float(flag.item())
+            if ok == 1.0:
+                return
+            self.halo, self.ex = False, None
+            self.n_rank = self.n
         self.sig, self.xy, self.col = (t.to(dev) for t in (sig, xy, col))
         self.g = [torch.zeros_like(t) for t in (self.sig, self.xy, self.col)]
         self.plan = _cabi.plan(self.sig, self.xy, self.col, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
