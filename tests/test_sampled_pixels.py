@@ -238,3 +238,25 @@ def test_sampled_path_errors_are_runtimeerrors(dev):
     g = (torch.empty_like(a), torch.empty_like(b), torch.empty_like(c))
     with pytest.raises(RuntimeError, match="grad_out"):
         _cabi.sample_backward(plan, st, a, b, c, torch.zeros(3, 4, device=dev), *g)
+
+
+def test_sampled_path_under_bf16_autocast(dev):
+    """AMP configs run the op inside torch.autocast (gsasr_amp_model.py:208): the sampled Functions compute in fp32"""
+    from gsasr_amd import gaussian_splatting as gsp
+    g = torch.Generator().manual_seed(3)
+    raw = 0.5 * torch.randn(16 * 16, 9, generator=g)
+    raw[:, 7:9] = torch.rand(16 * 16, 2, generator=g)
+    pts = _points(64, 64, 200, 4, dev)
+    kw = dict(default_step_size=1.2, mode="scale_modify", if_dmax=True, dmax_mode="fix", dmax=0.4)
+    p0 = raw.clone().to(dev).requires_grad_(True)
+    ref = gsp.generate_2D_gaussian_splatting_step((64, 64), p0, 4.0, torch.tensor([4.0, 4.0]), sample_coords=pts, **kw)
+    ref.sum().backward()
+    p1 = raw.clone().to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = gsp.generate_2D_gaussian_splatting_step((64, 64), p1.bfloat16().float(), 4.0, torch.tensor([4.0, 4.0]),
+                                                      sample_coords=pts, **kw)
+        out2 = gsp.generate_2D_gaussian_splatting_step((64, 64), p1, 4.0, torch.tensor([4.0, 4.0]), sample_coords=pts, **kw)
+    assert out.dtype == torch.float32 and out2.dtype == torch.float32
+    out2.sum().backward()
+    assert float((out2 - ref).abs().max()) <= 2e-6
+    assert _relmax(p1.grad.cpu().numpy(), p0.grad.cpu().numpy()) <= 1e-5
