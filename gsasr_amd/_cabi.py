@@ -32,6 +32,11 @@ FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
 FLAG_OVERWRITE_GRADS = 4   # GSASR_FLAG_OVERWRITE_GRADS
 FLAG_CHW_IMAGE = 8         # GSASR_FLAG_CHW_IMAGE
 FLAG_STRIDE8 = 16          # GSASR_FLAG_STRIDE8
+FLAG_CHW_GRAD = 32         # GSASR_FLAG_CHW_GRAD
+FLAG_FORWARD_ONLY = 64     # GSASR_FLAG_FORWARD_ONLY
+FLAG_BWD_GAUSSIAN = 128    # GSASR_FLAG_BWD_GAUSSIAN
+FLAG_BWD_TILE = 256        # GSASR_FLAG_BWD_TILE
+FLAG_BWD_ATOMIC = 512      # GSASR_FLAG_BWD_ATOMIC
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -41,7 +46,8 @@ class Dims(ctypes.Structure):
     _fields_ = [("s", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("c", ctypes.c_int),
                 ("dmax", ctypes.c_float), ("row0", ctypes.c_int), ("row1", ctypes.c_int),
                 ("cutoff", ctypes.c_float), ("flags", ctypes.c_uint),
-                ("batch", ctypes.c_int), ("slot", ctypes.c_int), ("sample_hw", ctypes.POINTER(ctypes.c_int))]
+                ("batch", ctypes.c_int), ("slot", ctypes.c_int), ("sample_hw", ctypes.POINTER(ctypes.c_int)),
+                ("grad_rows", ctypes.c_int)]
 
 
 _lib = None
@@ -105,7 +111,7 @@ def lib():
         L.gsasr_get_default_cutoff.restype = f
         L.gsasr_resolve_cutoff.restype = f
         L.gsasr_resolve_cutoff.argtypes = [f, i]
-        if L.gsasr_abi_version() != 2:
+        if L.gsasr_abi_version() != 3:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
     return _lib
@@ -330,14 +336,16 @@ def prologue_backward(gs_parameters, step, h: int, w: int, g_sigmas, g_coords, g
     return gp
 
 
-def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float]):
-    """prologue + plan + forward in ONE call: raw `gs_parameters[N,9]` -> planar image `[3,h,w]` (fresh)."""
+def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float],
+                 extra_flags: int = 0):
+    """prologue + plan + forward in ONE call: raw `gs_parameters[N,9]` -> planar image `[3,h,w]` (fresh).
+    `extra_flags`: FLAG_FORWARD_ONLY (no backward will follow), FLAG_BWD_TILE (plan for the tile-stationary backward)."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(step, "step_size")
     if dmax is not None and not (float(dmax) >= 0.0):
         raise RuntimeError("dmax must be >= 0")
     dev = gs_parameters.device
-    d = make_dims(gs_parameters.shape[0], h, w, dmax, flags=FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE)
+    d = make_dims(gs_parameters.shape[0], h, w, dmax, flags=FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE | int(extra_flags))
     L = lib()
     nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
@@ -350,14 +358,16 @@ def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int
     return img, Plan(d, ws, dev)
 
 
-def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad_hwc: torch.Tensor) -> torch.Tensor:
-    """splat backward + prologue backward in ONE call; `grad_hwc` is `[h,w,3]`; returns d/d gs_parameters `[N,9]`."""
+def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad: torch.Tensor, chw: bool = False) -> torch.Tensor:
+    """splat backward + prologue backward in ONE call; `grad` is `[h,w,3]`, or with `chw` the planar `[3,h,w]` autograd
+    hands back (tile-stationary backward, GSASR_FLAG_CHW_GRAD); returns d/d gs_parameters `[N,9]`."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(step, "step_size")
-    pg = _chk(grad_hwc, "grads", (p.dims.h, p.dims.w, 3))
+    pg = _chk(grad, "grads", (3, p.dims.h, p.dims.w) if chw else (p.dims.h, p.dims.w, 3))
+    d = _dims_with(p, FLAG_CHW_GRAD if chw else 0)
     with _on(p.device):
         gp = torch.empty_like(gs_parameters)
-        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
+        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(d), p.workspace.data_ptr(),
                                         p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
     return gp
 
@@ -380,7 +390,7 @@ def make_batch_dims(n_per: int, sizes, w_max: int, h_max: int, dmax: Optional[fl
     return d
 
 
-def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax: Optional[float]):
+def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax: Optional[float], extra_flags: int = 0):
     """prologue + plan + forward of a whole batch in ONE set of launches.
     `gs_parameters` [B,N,9], `steps` [B] (device), `sizes` [(h_b, w_b)] -> planar images `[B,3,slot,w_max]`
     (sample b in `[:, :, :h_b, :w_b]`, zero elsewhere) and the plan for `batch_backward`."""
@@ -392,7 +402,7 @@ def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax:
         raise RuntimeError("dmax must be >= 0")
     B, n = gs_parameters.shape[0], gs_parameters.shape[1]
     h_max, w_max = max(h for h, _ in sizes), max(w for _, w in sizes)
-    d = make_batch_dims(n, sizes, w_max, h_max, dmax, flags=FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE)
+    d = make_batch_dims(n, sizes, w_max, h_max, dmax, flags=FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE | int(extra_flags))
     L = lib()
     nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
@@ -406,14 +416,24 @@ def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax:
     return img, Plan(d, ws, dev)
 
 
-def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, grad_bhwc: torch.Tensor) -> torch.Tensor:
-    """`grad_bhwc` is `[B, slot, w_max, 3]`; returns d/d gs_parameters `[B,N,9]`."""
+def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, grad: torch.Tensor, chw: bool = False) -> torch.Tensor:
+    """`grad` is `[B, slot, w_max, 3]`, or with `chw` the planar `[B, 3, rows, w_max]` autograd hands back (any
+    `rows` >= every sample's height; tile-stationary backward); returns d/d gs_parameters `[B,N,9]`."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
     ps = _chk(steps, "step_sizes")
-    pg = _chk(grad_bhwc, "grads", (p.dims.batch, p.dims.slot, p.dims.w, 3))
+    d = p.dims
+    if chw:
+        if grad.dim() != 4 or grad.shape[0] != d.batch or grad.shape[1] != 3 or grad.shape[3] != d.w:
+            raise RuntimeError(f"grads has shape {tuple(grad.shape)}, expected [{d.batch}, 3, rows, {d.w}]")
+        pg = _chk(grad, "grads")
+        d = Dims.from_buffer_copy(p.dims)
+        d.flags |= FLAG_CHW_GRAD
+        d.grad_rows = int(grad.shape[2])
+    else:
+        pg = _chk(grad, "grads", (p.dims.batch, p.dims.slot, p.dims.w, 3))
     with _on(p.device):
         gp = torch.empty_like(gs_parameters)
-        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(p.dims), p.workspace.data_ptr(),
+        check(lib().gsasr_step_backward(pp, ps, pg, gp.data_ptr(), ctypes.byref(d), p.workspace.data_ptr(),
                                         p.workspace.numel(), _stream(p.device)), "gsasr_step_backward")
     return gp
 

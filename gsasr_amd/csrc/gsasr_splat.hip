@@ -82,6 +82,8 @@ struct Params {
     int batch;       // 1: one image.  B > 1: B samples stacked in a canvas of B slots (h = B*slot rows, w columns)
     int slot;        // rows per slot (multiple of 16)
     int nper;        // Gaussians per sample (sample-major order)
+    int part_k;      // tile-stationary backward: partial-gradient slots per Gaussian (PlanView::part)
+    int grad_rows;   // rows per plane of a planar (GSASR_FLAG_CHW_GRAD) upstream gradient of a batched canvas
 };
 
 // One sample of a batched canvas: its own pixel-grid size, its first canvas row and its px-table offset.
@@ -111,6 +113,11 @@ struct PlanView {
     uint4 *bbox;            // [2*s] {c0 | test<<15 | c1<<16, r0 | spans<<15 | r1<<16, span_lo[0..3], span_hi[0..3]},
                             //       {span_lo[4..7], span_hi[4..7], -, -}
     uint2 *win;             // [s] the first two words of bbox again, densely: what the coarse tests stream through
+    uint4 *qspan;           // [s] (plans with slots only) per band of 8 rows of the window (8 bands at most): the range of 8-px
+                            //       columns, counted from the window's first, that the ellipse {exponent >= -tau} reaches:
+                            //       {lo[0..3], hi[0..3], lo[4..7], hi[4..7]} bytes; lo > hi = none
+    float *part;            // [s * part_k * 8] tile-stationary backward: the raw sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} of
+                            //       Gaussian j (cell order) over the t-th 32x16-px tile of its window, written with plain stores
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -123,7 +130,8 @@ __device__ __forceinline__ Geo sample_geo(const Params &P, const PlanView &V, in
 }
 
 struct Layout {
-    size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox, off_win;
+    size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox, off_win, off_part, off_qspan;
+    int part_k;
     size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
     size_t total;
     int ncx, ncy, ncells;
@@ -155,6 +163,19 @@ int classify_blocks(const gsasr_dims *d)
     return (n + 255) / 256;
 }
 
+// Tile-stationary backward: every (32x16-px tile, Gaussian) pair leaves its partial sums in slot t of the Gaussian's
+// own row of `part_k` slots, t = the tile's ordinal inside the Gaussian's window (row-major), so that nothing is
+// accumulated atomically and the result does not depend on scheduling.  GSASR's Gaussians are about one LR pixel in
+// size, i.e. a window of ~5.6 LR pixels = 23 px at x4 (2 x 3 tiles at most), 45 px at x8 (3 x 4): 8 slots cover x4 and
+// below, 16 the larger scales; a Gaussian whose window spans more tiles than it has slots adds into `sums` with
+// fp32 atomics instead (any input stays correct).  The window sizes live on the device, so the host picks by HR pixels
+// per Gaussian, as for the Gaussian-stationary kernel's unrolling.
+int bwd_part_k(const gsasr_dims *d)
+{
+    const double px_per_gaussian = (double)(d->row1 - d->row0) * (double)d->w / (double)(d->s > 0 ? d->s : 1);
+    return px_per_gaussian >= 32.0 ? 16 : 8;
+}
+
 Layout make_layout(const gsasr_dims *d)
 {
     Layout L{};
@@ -180,6 +201,9 @@ Layout make_layout(const gsasr_dims *d)
     L.off_done = o;   o += align_up(s * 4, 256);
     L.off_bbox = o;   o += align_up(s * 32, 256);
     L.off_win = o;    o += align_up(s * 8, 256);
+    L.part_k = (d->flags & GSASR_FLAG_FORWARD_ONLY) ? 0 : bwd_part_k(d);
+    L.off_part = o;   o += align_up(s * 32 * (size_t)L.part_k, 256);
+    L.off_qspan = o;  o += L.part_k ? align_up(s * 16, 256) : 0;
     L.total = o;
     return L;
 }
@@ -204,6 +228,8 @@ PlanView make_view(const Layout &L, void *ws)
     V.done = (unsigned *)(b + L.off_done);
     V.bbox = (uint4 *)(b + L.off_bbox);
     V.win = (uint2 *)(b + L.off_win);
+    V.part = (float *)(b + L.off_part);
+    V.qspan = L.part_k ? (uint4 *)(b + L.off_qspan) : nullptr;
     return V;
 }
 
@@ -227,6 +253,17 @@ float resolve_cutoff(float cutoff, int s)
     return (float)(tau < 16.0 ? 16.0 : tau > (double)GSASR_SPLAT_EXACT_CUTOFF ? (double)GSASR_SPLAT_EXACT_CUTOFF : tau);
 }
 
+// which backward kernel: explicit flag > environment GSASR_SPLAT_BWD (gaussian | tile | atomic; development A/B) > default
+int bwd_env()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GSASR_SPLAT_BWD");
+        v = !e ? 0 : !strcmp(e, "gaussian") ? 1 : !strcmp(e, "tile") ? 2 : !strcmp(e, "atomic") ? 3 : 0;
+    }
+    return v;
+}
+
 Params make_params(const gsasr_dims *d, const Layout &L)
 {
     Params P;
@@ -237,9 +274,13 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.kcut = tau > 0.f ? (float)(std::sqrt(2.0 * (double)tau) * (1.0 + 1e-6)) : 0.f;
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
     P.flags = d->flags;
+    if (!(P.flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)))   // (development A/B switch)
+        P.flags |= bwd_env() == 2 ? GSASR_FLAG_BWD_TILE : bwd_env() == 3 ? GSASR_FLAG_BWD_ATOMIC : 0u;
     P.batch = batch_of(d);
     P.slot = d->batch > 1 ? d->slot : d->h;
     P.nper = d->batch > 1 ? d->s / d->batch : d->s;
+    P.part_k = L.part_k;
+    P.grad_rows = d->grad_rows > 0 ? d->grad_rows : P.slot;
     return P;
 }
 
@@ -539,6 +580,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     unsigned key = 0u, rnk = 0u;
     float4 recA = make_float4(0.f, 0.f, 0.f, 0.f), recB = recA, finA = recA, finB = recA;
     uint4 bb = make_uint4(0u, 0u, 0u, 0u), bc = bb;
+    uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);   // quadrant-row spans: every column unless computed below
     bool large = false;
     if (valid) {
         key = V.key[i];
@@ -599,28 +641,39 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 const float disc0 = 4.f * qa * tau, disc2 = 4.f * qa * qc - qb * qb, i2qa = 0.5f / qa;
                 const float eps = (float)WINDOW_EPS;
                 const int tx0 = b.c0 >> SUBX_SHIFT;
-                unsigned lo4[2] = {0u, 0u}, hi4[2] = {0u, 0u};
-                for (int t = 0; t < 8; ++t) {
-                    unsigned lo = 1u, hi = 0u;  // empty
-                    // the band's pixel rows Ya..Ya+15, relative to the centre
-                    const float v0 = (float)((double)(P.row0 + ((ty0 + t) << SUBY_SHIFT)) - cyp) - eps,
-                                v1 = v0 + (float)(SUBY - 1) + 2.f * eps;
-                    if (t <= ty1 - ty0 && v1 >= -vmax && v0 <= vmax) {
-                        const float a0 = fmaxf(v0, -vmax), a1 = fminf(v1, vmax);
-                        const float vr = fminf(fmaxf(vstar, a0), a1), vl = fminf(fmaxf(-vstar, a0), a1);
-                        const float dr_ = disc0 - disc2 * vr * vr;
-                        const float dl_ = disc0 - disc2 * vl * vl;
-                        const float uhi = (-qb * vr + sqrtf(fmaxf(dr_, 0.f))) * i2qa;
-                        const float ulo = (-qb * vl - sqrtf(fmaxf(dl_, 0.f))) * i2qa;
-                        const int xl = max(b.c0, (int)fmax(ceil(cxp + (double)(ulo - eps)), -1.0));
-                        const int xh = min(b.c1, (int)fmin(floor(cxp + (double)(uhi + eps)), 40000.0));
-                        if (xl <= xh && !(umax != umax)) {
-                            lo = (unsigned)min(255, (xl >> SUBX_SHIFT) - tx0);
-                            hi = (unsigned)min(255, (xh >> SUBX_SHIFT) - tx0);
+                // eight bands of (1 << shift) rows starting at band `first` (counted from row0)
+                auto spans = [&](int shift, int first, int nb, unsigned (&lo4)[2], unsigned (&hi4)[2]) {
+                    for (int t = 0; t < 8; ++t) {
+                        unsigned lo = 1u, hi = 0u;  // empty
+                        // the band's pixel rows Ya..Ya+2^shift-1, relative to the centre
+                        const float v0 = (float)((double)(P.row0 + ((first + t) << shift)) - cyp) - eps,
+                                    v1 = v0 + (float)((1 << shift) - 1) + 2.f * eps;
+                        if (t < nb && v1 >= -vmax && v0 <= vmax) {
+                            const float a0 = fmaxf(v0, -vmax), a1 = fminf(v1, vmax);
+                            const float vr = fminf(fmaxf(vstar, a0), a1), vl = fminf(fmaxf(-vstar, a0), a1);
+                            const float dr_ = disc0 - disc2 * vr * vr;
+                            const float dl_ = disc0 - disc2 * vl * vl;
+                            const float uhi = (-qb * vr + sqrtf(fmaxf(dr_, 0.f))) * i2qa;
+                            const float ulo = (-qb * vl - sqrtf(fmaxf(dl_, 0.f))) * i2qa;
+                            const int xl = max(b.c0, (int)fmax(ceil(cxp + (double)(ulo - eps)), -1.0));
+                            const int xh = min(b.c1, (int)fmin(floor(cxp + (double)(uhi + eps)), 40000.0));
+                            if (xl <= xh && !(umax != umax)) {
+                                lo = (unsigned)min(255, (xl >> SUBX_SHIFT) - tx0);
+                                hi = (unsigned)min(255, (xh >> SUBX_SHIFT) - tx0);
+                            }
                         }
+                        lo4[t >> 2] |= lo << (8 * (t & 3));
+                        hi4[t >> 2] |= hi << (8 * (t & 3));
                     }
-                    lo4[t >> 2] |= lo << (8 * (t & 3));
-                    hi4[t >> 2] |= hi << (8 * (t & 3));
+                };
+                unsigned lo4[2] = {0u, 0u}, hi4[2] = {0u, 0u};
+                spans(SUBY_SHIFT, ty0, ty1 - ty0 + 1, lo4, hi4);
+                // the same per band of 8 rows, for the 8x8-px quadrants of the tile-stationary backward
+                const int q0 = (b.r0 - P.row0) >> 3, q1 = (b.r1 - P.row0) >> 3;
+                if ((P.flags & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)) && V.qspan && q1 - q0 < 8) {
+                    unsigned l8[2] = {0u, 0u}, h8[2] = {0u, 0u};
+                    spans(3, q0, q1 - q0 + 1, l8, h8);
+                    qs = make_uint4(l8[0], h8[0], l8[1], h8[1]);
                 }
                 bb.z = lo4[0]; bb.w = hi4[0];
                 bc.x = lo4[1]; bc.y = hi4[1];
@@ -678,11 +731,11 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     V.bbox[2 * j] = bb;
     V.bbox[2 * j + 1] = bc;
     V.win[j] = make_uint2(bb.x, bb.y);
-    if (large) {  // large Gaussians accumulate their row chunks atomically: start from zero
-        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        V.done[j] = 0u;
-    }
+    if (V.qspan) V.qspan[j] = qs;
+    // the atomic accumulators (row chunks of a large Gaussian; windows wider than their slots in the tile backward) start from zero
+    reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (large) V.done[j] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1480,6 +1533,417 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward, TILE-stationary (BASELINE.json north_star's shape: a workgroup owns an HR tile, stages its grad_img ONCE
+// in LDS and streams the Gaussians binned near it).  Measured against the Gaussian-stationary k_render_bwd above in
+// DESIGN.md 3c; the host picks between the two (gsasr_splat_backward).
+//
+//   tile      32 x 16 px = 8 "quadrants" of 8 x 8 px; one workgroup of four waves per tile, XCD-banded tile order.
+//   stage     the tile's gradient (HWC or planar CHW, zero outside the image / the sample / the row band) goes to LDS as
+//             packed row pairs {r_a, r_b, g_a, g_b, b_a, b_b} per (column, row pair) of each quadrant, with the px / py
+//             table entries of the tile.  Every pixel of grad_img is read once per tile that holds it -- exactly once.
+//   level 1   as in the forward (fwd_block): the four waves test the windows of the Gaussians binned within reach of
+//             the tile, 64 per wave and chunk, and append the survivors to a list in LDS.  A survivor also appends one
+//             ITEM per quadrant its window touches (1..8), survivor-major, the last one marked.
+//   level 2   LANE = ITEM = (Gaussian, quadrant): a lane loads its Gaussian's records once and evaluates it at the 64
+//             pixels of its quadrant -- gradients read from LDS (lanes of different quadrants hit disjoint banks), two
+//             rows per packed-fp32 operation, columns in the outer loop so that u = dx/sx is constant in the inner one
+//             and the same residual-form sums as bwd_sweep apply.  No cross-lane reduction of pixels, no masks: a pixel
+//             outside the Gaussian's window adds a term below exp(-tau), a pixel outside the image adds 0 * v.
+//             The items of one Gaussian sit in adjacent lanes (chunks are cut at the last marked lane, so a Gaussian never
+//             straddles two chunks): three shuffle steps add them up, and the first lane of each run stores the eight raw
+//             sums into the Gaussian's slot for THIS tile (PlanView::part) -- plain 32-byte stores, no atomics, no
+//             dependence on scheduling.  (Measured on this chip: fp32 global atomics retire ~19 G cache-line requests/s
+//             chip-wide and ds_add_f32 ~3 cycles per lane; tools/atomic_rate.hip.  One atomic set per (tile, Gaussian)
+//             would be 14 us of atomic traffic at config 2.)
+//   gather    k_bwd_gather (or the fused k_prologue_bwd_gather of the step entry points): one thread per Gaussian adds
+//             the slots of its window's tiles in order, applies the Gaussian's constants and writes the gradient.
+// A Gaussian whose window spans more tiles than it has slots (or the "large" class) adds into PlanView::sums with
+// atomics instead; the gather adds those as well.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BT_W = 32, BT_H = 16;                 // tile
+#ifndef BT_WAVES_N
+#define BT_WAVES_N 2
+#endif
+constexpr int BT_WAVES = BT_WAVES_N;                // waves per workgroup (= per tile)
+constexpr int BT_CHUNKS = 8 / BT_WAVES;             // candidate chunks per wave and round (level 1)
+constexpr int BT_LIST = BT_WAVES * BT_CHUNKS * 64;  // survivors per round at most (512)
+constexpr int BT_THREADS = 64 * BT_WAVES;
+constexpr int BT_QSTRIDE = 32 * 8 + 8;              // floats per quadrant block: 32 entries of 8 floats, +8 so that the
+                                                    // blocks of the eight quadrants start 8 banks apart
+constexpr unsigned BT_WIDE = 0xffu;                 // slot code: window spans more tiles than part_k -> atomics into sums
+
+__device__ __forceinline__ int bt_tile_span(unsigned wx, unsigned wy, int row0, int &ntx, int &tx0, int &ty0)
+{
+    const int c0 = (int)(wx & 0x7fffu), c1 = (int)(wx >> 16), r0 = (int)(wy & 0x7fffu), r1 = (int)(wy >> 16);
+    tx0 = c0 >> 5;
+    ty0 = (r0 - row0) >> 4;
+    ntx = (c1 >> 5) - tx0 + 1;
+    return ntx * (((r1 - row0) >> 4) - ty0 + 1);
+}
+
+// One item: Gaussian j (cell order) at the 64 pixels of one quadrant.  gq = the quadrant's block of staged gradients,
+// pxq / pyq = its 8 column / row coordinates.  a[] = raw sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} (cf. bwd_sweep).
+template <bool TEST>
+__device__ __forceinline__ void bt_eval(const PlanView &V, unsigned j, float dm, const float *gq, const float *pxq,
+                                        const float *pyq, float (&a)[8])
+{
+    constexpr float HALF_LOG2E = 0.72134752044448170368f;
+    const float4 ra = V.rec[2 * (size_t)j], rb = V.rec[2 * (size_t)j + 1];
+    const float4 fa = V.fin[2 * (size_t)j];
+    const float isy = V.fin[2 * (size_t)j + 1].x;
+    const float x = ra.x, y = ra.y, cr = rb.y, cg = rb.z, cb = rb.w;
+    const float cinv = fa.x, kappa = fa.y, rho = fa.z, isx = fa.w;
+    // exponent (log2) = -h u^2 - h c B^2 with u = dx/sx, B = dy/sy - rho u, c = 1/(1-rho^2) (bwd_trip); B is carried
+    // pre-scaled by sB = sqrt(h c), so that the exponent is K0(u) - B'^2
+    const float sB = __builtin_amdgcn_sqrtf(HALF_LOG2E * cinv), inv_sB = __builtin_amdgcn_rcpf(sB);
+    const float isyB = isy * sB, rsB = rho * sB;
+    v2f vp[4], rt[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const v2f dy = (v2f){pyq[2 * p], pyq[2 * p + 1]} - y;
+        vp[p] = dy * isyB;
+        if (TEST) rt[p] = (v2f){fabsf(dy.x) <= dm ? 0.f : -INFINITY, fabsf(dy.y) <= dm ? 0.f : -INFINITY};
+    }
+    float s_uM = 0.f, s_uuM = 0.f, s_N1 = 0.f, s_uN1 = 0.f, s_N2 = 0.f;
+    v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
+    for (int c = 0; c < 8; ++c) {
+        const float dx = pxq[c] - x;
+        const float u = dx * isx, ru = rsB * u;
+        float K0 = -HALF_LOG2E * u * u;
+        if (TEST) K0 = fabsf(dx) <= dm ? K0 : -INFINITY;   // exponent -inf: v = 0 exactly, every product with it is 0
+        v2f M0 = {0.f, 0.f}, N1 = {0.f, 0.f}, N2 = {0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 d0 = *reinterpret_cast<const float4 *>(gq + (c * 4 + p) * 8);
+            const float2 d1 = *reinterpret_cast<const float2 *>(gq + (c * 4 + p) * 8 + 4);
+            const v2f Bv = vp[p] - ru;
+            v2f pw = K0 - Bv * Bv;
+            if (TEST) pw += rt[p];
+            const v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+            const v2f gr = {d0.x, d0.y}, gn = {d0.z, d0.w}, gb = {d1.x, d1.y};
+            const v2f gp = gb * cb + (gn * cg + gr * cr);   // gs.cu:150
+            const v2f qq = gp * v, qB = qq * Bv;
+            M0 += qq;
+            N1 += qB;
+            N2 += qB * Bv;
+            Cr += v * gr;
+            Cg += v * gn;
+            Cb += v * gb;
+        }
+        // the column's sums, as polynomials in its u (expanded after the last column)
+        const float m0 = M0.x + M0.y, n1 = N1.x + N1.y, n2 = N2.x + N2.y;
+        const float um = u * m0;
+        s_uM += um;
+        s_uuM = fmaf(u, um, s_uuM);
+        s_N1 += n1;
+        s_uN1 = fmaf(u, n1, s_uN1);
+        s_N2 += n2;
+    }
+    // undo the scale of B, then  sum qA = kappa sum(u M0) - rho sum N1  etc.: bwd_sweep's per-column expansion summed
+    // over the columns (A = kappa u - rho B, v = B + rho u)
+    const float N1t = s_N1 * inv_sB, uN1t = s_uN1 * inv_sB, N2t = s_N2 * inv_sB * inv_sB;
+    a[0] = kappa * s_uM - rho * N1t;
+    a[1] = N1t;
+    a[2] = kappa * s_uuM - rho * uN1t;
+    a[3] = N2t + rho * uN1t;
+    a[4] = kappa * uN1t - rho * N2t;
+    a[5] = Cr.x + Cr.y;
+    a[6] = Cg.x + Cg.y;
+    a[7] = Cb.x + Cb.y;
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_render_bwd_tile(
+    Params P, PlanView V, const float *__restrict__ grad, int tiles_x, int use_atomics)
+{
+    __shared__ __attribute__((aligned(16))) float s_g[8 * BT_QSTRIDE];
+    __shared__ float s_px[BT_W], s_py[BT_H];
+    __shared__ unsigned s_list[BT_LIST];            // survivor: index in cell order | needs the dmax test << 31
+    __shared__ unsigned char s_slot[BT_LIST];       // its slot in part[] for this tile, or BT_WIDE
+    __shared__ unsigned short s_items[BT_LIST * 8]; // item: survivor (9 bits) | quadrant << 9 | last of its survivor << 12
+    __shared__ unsigned s_cnt[2];                   // survivors, items of the round
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tt = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = (int)(tt % (unsigned)tiles_x), ty = (int)(tt / (unsigned)tiles_x);
+    const int bx0 = tx * BT_W, by0 = P.row0 + ty * BT_H;
+    const int bx1 = min(bx0 + BT_W - 1, P.w - 1), by1 = min(by0 + BT_H - 1, P.row1 - 1);
+    const int smp = P.batch > 1 ? by0 / P.slot : 0;
+    const Geo g = sample_geo(P, V, smp);
+
+    // ---- stage the tile ---------------------------------------------------------------------------------
+    {
+        const int ylim = min(P.row1, g.base + g.h);
+        const bool chw = (P.flags & GSASR_FLAG_CHW_GRAD) != 0u;
+        size_t plane = (size_t)(P.row1 - P.row0) * P.w, org = 0;     // planar: [3, rows, w]; batched [B, 3, grad_rows, w]
+        int yoff = P.row0;
+        if (chw && P.batch > 1) {
+            plane = (size_t)P.grad_rows * P.w;
+            org = (size_t)smp * 3 * plane;
+            yoff = g.base;
+        }
+#pragma unroll
+        for (int i = tid; i < BT_W * BT_H; i += BT_THREADS) {
+            const int row = i >> 5, col = i & 31, X = bx0 + col, Y = by0 + row;
+            float r = 0.f, gg = 0.f, b = 0.f;
+            if (X < g.w && Y < ylim) {
+                if (chw) {
+                    const float *q = grad + org + (size_t)(Y - yoff) * P.w + X;
+                    r = q[0]; gg = q[plane]; b = q[2 * plane];
+                } else {
+                    const float *q = grad + ((size_t)(Y - P.row0) * P.w + X) * 3;
+                    r = q[0]; gg = q[1]; b = q[2];
+                }
+            }
+            float *e = s_g + ((row >> 3) * 4 + (col >> 3)) * BT_QSTRIDE + (((col & 7) * 4 + ((row & 7) >> 1)) * 8) + (row & 1);
+            e[0] = r; e[2] = gg; e[4] = b;
+        }
+        if (tid < BT_W) s_px[tid] = V.px[g.pxo + min(bx0 + tid, P.w - 1)];
+        else if (tid < BT_W + BT_H) s_py[tid - BT_W] = V.py[min(by0 + tid - BT_W, P.h - 1)];
+        if (tid < 2) s_cnt[tid] = 0u;
+    }
+
+    // ---- segment table of the tile (every wave builds the same one; cf. fwd_block) ------------------------
+    const unsigned *__restrict__ cs = V.cell_start;
+    const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    int nseg = 0;
+    unsigned sbeg = 0, send = 0;
+    if (rx > 0) {
+        const int cx0 = max(bx0 - rx, 0) >> CELL_SHIFT, cx1 = min((bx1 + rx) >> CELL_SHIFT, P.ncx - 1);
+        const int cy0 = max(by0 - ry, 0) >> CELL_SHIFT, cy1 = min((by1 + ry) >> CELL_SHIFT, P.ncy - 1);
+        nseg = cy1 - cy0 + 1;
+        if (lane < nseg) {
+            sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+            send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
+        }
+    }
+    if (lane == nseg) {
+        sbeg = cs[P.ncells];
+        send = cs[P.ncells + 1];
+    }
+    ++nseg;
+    const unsigned len = send - sbeg;
+    unsigned pin = len;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)pin, o);
+        if (lane >= o) pin += v;
+    }
+    const unsigned pex = pin - len;
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+    const unsigned nchunks = (total + 63u) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rseg = 0;
+    __syncthreads();
+
+    for (unsigned base = 0; base < nchunks; base += (unsigned)(BT_WAVES * BT_CHUNKS)) {
+#ifdef BT_DEBUG
+        for (int i = tid; i < BT_LIST * 8; i += BT_THREADS) s_items[i] = 0xffffu;
+        __syncthreads();
+#endif
+        // ---- level 1: candidates -> survivors + items ----------------------------------------------------
+        unsigned cj[BT_CHUNKS];
+        uint2 cw[BT_CHUNKS];
+#pragma unroll
+        for (int k = 0; k < BT_CHUNKS; ++k) {
+            const unsigned c = base + (unsigned)wv + (unsigned)(BT_WAVES * k);
+            cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
+            cw[k] = make_uint2(0x7fffu, 0x7fffu);
+            if (cj[k] != 0xffffffffu) cw[k] = V.win[cj[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < BT_CHUNKS; ++k) {
+            const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
+            const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
+            const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) continue;
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&s_cnt[0], (unsigned)__builtin_popcountll(m));
+            at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+            const unsigned pos = at + (unsigned)__builtin_popcountll(m & below);
+            // quadrants of the tile the window touches, row by row trimmed to the columns the ellipse reaches (k_bin's
+            // per-8-row spans): the corners of the window are empty for every Gaussian, most of it for a correlated one
+            const int qx0 = max(c0 - bx0, 0) >> 3, qx1 = min(c1 - bx0, BT_W - 1) >> 3;
+            const int qy0 = max(r0 - by0, 0) >> 3, qy1 = min(r1 - by0, BT_H - 1) >> 3;
+            int xl[2] = {1, 1}, xh[2] = {0, 0};
+            if (hit) {
+                uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);
+                if (V.qspan) qs = V.qspan[cj[k]];
+                const int t8 = ((by0 - P.row0) >> 3) - ((r0 - P.row0) >> 3), cu = (c0 >> 3) - (bx0 >> 3);
+#pragma unroll
+                for (int qy = 0; qy < 2; ++qy) {
+                    const unsigned t = (unsigned)(t8 + qy) & 7u, sh = (t & 3u) * 8u;
+                    const int lo = (int)(((t < 4u ? qs.x : qs.z) >> sh) & 0xffu), hi = (int)(((t < 4u ? qs.y : qs.w) >> sh) & 0xffu);
+                    if (qy >= qy0 && qy <= qy1) {
+                        xl[qy] = max(qx0, cu + lo);
+                        xh[qy] = min(qx1, cu + hi);
+                    }
+                }
+            }
+            const unsigned n_i = (unsigned)(max(xh[0] - xl[0] + 1, 0) + max(xh[1] - xl[1] + 1, 0));
+            unsigned inc = n_i;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = (unsigned)__shfl_up((int)inc, o);
+                if (lane >= o) inc += v;
+            }
+            unsigned ib = 0;
+            if (lane == 63) ib = atomicAdd(&s_cnt[1], inc);
+            ib = (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
+            if (hit) {
+                s_list[pos] = cj[k] | ((cw[k].x & 0x8000u) << 16);
+                int ntx, wtx0, wty0;
+                const int nt = bt_tile_span(cw[k].x, cw[k].y, P.row0, ntx, wtx0, wty0);
+                const unsigned slot = nt <= P.part_k ? (unsigned)((ty - wty0) * ntx + (tx - wtx0)) : BT_WIDE;
+                s_slot[pos] = (unsigned char)slot;
+                unsigned off = ib + inc - n_i;
+                const unsigned last = off + n_i - 1u;
+#pragma unroll
+                for (int qy = 0; qy < 2; ++qy)
+                    for (int qx = xl[qy]; qx <= xh[qy]; ++qx, ++off)
+                        s_items[off] = (unsigned short)((unsigned)pos | (unsigned)(qy * 4 + qx) << 9 | (off == last ? 0x1000u : 0u));
+                if (n_i == 0u && slot != BT_WIDE && !use_atomics) {   // the ellipse misses the tile: its slot is still read
+                    float4 *o = reinterpret_cast<float4 *>(V.part + ((size_t)cj[k] * P.part_k + slot) * 8);
+                    o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned nsurv = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[0]);
+        const unsigned nitems = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[1]);
+#ifdef BT_DEBUG
+        if (tid == 0) { atomicAdd(&V.done[0], nitems); atomicAdd(&V.done[2], nsurv); }
+#else
+        (void)nsurv;
+#endif
+        // ---- level 2: this wave's run of items, cut where a Gaussian's items end ---------------------------
+        // run boundaries: nitems * w / 4 moved up to the next item that starts a Gaussian
+        unsigned run[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            unsigned b = nitems * (unsigned)(wv + e) / (unsigned)BT_WAVES;
+            if (b > 0u && b < nitems) {
+                const unsigned i = b - 1u + (unsigned)lane;
+                const unsigned long long tails = __ballot(i < nitems && (s_items[i < nitems ? i : 0u] & 0x1000u));
+                b = tails ? b + (unsigned)__builtin_ctzll(tails) : nitems;
+            }
+            run[e] = b;
+        }
+        for (unsigned p0 = run[0]; p0 < run[1];) {
+            const unsigned idx = p0 + (unsigned)lane;
+            const unsigned it = idx < run[1] ? s_items[idx] : 0u;
+            const unsigned long long tails = __ballot(idx < run[1] && (it & 0x1000u));
+            const int tlast = 63 - __builtin_clzll(tails);            // (a run ends on a marked item: tails != 0)
+            const bool valid = lane <= tlast;
+            const unsigned lidx = it & 0x1ffu, q = (it >> 9) & 7u;
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            unsigned j = 0u;
+            unsigned e = 0u;
+            if (valid) {
+                e = s_list[lidx];
+                j = e & 0x7fffffffu;
+            }
+            // (the dmax test costs an instruction per pixel pair: only chunks holding a Gaussian that needs it pay)
+            if (BOUNDED && __ballot(valid && (e >> 31)) != 0ull) {
+                if (valid) bt_eval<true>(V, j, (e >> 31) ? P.dmax : INFINITY, s_g + q * BT_QSTRIDE, s_px + (q & 3u) * 8u, s_py + (q >> 2) * 8u, a);
+            } else {
+                if (valid) bt_eval<false>(V, j, INFINITY, s_g + q * BT_QSTRIDE, s_px + (q & 3u) * 8u, s_py + (q >> 2) * 8u, a);
+            }
+            // add up the items of each Gaussian (adjacent lanes, at most 8): three shuffle steps; its first lane gets the total
+            const unsigned key = valid ? lidx : 0xffffu;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const bool same = (unsigned)__shfl_down((int)key, o) == key && lane + o < 64;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float other = __shfl_down(a[k], o);
+                    a[k] += same ? other : 0.f;
+                }
+            }
+            // (the shuffle must run with every lane enabled: a lane that has been switched off by a short-circuit
+            // supplies 0 to its neighbour)
+            const unsigned prev = (unsigned)__shfl_up((int)key, 1);
+            const bool head = valid && (lane == 0 || prev != key);
+#ifdef BT_DEBUG
+            {
+                const unsigned long long vm = __ballot(valid), hm = __ballot(head), um = __ballot(valid && it == 0xffffu);
+                if (um && lane == 0) atomicAdd(&V.done[4], (unsigned)__builtin_popcountll(um));
+                if (lane == 0) { atomicAdd(&V.done[1], (unsigned)__builtin_popcountll(vm)); atomicAdd(&V.done[3], (unsigned)__builtin_popcountll(hm)); }
+            }
+#endif
+            if (head) {
+                const unsigned slot = s_slot[lidx];
+                if (slot != BT_WIDE && !use_atomics) {
+                    float4 *o = reinterpret_cast<float4 *>(V.part + ((size_t)j * P.part_k + slot) * 8);
+                    o[0] = make_float4(a[0], a[1], a[2], a[3]);
+                    o[1] = make_float4(a[4], a[5], a[6], a[7]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) atomicAdd(V.sums + 8 * (size_t)j + k, a[k]);
+                }
+            }
+            p0 += (unsigned)tlast + 1u;
+        }
+        __syncthreads();
+        if (tid < 2) s_cnt[tid] = 0u;
+        __syncthreads();
+    }
+}
+
+// The eight gradient components of the Gaussian in cell-order slot j after k_render_bwd_tile: the slots of its window's
+// tiles in order (+ whatever went through the atomic accumulators, which are re-armed), times the Gaussian's
+// constants (bwd_scale).  Output order {x, y | sx, sy, rho | r, g, b}; returns the Gaussian's original index.
+__device__ __forceinline__ unsigned bwd_gather(const Params &P, const PlanView &V, unsigned j, bool use_atomics, float (&o)[8])
+{
+    const uint2 w = V.win[j];
+    const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
+    float4 *sm = reinterpret_cast<float4 *>(V.sums) + 2 * (size_t)j;
+    float4 a = sm[0], b = sm[1];
+    if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f || b.x != 0.f || b.y != 0.f || b.z != 0.f || b.w != 0.f ||
+        a.x != a.x) {
+        sm[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sm[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool dead = (int)(w.x & 0x7fffu) > (int)(w.x >> 16);
+    if (!dead && !use_atomics) {
+        int ntx, tx0, ty0;
+        const int nt = bt_tile_span(w.x, w.y, P.row0, ntx, tx0, ty0);
+        if (nt <= P.part_k) {
+            const float4 *pp = reinterpret_cast<const float4 *>(V.part + (size_t)j * P.part_k * 8);
+            for (int t = 0; t < nt; ++t) {
+                const float4 u = pp[2 * t], v = pp[2 * t + 1];
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+            }
+        }
+    }
+    if (dead) {
+        a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+        o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = o[6] = o[7] = 0.f;
+    } else {
+        const float c = fa.x, fx = c * fa.w, fy = c * fb.x;
+        o[0] = a.x * fx; o[1] = a.y * fy; o[2] = a.z * fx; o[3] = a.w * fy; o[4] = b.x * c * c;
+        o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+    return __float_as_uint(fb.w);
+}
+
+__global__ __launch_bounds__(256) void k_bwd_gather(Params P, PlanView V, int use_atomics, float *__restrict__ g_sigmas,
+                                                    float *__restrict__ g_coords, float *__restrict__ g_colors)
+{
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= (unsigned)P.s) return;
+    float o[8];
+    const unsigned i = bwd_gather(P, V, j, use_atomics != 0, o);
+    float *pc = g_coords + (size_t)i * stride2(P), *ps = g_sigmas + (size_t)i * stride3(P), *pk = g_colors + (size_t)i * stride3(P);
+    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) {
+        pc[0] = o[0]; pc[1] = o[1]; ps[0] = o[2]; ps[1] = o[3]; ps[2] = o[4]; pk[0] = o[5]; pk[1] = o[6]; pk[2] = o[7];
+    } else {   // (one thread per Gaussian: a plain read-modify-write)
+        pc[0] += o[0]; pc[1] += o[1]; ps[0] += o[2]; ps[1] += o[3]; ps[2] += o[4]; pk[0] += o[5]; pk[1] += o[6]; pk[2] += o[7];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // sampled pixels.  The reference renders the whole image and then picks `sample_coords`
 // out of it (utils/gaussian_splatting.py:214-216); here only the requested points are evaluated.
 //   k_pts_count / k_pts_scan / k_pts_place   counting sort of the points into point-cells (8x8 px; coarser when the
@@ -1936,6 +2400,25 @@ __global__ __launch_bounds__(256) void k_prologue_fwd(const float *__restrict__ 
     colors[i * 3 + 2] = sigmoidf_(q[6]) * alpha;
 }
 
+// chain rule of k_prologue_fwd for one Gaussian: q = its raw parameters, gs/gc/gk = d/d{sigmas, coords, colors}
+__device__ __forceinline__ void prologue_chain(const float *__restrict__ q, float step, int h, int w, float gs0, float gs1,
+                                               float gs2, float gc0, float gc1, float k0, float k1, float k2,
+                                               float *__restrict__ o)
+{
+    const float W = (float)w, H = (float)h;
+    const float s0 = sigmoidf_(q[0]), s1 = sigmoidf_(q[1]), th = tanhf(q[2]), al = sigmoidf_(q[3]);
+    const float r = sigmoidf_(q[4]), g = sigmoidf_(q[5]), b = sigmoidf_(q[6]);
+    o[0] = gs1 * (2.f / (H - 1.f) / step) * 0.99999f * s0 * (1.f - s0);
+    o[1] = gs0 * (2.f / (W - 1.f) / step) * 0.99999f * s1 * (1.f - s1);
+    o[2] = gs2 * 0.999999f * (1.f - th * th);
+    o[3] = (k0 * r + k1 * g + k2 * b) * al * (1.f - al);
+    o[4] = k0 * al * r * (1.f - r);
+    o[5] = k1 * al * g * (1.f - g);
+    o[6] = k2 * al * b * (1.f - b);
+    o[7] = gc0 * 2.f * W / (W - 1.f);
+    o[8] = gc1 * 2.f * H / (H - 1.f);
+}
+
 __global__ __launch_bounds__(256) void k_prologue_bwd(const float *__restrict__ p, const float *__restrict__ step_ptr,
                                                       int n, int h, int w, const float *__restrict__ gs,
                                                       const float *__restrict__ gc, const float *__restrict__ gk,
@@ -1949,21 +2432,28 @@ __global__ __launch_bounds__(256) void k_prologue_bwd(const float *__restrict__ 
         w = g.y;
     }
     const float step = step_ptr[geo ? i / nper : 0];
-    const float *q = p + (size_t)i * 9;
-    const float W = (float)w, H = (float)h;
-    const float s0 = sigmoidf_(q[0]), s1 = sigmoidf_(q[1]), th = tanhf(q[2]), al = sigmoidf_(q[3]);
-    const float r = sigmoidf_(q[4]), g = sigmoidf_(q[5]), b = sigmoidf_(q[6]);
-    float *o = gp + (size_t)i * 9;
-    o[0] = gs[i * 3 + 1] * (2.f / (H - 1.f) / step) * 0.99999f * s0 * (1.f - s0);
-    o[1] = gs[i * 3 + 0] * (2.f / (W - 1.f) / step) * 0.99999f * s1 * (1.f - s1);
-    o[2] = gs[i * 3 + 2] * 0.999999f * (1.f - th * th);
-    const float k0 = gk[i * 3 + 0], k1 = gk[i * 3 + 1], k2 = gk[i * 3 + 2];
-    o[3] = (k0 * r + k1 * g + k2 * b) * al * (1.f - al);
-    o[4] = k0 * al * r * (1.f - r);
-    o[5] = k1 * al * g * (1.f - g);
-    o[6] = k2 * al * b * (1.f - b);
-    o[7] = gc[i * 2 + 0] * 2.f * W / (W - 1.f);
-    o[8] = gc[i * 2 + 1] * 2.f * H / (H - 1.f);
+    prologue_chain(p + (size_t)i * 9, step, h, w, gs[i * 3 + 0], gs[i * 3 + 1], gs[i * 3 + 2], gc[i * 2 + 0], gc[i * 2 + 1],
+                   gk[i * 3 + 0], gk[i * 3 + 1], gk[i * 3 + 2], gp + (size_t)i * 9);
+}
+
+// the same behind the tile-stationary backward: the gather of the partial-gradient slots (bwd_gather) and the chain rule
+// in one kernel, one thread per Gaussian in cell order -- the kernel-frame gradients never go through memory
+__global__ __launch_bounds__(256) void k_prologue_bwd_gather(Params P, PlanView V, int use_atomics, const float *__restrict__ p,
+                                                             const float *__restrict__ step_ptr, float *__restrict__ gp)
+{
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= (unsigned)P.s) return;
+    float o[8];
+    const unsigned i = bwd_gather(P, V, j, use_atomics != 0, o);
+    int h = P.h, w = P.w;
+    float step = step_ptr[0];
+    if (P.batch > 1) {
+        const int4 g = V.geo[i / (unsigned)P.nper];
+        h = g.x;
+        w = g.y;
+        step = step_ptr[i / (unsigned)P.nper];
+    }
+    prologue_chain(p + (size_t)i * 9, step, h, w, o[2], o[3], o[4], o[0], o[1], o[5], o[6], o[7], gp + (size_t)i * 9);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2169,37 +2659,100 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     return GSASR_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// mode: 0 = Gaussian-stationary, 1 = tile-stationary with slots, 2 = tile-stationary with atomics
+int bwd_mode(const gsasr_dims *dims, const Layout &L)
+{
+    // Default: Gaussian-stationary.  Measured on MI355X the two kernels are within a few percent of each
+    // other at every scale -- both are bound by VALU issue -- and the Gaussian-stationary one is ahead for GSASR's LR-pixel
+    // sized Gaussians (x4: 38 vs 47 us at config 2); the tile-stationary one is deterministic and reads the planar
+    // gradient autograd returns, which is worth more than that to a caller who would otherwise permute it.
+    const unsigned f = dims->flags;
+    int mode = 0;
+    if (f & GSASR_FLAG_BWD_GAUSSIAN) mode = 0;
+    else if (f & GSASR_FLAG_BWD_ATOMIC) mode = 2;
+    else if (f & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_CHW_GRAD)) mode = 1;
+    else if (bwd_env()) mode = bwd_env() - 1;
+    if (L.part_k == 0 && mode == 1) mode = (f & GSASR_FLAG_CHW_GRAD) ? 2 : 0;   // a forward-only plan has no slots
+    return mode;
+}
+
+// Backward of the splat.  With `gather` the kernel-frame gradients are written (or added) to g_*; without it a
+// tile-stationary run stops after the tile kernel and the caller fuses the gather into its next kernel
+// (k_prologue_bwd_gather) -- *mode_out tells which kernel ran.
+int splat_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_img, float *g_sigmas,
+                   float *g_coords, float *g_colors, const gsasr_dims *dims, const void *workspace, size_t workspace_bytes,
+                   void *stream, bool gather, int *mode_out)
+{
+    Layout L;
+    if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
+    const int mode = bwd_mode(dims, L);
+    if (mode_out) *mode_out = mode;
+    if (dims->s == 0) return GSASR_OK;
+    if (gather && (!g_sigmas || !g_coords || !g_colors)) return fail(GSASR_ERR_ARG, "null pointer");
+    if (mode == 0 && (dims->flags & GSASR_FLAG_CHW_GRAD))
+        return fail(GSASR_ERR_ARG, "GSASR_FLAG_CHW_GRAD needs the tile-stationary backward");
+    hipStream_t st = (hipStream_t)stream;
+    const Params P = make_params(dims, L);
+    const PlanView V = make_view(L, const_cast<void *>(workspace));
+    const int rows = dims->row1 - dims->row0;
+    if (rows > 0 && !grad_img) return fail(GSASR_ERR_ARG, "null pointer");
+    if (mode == 0) {
+        if (!sigmas || !coords || !colors || !g_sigmas || !g_coords || !g_colors) return fail(GSASR_ERR_ARG, "null pointer");
+        if (rows == 0) {  // empty band: the gradient is zero
+            if (dims->flags & GSASR_FLAG_OVERWRITE_GRADS) {
+                const size_t e3 = (dims->flags & GSASR_FLAG_STRIDE8) ? 0 : sizeof(float) * 3 * (size_t)dims->s;
+                if (!e3) {
+                    HIP_TRY(hipMemsetAsync(g_sigmas, 0, sizeof(float) * 8 * (size_t)dims->s, st));   // one packed [s,8] array
+                } else {
+                    HIP_TRY(hipMemsetAsync(g_sigmas, 0, e3, st));
+                    HIP_TRY(hipMemsetAsync(g_coords, 0, sizeof(float) * 2 * (size_t)dims->s, st));
+                    HIP_TRY(hipMemsetAsync(g_colors, 0, e3, st));
+                }
+            }
+            return GSASR_OK;
+        }
+        const dim3 grid((unsigned)((dims->s + BWD_WAVES - 1) / BWD_WAVES)), block(64 * BWD_WAVES);
+        // Two instantiations of the same sweep (identical results): with the two-trip unrolled loop (88 VGPRs, 5 waves
+        // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
+        // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
+        const bool unroll = (double)rows * (double)dims->w >= 32.0 * (double)dims->s;
+#define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
+        if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
+        else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
+#undef GSASR_BWD
+        HIP_TRY(hipGetLastError());
+        return GSASR_OK;
+    }
+    if (rows > 0) {
+        const int tiles_x = (dims->w + BT_W - 1) / BT_W, tiles_y = (rows + BT_H - 1) / BT_H;
+        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(BT_THREADS);
+        if (P.bounded) hipLaunchKernelGGL(k_render_bwd_tile<true>, grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2);
+        else hipLaunchKernelGGL(k_render_bwd_tile<false>, grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2);
+        HIP_TRY(hipGetLastError());
+    }
+    if (gather) {
+        // (an empty band left no slots behind: the gather then only sees the zero accumulators)
+        Params Pg = P;
+        if (rows == 0) Pg.part_k = 0;
+        hipLaunchKernelGGL(k_bwd_gather, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, st, Pg, V,
+                           (int)(mode == 2 || rows == 0), g_sigmas, g_coords, g_colors);
+        HIP_TRY(hipGetLastError());
+    }
+    return GSASR_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int gsasr_splat_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_img,
                          float *g_sigmas, float *g_coords, float *g_colors, const gsasr_dims *dims,
                          const void *workspace, size_t workspace_bytes, void *stream)
 {
-    Layout L;
-    if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
-    if (dims->s == 0) return GSASR_OK;
-    if (!sigmas || !coords || !colors || !g_sigmas || !g_coords || !g_colors) return fail(GSASR_ERR_ARG, "null pointer");
-    if (dims->row1 == dims->row0) {  // empty band: the gradient is zero
-        if (dims->flags & GSASR_FLAG_OVERWRITE_GRADS) {
-            HIP_TRY(hipMemsetAsync(g_sigmas, 0, sizeof(float) * 3 * (size_t)dims->s, (hipStream_t)stream));
-            HIP_TRY(hipMemsetAsync(g_coords, 0, sizeof(float) * 2 * (size_t)dims->s, (hipStream_t)stream));
-            HIP_TRY(hipMemsetAsync(g_colors, 0, sizeof(float) * 3 * (size_t)dims->s, (hipStream_t)stream));
-        }
-        return GSASR_OK;
-    }
-    if (!grad_img) return fail(GSASR_ERR_ARG, "null pointer");
-    const Params P = make_params(dims, L);
-    const PlanView V = make_view(L, const_cast<void *>(workspace));
-    const dim3 grid((unsigned)((dims->s + BWD_WAVES - 1) / BWD_WAVES)), block(64 * BWD_WAVES);
-    hipStream_t st = (hipStream_t)stream;
-    // Two instantiations of the same sweep (identical results): with the two-trip unrolled loop (88 VGPRs, 5 waves
-    // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
-    // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
-    const bool unroll = (double)(dims->row1 - dims->row0) * (double)dims->w >= 32.0 * (double)dims->s;
-#define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
-    if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
-    else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
-#undef GSASR_BWD
-    HIP_TRY(hipGetLastError());
-    return GSASR_OK;
+    return splat_backward(sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors, dims, workspace, workspace_bytes,
+                          stream, true, nullptr);
 }
 
 int gsasr_prologue_forward(const float *gs_parameters, const float *step_size, int n, int h, int w, float *sigmas,
@@ -2309,14 +2862,23 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
     float *gs = (float *)(b + S.off_gsig), *gc = (float *)(b + S.off_gxy), *gk = (float *)(b + S.off_gcol);
     gsasr_dims d = *dims;
     d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
-    if (int rc = gsasr_splat_backward(sig, xy, col, grad_img, gs, gc, gk, &d, workspace, S.plan_bytes, stream)) return rc;
+    int mode = 0;
+    if (int rc = splat_backward(sig, xy, col, grad_img, gs, gc, gk, &d, workspace, S.plan_bytes, stream, false, &mode)) return rc;
+    if (dims->s == 0) return GSASR_OK;
+    if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
+    const dim3 grid((unsigned)((dims->s + 255) / 256)), block(256);
+    if (mode != 0) {   // tile-stationary: gather of the slots + chain rule in one kernel
+        const Layout L = make_layout(dims);
+        const PlanView V = make_view(L, workspace);
+        hipLaunchKernelGGL(k_prologue_bwd_gather, grid, block, 0, (hipStream_t)stream, make_params(&d, L), V, (int)(mode == 2 || d.row1 == d.row0),
+                           gs_parameters, step_size, g_parameters);
+        HIP_TRY(hipGetLastError());
+        return GSASR_OK;
+    }
     if (dims->batch > 1) {
-        if (dims->s == 0) return GSASR_OK;
-        if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
         const PlanView V = make_view(make_layout(dims), workspace);
-        hipLaunchKernelGGL(k_prologue_bwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           gs_parameters, step_size, dims->s, 0, 0, gs, gc, gk, g_parameters, dims->s / dims->batch,
-                           (const int4 *)V.geo);
+        hipLaunchKernelGGL(k_prologue_bwd, grid, block, 0, (hipStream_t)stream, gs_parameters, step_size, dims->s, 0, 0, gs, gc,
+                           gk, g_parameters, dims->s / dims->batch, (const int4 *)V.geo);
         HIP_TRY(hipGetLastError());
         return GSASR_OK;
     }

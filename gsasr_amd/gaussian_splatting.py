@@ -68,6 +68,18 @@ class _Splat(torch.autograd.Function):
         return (*g, None, None, None)
 
 
+# Which backward kernel the fused entry points plan for: "gaussian" (one wave per Gaussian; needs the upstream gradient
+# permuted to [H,W,3]), "tile" (one workgroup per 32x16-px tile; reads the planar gradient in place; deterministic), or
+# "auto" (the measured choice per shape).
+BACKWARD_KERNEL = "auto"
+
+
+def _tile_backward(n_pixels: int, n_gaussians: int) -> bool:
+    if BACKWARD_KERNEL != "auto":
+        return BACKWARD_KERNEL == "tile"
+    return False
+
+
 class _FusedStep(torch.autograd.Function):
     """raw decoder output `gs_parameters[N,9]` -> `[3,H,W]` image with ONE prologue kernel (activations +
     kernel-frame conversion, reference :174-180 and :121-123) in front of the splat, the splat writing the
@@ -79,9 +91,11 @@ class _FusedStep(torch.autograd.Function):
     @fp32_boundary_fwd
     def forward(ctx, gs_parameters, step, H, W, dmax):
         from . import _cabi
-        img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax)   # one C call: prologue + plan + splat
+        tile = _tile_backward(H * W, gs_parameters.shape[0])
+        flags = (_cabi.FLAG_BWD_TILE if tile else 0) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
+        img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax, flags)   # one C call: prologue + plan + splat
         ctx.save_for_backward(gs_parameters, step)
-        ctx.plan = plan
+        ctx.plan, ctx.tile = plan, tile
         return img
 
     @staticmethod
@@ -90,7 +104,9 @@ class _FusedStep(torch.autograd.Function):
     def backward(ctx, grad_output):
         from . import _cabi
         gs_parameters, step = ctx.saved_tensors
-        grad_hwc = grad_output.permute(1, 2, 0).contiguous()   # the backward kernel sweeps 12-byte HWC pixels
+        if ctx.tile:   # the tile-stationary backward stages the planar gradient as it is
+            return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_output.contiguous(), chw=True), None, None, None, None
+        grad_hwc = grad_output.permute(1, 2, 0).contiguous()   # the Gaussian-stationary kernel sweeps 12-byte HWC pixels
         return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_hwc), None, None, None, None
 
 
@@ -343,9 +359,11 @@ class _FusedBatch(torch.autograd.Function):
     @fp32_boundary_fwd
     def forward(ctx, gs_parameters, steps, sizes, dmax):
         from . import _cabi
-        img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax)
+        tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1])
+        flags = (_cabi.FLAG_BWD_TILE if tile else 0) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
+        img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax, flags)
         ctx.save_for_backward(gs_parameters, steps)
-        ctx.plan = plan
+        ctx.plan, ctx.tile = plan, tile
         ctx.h_max = max(h for h, _ in sizes)
         return img[:, :, : ctx.h_max]          # the slot is h_max rounded up to whole 16-row tiles
 
@@ -356,6 +374,8 @@ class _FusedBatch(torch.autograd.Function):
         from . import _cabi
         gs_parameters, steps = ctx.saved_tensors
         d = ctx.plan.dims
+        if ctx.tile:   # [B,3,Hmax,Wmax] read in place: rows per plane = Hmax, pixels outside a sample's own grid never read
+            return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad_output.contiguous(), chw=True), None, None, None
         grad = grad_output.new_zeros(d.batch, d.slot, d.w, 3)      # [B, slot, Wmax, 3]: what the backward sweeps
         grad[:, : ctx.h_max] = grad_output.permute(0, 2, 3, 1)
         return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad), None, None, None

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSASR_SPLAT_ABI_VERSION 2 /* 2: gsasr_dims gained batch / slot / sample_hw */
+#define GSASR_SPLAT_ABI_VERSION 3 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags */
 
 enum gsasr_status {
     GSASR_OK = 0,
@@ -57,6 +57,19 @@ enum gsasr_status {
                                          [s,8] records {sx,sy,rho,x,y,r,g,b}: element k of Gaussian i is at
                                          ptr[8*i+k].  Pass base, base+3, base+5 of one array; this is the wire
                                          format of the multi-GPU exchange, so nothing is repacked around it */
+
+#define GSASR_FLAG_CHW_GRAD 32u       /* backward reads grad_img as planar [3, row1-row0, w] (what autograd hands back for the
+                                         planar image of GSASR_FLAG_CHW_IMAGE; batched canvas: [B, 3, grad_rows, w]) instead
+                                         of [row1-row0, w, 3]: no permute pass in front of the backward.  Tile backward only */
+#define GSASR_FLAG_FORWARD_ONLY 64u   /* the plan will not be used by a backward: the workspace carries no partial-gradient
+                                         slots (32 * part_k bytes per Gaussian); a backward on it uses the
+                                         Gaussian-stationary kernel */
+#define GSASR_FLAG_BWD_GAUSSIAN 128u  /* backward kernel choice (default: the library picks): Gaussian-stationary
+                                         (one wave per Gaussian sweeping its window through L1/L2) ...              */
+#define GSASR_FLAG_BWD_TILE 256u      /* ... or tile-stationary (one workgroup per 32x16-px tile, grad_img staged once
+                                         in LDS, deterministic partial-gradient slots + gather)                     */
+#define GSASR_FLAG_BWD_ATOMIC 512u    /* tile-stationary with ONE fp32 atomic set per (tile, Gaussian) instead of the
+                                         slots (the measured alternative of DESIGN.md 3c; order-dependent rounding)  */
 
 typedef struct gsasr_dims {
     int s;        /* number of Gaussians                                              */
@@ -80,6 +93,8 @@ typedef struct gsasr_dims {
     int batch;
     int slot;
     const int *sample_hw; /* HOST array [2*batch]: (h_b, w_b) per sample, read during the call */
+    int grad_rows;        /* batched canvas + GSASR_FLAG_CHW_GRAD: rows per plane of grad_img [B, 3, grad_rows, w]
+                             (>= every h_b; 0 = slot), so that the [B,3,Hmax,Wmax] gradient autograd returns is read in place */
 } gsasr_dims;
 
 #define GSASR_MAX_BATCH 64

@@ -1,0 +1,255 @@
+"""GPU parity of the TILE-stationary backward (k_render_bwd_tile + gather; GSASR_FLAG_BWD_TILE / _ATOMIC /
+GSASR_FLAG_CHW_GRAD) against the CPU oracle, with the same inputs the Gaussian-stationary kernel is held to in
+test_hip_parity.py.  Reference semantics: utils/gs_cuda_dmax/gs.cu:85-165, utils/gs_cuda/gs.cu:112-176.
+
+Besides the tensor-level bar (2e-4 of the tensor's max-abs) every case applies a per-Gaussian criterion: a Gaussian's
+gradient row may be off by 5e-4 of that row's own max-abs (+ a floor of 1e-5 of the tensor's max-abs), so that a
+small-gradient Gaussian cannot be wrong unnoticed.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RASTER = sorted(glob.glob(os.path.join(GOLDEN, "raster_*.npz")))
+GRAD_RTOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the MI355X box)"
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def per_gaussian_ok(got, want, name, rho=None):
+    err = np.abs(got - want)
+    assert np.isfinite(got).all(), name
+    assert err.max() <= GRAD_RTOL * np.abs(want).max() + 1e-30, (name, float(err.max()), float(np.abs(want).max()))
+    tol = 5e-4 * np.abs(want).max(axis=1, keepdims=True) + 1e-5 * np.abs(want).max() + 1e-30
+    bad = err > tol
+    if rho is not None:   # |rho| > 0.99 is ill-conditioned in fp32 (1/(1-rho^2)): the tensor-level bar only
+        bad &= ((1.0 - rho.astype(np.float64) ** 2) >= 0.02)[:, None]
+    assert not bad.any(), (name, int(np.argwhere(bad)[0][0]), float(err[bad].max()), float(np.abs(want).max()))
+
+
+def _backward(sig, xy, col, wgt, h, w, dmax, dev, flag, cutoff=0.0, rows=None, chw=False, accumulate=False):
+    from gsasr_amd import _cabi
+    a, b, c = (_t(x, dev) for x in (sig, xy, col))
+    plan = _cabi.plan(a, b, c, h, w, dmax, rows=rows, cutoff=cutoff, flags=flag)
+    g = [torch.full_like(t, 0.5 if accumulate else float("nan")) for t in (a, b, c)]
+    gw = _t(wgt if rows is None else wgt[rows[0]:rows[1]], dev)
+    if chw:
+        gw = gw.permute(2, 0, 1).contiguous()
+        plan.dims.flags |= _cabi.FLAG_CHW_GRAD | _cabi.FLAG_OVERWRITE_GRADS
+        L = _cabi.lib()
+        import ctypes
+        _cabi.check(L.gsasr_splat_backward(a.data_ptr(), b.data_ptr(), c.data_ptr(), gw.data_ptr(), g[0].data_ptr(), g[1].data_ptr(),
+                                           g[2].data_ptr(), ctypes.byref(plan.dims), plan.workspace.data_ptr(), plan.workspace.numel(),
+                                           _cabi._stream(dev)), "gsasr_splat_backward")
+    else:
+        _cabi.backward(plan, a, b, c, gw, *g, overwrite=not accumulate)
+    torch.cuda.synchronize()
+    out = [t.cpu().numpy() for t in g]
+    if accumulate:
+        out = [o - 0.5 for o in out]
+    return out
+
+
+def _check(sig, xy, col, wgt, h, w, dmax, dev, flag, **kw):
+    from oracle import gs_oracle
+    rows = kw.get("rows")
+    got = _backward(sig, xy, col, wgt, h, w, dmax, dev, flag, **kw)
+    wgt_band = wgt if rows is None else wgt[rows[0]:rows[1]]
+    want = gs_oracle.backward_f64(sig, xy, col, wgt_band, dmax, h=h, rows=rows) if rows is not None else \
+        gs_oracle.backward_f64(sig, xy, col, wgt, dmax)
+    for g, r, name in zip(got, want, ("sigmas", "coords", "colors")):
+        per_gaussian_ok(g, r, name, rho=sig[:, 2])
+    return got
+
+
+def _flags():
+    from gsasr_amd import _cabi
+    return {"tile": _cabi.FLAG_BWD_TILE, "atomic": _cabi.FLAG_BWD_ATOMIC, "gaussian": _cabi.FLAG_BWD_GAUSSIAN}
+
+
+def _synth(h_lr, w_lr, scale, seed, gpp=1):
+    from gsasr_amd import synthetic
+    sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=seed, gpp=gpp)
+    wgt = synthetic.grad_image(H, W, seed + 1)
+    return sig.numpy(), xy.numpy(), col.numpy(), H, W, wgt.numpy()
+
+
+@pytest.mark.parametrize("mode", ["tile", "atomic", "gaussian"])
+@pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[7:-4] for p in RASTER])
+def test_golden_backward(path, mode, dev):
+    z = np.load(path)
+    dmax = None if float(z["dmax"]) < 0 else float(z["dmax"])
+    got = _check(z["sigmas"], z["coords"], z["colors"], z["weight"], int(z["h"]), int(z["w"]), dmax, dev, _flags()[mode])
+    for g, key in zip(got, ("g_sigmas", "g_coords", "g_colors")):   # the reference's own fp64-input run
+        assert np.abs(g - z[key + "_f64"]).max() <= GRAD_RTOL * np.abs(z[key + "_f64"]).max(), key
+
+
+@pytest.mark.parametrize("cutoff", [0.0, 32.0, 104.0, -1.0], ids=["adaptive", "tau32", "tau104", "nocut"])
+@pytest.mark.parametrize("dmax", [None, 0.5, 0.1], ids=["unbounded", "dmax0.5", "dmax0.1"])
+def test_synthetic_x4_256(dmax, cutoff, dev):
+    sig, xy, col, H, W, wgt = _synth(64, 64, 4.0, seed=10)
+    _check(sig, xy, col, wgt, H, W, dmax, dev, _flags()["tile"], cutoff=cutoff)
+
+
+@pytest.mark.parametrize("case", [(37, 29, 3.0, 1), (24, 40, 2.5, 1), (12, 12, 4.0, 16), (20, 16, 12.0, 1), (31, 17, 6.5, 2),
+                                  (48, 48, 4.0, 16)], ids=lambda c: "lr%dx%d_s%g_gpp%d" % c)
+def test_ragged_sizes_scales_and_densities(case, dev):
+    """non-square, H/W not multiples of the tile, fractional scale, x12 windows wider than their slots (atomic fallback
+    inside the slot mode), 16 Gaussians per LR pixel (many rounds per tile; the last one is BASELINE config 5's sample)"""
+    h_lr, w_lr, scale, gpp = case
+    sig, xy, col, H, W, wgt = _synth(h_lr, w_lr, scale, seed=20, gpp=gpp)
+    for dmax in (None, 0.25):
+        _check(sig, xy, col, wgt, H, W, dmax, dev, _flags()["tile"])
+
+
+def test_planar_gradient_equals_interleaved(dev):
+    sig, xy, col, H, W, wgt = _synth(40, 33, 4.0, seed=40)
+    a = _check(sig, xy, col, wgt, H, W, 0.3, dev, _flags()["tile"])
+    b = _check(sig, xy, col, wgt, H, W, 0.3, dev, _flags()["tile"], chw=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)          # same kernel, same order of operations: bit-identical
+
+
+def test_deterministic_and_accumulate_contract(dev):
+    """slots + gather: run to run bit-identical (no atomics on the normal path); without OVERWRITE_GRADS the
+    gradient is ADDED to what the caller left in the outputs (the reference's dmax backward, gs.cu:139-146)"""
+    sig, xy, col, H, W, wgt = _synth(56, 56, 4.0, seed=50)
+    a = _backward(sig, xy, col, wgt, H, W, 0.1, dev, _flags()["tile"])
+    b = _backward(sig, xy, col, wgt, H, W, 0.1, dev, _flags()["tile"])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    c = _backward(sig, xy, col, wgt, H, W, 0.1, dev, _flags()["tile"], accumulate=True)
+    for x, y in zip(a, c):
+        assert np.abs(x - y).max() <= 1e-6 * max(1.0, np.abs(x).max())
+
+
+def test_row_band(dev):
+    sig, xy, col, H, W, wgt = _synth(48, 40, 4.0, seed=60)
+    for rows in ((0, 64), (50, 131), (H - 37, H)):
+        _check(sig, xy, col, wgt, H, W, 0.2, dev, _flags()["tile"], rows=rows)
+
+
+def test_large_class_and_degenerate_gaussians(dev):
+    """check.py-style sigma ~ U(0,1): every Gaussian spans the image (large class: more tiles than slots, atomic
+    accumulators), plus off-image, NaN and needle Gaussians"""
+    rng = np.random.default_rng(7)
+    s, h, w = 60, 70, 90
+    sig = np.concatenate([0.999 * rng.random((s, 2)), 1.8 * rng.random((s, 1)) - 0.9], 1).astype(np.float32)
+    xy = (2 * rng.random((s, 2)) - 1).astype(np.float32)
+    col = rng.random((s, 3)).astype(np.float32)
+    wgt = rng.random((h, w, 3)).astype(np.float32)
+    sig[5, :2] = (1e-5, 0.5)
+    sig[6, :2] = (0.4, 2e-6)
+    xy[7] = (3.0, 0.2)
+    xy[8] = (np.nan, 0.0)
+    sig[9, 2] = 0.9995
+    from oracle import gs_oracle
+    for dmax in (None, 0.6):
+        got = _backward(sig, xy, col, wgt, h, w, dmax, dev, _flags()["tile"])
+        keep = np.ones(s, bool)
+        keep[8] = False   # a non-finite Gaussian is dropped (documented deviation: the reference propagates NaN)
+        want = gs_oracle.backward_f64(sig[keep], xy[keep], col[keep], wgt, dmax)
+        for g, r, name in zip(got, want, ("sigmas", "coords", "colors")):
+            assert np.all(g[8] == 0.0)
+            per_gaussian_ok(g[keep], r, name, rho=sig[keep, 2])
+
+
+def test_fused_step_planar_backward_through_host_api(dev):
+    """generate_2D_gaussian_splatting_step with BACKWARD_KERNEL = 'tile' (plan with slots, planar gradient read in
+    place) against the oracle composed with the torch prologue"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    from oracle import gs_oracle
+    h_lr, w_lr, scale = 30, 26, 4.0
+    H, W = int(h_lr * scale), int(w_lr * scale)
+    p = synthetic.gs_parameters(h_lr, w_lr, seed=70)
+    wgt = synthetic.grad_image(H, W, 71)
+    old = gsp.BACKWARD_KERNEL
+    res = {}
+    try:
+        for mode in ("gaussian", "tile"):
+            gsp.BACKWARD_KERNEL = mode
+            pa = p.to(dev).requires_grad_(True)
+            out = gsp.generate_2D_gaussian_splatting_step((H, W), pa, scale, torch.tensor([scale, scale]), dmax=0.3)
+            (out * wgt.to(dev).permute(2, 0, 1)).sum().backward()
+            res[mode] = (out.detach().cpu().numpy(), pa.grad.cpu().numpy())
+    finally:
+        gsp.BACKWARD_KERNEL = old
+    # reference composition on the CPU: torch prologue (autograd) + oracle splat backward
+    pc = p.clone().requires_grad_(True)
+    sx, sy, rho, xy, col = gsp._activate(pc)
+    sig_k, xy_k, col_k, _, _ = gsp._to_kernel_frame(sx, sy, rho, xy, col, (H, W), 1.2 / scale)
+    g = gs_oracle.backward_f64(sig_k.detach().numpy(), xy_k.detach().numpy(), col_k.detach().numpy(), wgt.numpy(), 0.3)
+    torch.autograd.backward([sig_k, xy_k, col_k], [torch.from_numpy(x).float() for x in g])
+    want = pc.grad.numpy()
+    for mode in ("gaussian", "tile"):
+        per_gaussian_ok(res[mode][1], want, "gs_parameters/" + mode)
+    # (two plans: the order of the Gaussians inside a cell, hence the forward's summation order, is not fixed)
+    assert np.abs(res["gaussian"][0] - res["tile"][0]).max() <= 1e-5
+
+
+def test_batched_canvas_planar_backward(dev):
+    """ragged batch through generate_2D_gaussian_splatting_batch: the [B,3,Hmax,Wmax] gradient is read in place
+    (grad_rows = Hmax < slot) and only inside each sample's own grid"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    sizes = [(40, 56), (64, 37), (50, 50)]
+    h_lr, w_lr = 10, 12
+    p = torch.stack([synthetic.gs_parameters(h_lr, w_lr, seed=80 + b, gpp=2) for b in range(3)]).to(dev)
+    scales = [4.0, 5.3, 4.4]
+    sms = [torch.tensor([s, s]) for s in scales]
+    hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    wgt = torch.rand(3, 3, hm, wm, generator=torch.Generator().manual_seed(5)).to(dev)
+    old = gsp.BACKWARD_KERNEL
+    res = {}
+    try:
+        for mode in ("gaussian", "tile"):
+            gsp.BACKWARD_KERNEL = mode
+            pa = p.clone().requires_grad_(True)
+            out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, scales, sms, dmax=0.4)
+            (out * wgt).sum().backward()
+            res[mode] = pa.grad.cpu().numpy()
+    finally:
+        gsp.BACKWARD_KERNEL = old
+    for b in range(3):
+        per_gaussian_ok(res["tile"][b], res["gaussian"][b], f"sample {b}")
+    # and the per-sample loop of single-image steps (the reference's structure) as the independent target
+    pa = p.clone().requires_grad_(True)
+    tot = 0
+    for b in range(3):
+        o = gsp.generate_2D_gaussian_splatting_step(sizes[b], pa[b], scales[b], sms[b], dmax=0.4)
+        tot = tot + (o * wgt[b, :, :sizes[b][0], :sizes[b][1]]).sum()
+    tot.backward()
+    for b in range(3):
+        per_gaussian_ok(res["tile"][b], pa.grad[b].cpu().numpy(), f"sample {b} vs loop")
+
+
+def test_config2_full_size_tile_backward_against_oracle(dev):
+    """BASELINE config 2 in full (1024^2, 65 536 Gaussians, dmax 0.1): gradient of a 96-row band against the
+    oracle (all Gaussians, band rows only: the oracle finishes in seconds), the rest through the row-partition property"""
+    from gsasr_amd import synthetic
+    from oracle import gs_oracle
+    sig, xy, col, H, W = synthetic.kernel_inputs(256, 256, 4.0, seed=0)
+    wgt = synthetic.grad_image(H, W, 1)
+    s, c, k, g = sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy()
+    rows = (448, 544)
+    got = _backward(s, c, k, g, H, W, 0.1, dev, _flags()["tile"], rows=rows)
+    want = gs_oracle.backward_f64(s, c, k, g[rows[0]:rows[1]], 0.1, h=H, rows=rows)
+    for a, b, name in zip(got, want, ("sigmas", "coords", "colors")):
+        per_gaussian_ok(a, b, name, rho=s[:, 2])
+    full = _backward(s, c, k, g, H, W, 0.1, dev, _flags()["tile"])
+    ref = _backward(s, c, k, g, H, W, 0.1, dev, _flags()["gaussian"])
+    for a, b, name in zip(full, ref, ("sigmas", "coords", "colors")):
+        per_gaussian_ok(a, b, name, rho=s[:, 2])
