@@ -48,6 +48,7 @@
 // No MFMA: this is gather/scatter-accumulate with one transcendental per pair, not a contraction.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -163,6 +164,17 @@ int classify_blocks(const gsasr_dims *d)
     return (n + 255) / 256;
 }
 
+// which backward kernel: explicit flag > environment GSASR_SPLAT_BWD (gaussian | tile | atomic; development A/B) > default
+int bwd_env()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GSASR_SPLAT_BWD");
+        v = !e ? 0 : !strcmp(e, "gaussian") ? 1 : !strcmp(e, "tile") ? 2 : !strcmp(e, "atomic") ? 3 : 0;
+    }
+    return v;
+}
+
 // Tile-stationary backward: every (32x16-px tile, Gaussian) pair leaves its partial sums in slot t of the Gaussian's
 // own row of `part_k` slots, t = the tile's ordinal inside the Gaussian's window (row-major), so that nothing is
 // accumulated atomically and the result does not depend on scheduling.  GSASR's Gaussians are about one LR pixel in
@@ -172,6 +184,8 @@ int classify_blocks(const gsasr_dims *d)
 // per Gaussian, as for the Gaussian-stationary kernel's unrolling.
 int bwd_part_k(const gsasr_dims *d)
 {
+    // only plans made for the tile-stationary backward carry slots (32 * part_k bytes per Gaussian)
+    if ((d->flags & GSASR_FLAG_FORWARD_ONLY) || !((d->flags & GSASR_FLAG_BWD_TILE) || bwd_env() == 2)) return 0;
     const double px_per_gaussian = (double)(d->row1 - d->row0) * (double)d->w / (double)(d->s > 0 ? d->s : 1);
     return px_per_gaussian >= 32.0 ? 16 : 8;
 }
@@ -201,7 +215,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_done = o;   o += align_up(s * 4, 256);
     L.off_bbox = o;   o += align_up(s * 32, 256);
     L.off_win = o;    o += align_up(s * 8, 256);
-    L.part_k = (d->flags & GSASR_FLAG_FORWARD_ONLY) ? 0 : bwd_part_k(d);
+    L.part_k = bwd_part_k(d);
     L.off_part = o;   o += align_up(s * 32 * (size_t)L.part_k, 256);
     L.off_qspan = o;  o += L.part_k ? align_up(s * 16, 256) : 0;
     L.total = o;
@@ -233,15 +247,21 @@ PlanView make_view(const Layout &L, void *ws)
     return V;
 }
 
-float g_default_cutoff = -12345.f;  // process default: 0 = adaptive; resolved lazily from env GSASR_SPLAT_CUTOFF
+// process default of the support cutoff: 0 = adaptive; first read from the environment (GSASR_SPLAT_CUTOFF), then
+// whatever gsasr_set_default_cutoff stored.  One atomic word: setting and planning from different threads is a benign
+// race on WHICH value a plan sees, never a torn one.
+std::atomic<float> g_default_cutoff{-12345.f};
 
 float default_cutoff()
 {
-    if (g_default_cutoff == -12345.f) {
+    float v = g_default_cutoff.load(std::memory_order_relaxed);
+    if (v == -12345.f) {
         const char *e = getenv("GSASR_SPLAT_CUTOFF");
-        g_default_cutoff = e ? (float)atof(e) : 0.f;
+        float init = e ? (float)atof(e) : 0.f, expected = -12345.f;
+        g_default_cutoff.compare_exchange_strong(expected, init, std::memory_order_relaxed);
+        v = g_default_cutoff.load(std::memory_order_relaxed);
     }
-    return g_default_cutoff;
+    return v;
 }
 
 // tau used for `s` Gaussians: explicit, process-fixed, or adaptive ln(s/eps) in [16, 104] (see the header)
@@ -251,17 +271,6 @@ float resolve_cutoff(float cutoff, int s)
     if (cutoff != 0.f) return cutoff;
     const double tau = std::log((double)(s > 1 ? s : 1) / (double)GSASR_SPLAT_DEFAULT_EPS);
     return (float)(tau < 16.0 ? 16.0 : tau > (double)GSASR_SPLAT_EXACT_CUTOFF ? (double)GSASR_SPLAT_EXACT_CUTOFF : tau);
-}
-
-// which backward kernel: explicit flag > environment GSASR_SPLAT_BWD (gaussian | tile | atomic; development A/B) > default
-int bwd_env()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GSASR_SPLAT_BWD");
-        v = !e ? 0 : !strcmp(e, "gaussian") ? 1 : !strcmp(e, "tile") ? 2 : !strcmp(e, "atomic") ? 3 : 0;
-    }
-    return v;
 }
 
 Params make_params(const gsasr_dims *d, const Layout &L)
@@ -314,8 +323,10 @@ __device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y
     Box b;
     float ext_x = P.dmax, ext_y = P.dmax;
     if (P.kcut > 0.f) {  // marginal bound of the ellipse {exponent >= -tau}: |dx| <= sx*sqrt(2 tau), any rho
-        ext_x = fminf(ext_x, P.kcut * sx);
-        ext_y = fminf(ext_y, P.kcut * sy);
+        // (|sigma|: the reference's formulas only see sigma^2 and 1/(sx sy), gs.cu:33-56, so a negative sigma -- the
+        // raw op accepts any float, check.py feeds randn -- is a Gaussian like any other, with the sign of rho flipped)
+        ext_x = fminf(ext_x, P.kcut * fabsf(sx));
+        ext_y = fminf(ext_y, P.kcut * fabsf(sy));
     }
     // Pixel X sits at px = 2X/(w-1)-1, so |px - x| <= ext  <=>  |X - cxp| <= ext*hx with cxp = (x+1)*hx.
     // Evaluated in double (once per Gaussian); the float pixel table differs from the exact grid by
@@ -613,8 +624,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         // does a pixel of a tile this Gaussian is binned to ever need the dmax test?  Not if its support box
         // lies inside its dmax box: pixels beyond the support box carry < exp(-tau) whether tested or not.
         const float hx = 0.5f * (float)(g.w - 1), hy = 0.5f * (float)(g.h - 1);
-        const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * sx * hx + 1.f <= P.dmax * hx &&
-                                               P.kcut * sy * hy + 1.f <= P.dmax * hy);
+        const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * fabsf(sx) * hx + 1.f <= P.dmax * hx &&
+                                               P.kcut * fabsf(sy) * hy + 1.f <= P.dmax * hy);
         if (b.cls == 2) {
             bb = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
         } else {
@@ -636,8 +647,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 const float omr = (float)(1.0 - dr * dr);
                 const float iq = 1.f / (omr * spx * spy);
                 const float qa = 0.5f * iq * (spy / spx), qb = -rho * iq, qc = 0.5f * iq * (spx / spy);
-                const float umax = spx * P.kcut, vmax = spy * P.kcut;
-                const float vstar = rho * spy / spx * umax;                   // v of the ellipse's rightmost point
+                const float umax = fabsf(spx) * P.kcut, vmax = fabsf(spy) * P.kcut;
+                const float vstar = -qb * umax / (2.f * qc);                  // v of the ellipse's rightmost point (= rho spy k)
                 const float disc0 = 4.f * qa * tau, disc2 = 4.f * qa * qc - qb * qb, i2qa = 0.5f / qa;
                 const float eps = (float)WINDOW_EPS;
                 const int tx0 = b.c0 >> SUBX_SHIFT;
@@ -2568,7 +2579,7 @@ int gsasr_abi_version(void) { return GSASR_SPLAT_ABI_VERSION; }
 
 const char *gsasr_last_error(void) { return tl_err; }
 
-void gsasr_set_default_cutoff(float tau) { g_default_cutoff = tau; }
+void gsasr_set_default_cutoff(float tau) { g_default_cutoff.store(tau, std::memory_order_relaxed); }
 
 float gsasr_get_default_cutoff(void) { return default_cutoff(); }
 

@@ -400,6 +400,13 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
     return default_step_size / final
 
 
+def max_canvas_batch(h_max: int) -> int:
+    """samples of up to `h_max` rows that fit ONE batched canvas: 64 slots (GSASR_MAX_BATCH) of h_max rounded up to
+    whole 16-row tiles, 32 767 canvas rows in all (the plan packs pixel indices in 15 bits)"""
+    slot = (int(h_max) + 15) // 16 * 16
+    return max(1, min(64, 32767 // slot))
+
+
 def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_modifies, default_step_size=1.2,
                                          mode='scale_modify', if_dmax=True, dmax_mode='fix', dmax=25, sample_coords=None):
     """Batched `generate_2D_gaussian_splatting_step`: `gs_parameters` `[B,N,9]`, per-sample
@@ -414,7 +421,19 @@ def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_
     if gs_parameters.dtype != torch.float32:
         gs_parameters = gs_parameters.float()
     uniform_dmax = (not if_dmax) or dmax_mode == 'fix' or len(set(sizes)) == 1
-    if 1 < B <= 64 and gs_parameters.is_cuda and gs_parameters.dim() == 3 and gs_parameters.shape[2] == 9 and uniform_dmax:
+    cap = max_canvas_batch(max(h for h, _ in sizes))
+    if B > cap >= 2 and gs_parameters.is_cuda and gs_parameters.dim() == 3 and uniform_dmax:
+        # more samples than one canvas holds (64 slots, 32 767 rows): several canvases of `cap` samples, the last
+        # one possibly a single sample (which takes the per-sample path below)
+        parts = [generate_2D_gaussian_splatting_batch(sr_sizes[a: a + cap], gs_parameters[a: a + cap], scales[a: a + cap],
+                                                      scale_modifies[a: a + cap], default_step_size, mode, if_dmax, dmax_mode,
+                                                      dmax, None if sample_coords is None else sample_coords[a: a + cap])
+                 for a in range(0, B, cap)]
+        if sample_coords is None:
+            h_max, w_max = max(h for h, _ in sizes), max(w for _, w in sizes)
+            parts = [F.pad(o, (0, w_max - o.shape[3], 0, h_max - o.shape[2])) for o in parts]
+        return torch.cat(parts)
+    if 1 < B <= cap and gs_parameters.is_cuda and gs_parameters.dim() == 3 and gs_parameters.shape[2] == 9 and uniform_dmax:
         dev = gs_parameters.device
         steps = _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev)
         dmax_eff = _resolve_dmax(dmax, dmax_mode, sr_sizes[0]) if if_dmax else None

@@ -149,12 +149,17 @@ class _BandSplat(Function):
 
 
 def splat_band(sigmas, coords, colors, h: int, w: int, dmax: Optional[float] = None, group=None,
-               grad_reduce: str = "reduce_scatter", rows: Optional[Tuple[int, int]] = None, backend=None):
+               grad_reduce: str = "all_reduce", rows: Optional[Tuple[int, int]] = None, backend=None):
     """Render this rank's row band: returns `[r1-r0, w, 3]` (HWC, like `GSCUDA.apply`).
 
     All ranks must hold identical `sigmas/coords/colors` (see `broadcast_gaussians`).  Backward
-    reduces the per-Gaussian gradients across the group with `grad_reduce` in
-    {"reduce_scatter", "all_reduce", "none"}.
+    reduces the per-Gaussian gradients across the group with `grad_reduce`:
+      "all_reduce" (default)  every rank gets the complete gradient -- right for a replicated decoder and for the
+                              `broadcast_gaussians(src)` flow, where only the src rank has an autograd graph behind
+                              the Gaussians and needs ALL of their gradient;
+      "reduce_scatter"        rank g gets the complete gradient of its `gaussian_slice` rows and ZEROS elsewhere --
+                              only for a decoder that is itself sharded by Gaussian slice (1/G of the volume);
+      "none"                  the rank's partial gradient, no collective.
     """
     if rows is None:
         if dist.is_available() and dist.is_initialized():
@@ -195,9 +200,10 @@ class BandExchange:
       backward: the local backward writes `g_records` for all three parts; the two halo parts are sent
                 back (same batched call, reversed) and `merge` adds them into the owners' gradients.
 
-    Nothing here synchronises the host.  Two conditions cannot be detected without reading `counts`
-    (device): more than `cap` Gaussians selected for one side, or a footprint reaching beyond the adjacent
-    band.  `check()` reads them (host sync) and raises; call it once after warm-up or every few steps.
+    Nothing here synchronises the host.  Two conditions make a step incomplete: more than `cap` Gaussians selected
+    for one side, or a footprint reaching beyond the adjacent band.  `splat_band_local` poisons its image and its
+    gradient with a NaN (device-side, from `counts`) when that happens, so it cannot go unnoticed; `check()` reads
+    `counts` (host sync) and raises with the numbers.
     """
 
     def __init__(self, n_local: int, cap: int, h: int, w: int, dmax: Optional[float], cutoff: float = 0.0,
@@ -269,6 +275,7 @@ class BandExchange:
 
     def exchange_forward(self) -> torch.Tensor:
         """own Gaussians are in `self.own`; returns `records` with the neighbours' halos in place."""
+        self.version = getattr(self, "version", 0) + 1
         self.select()
         self._swap(self.send_up, self.from_above, self.send_down, self.from_below)
         return self.records
@@ -279,6 +286,12 @@ class BandExchange:
         n, c = self.n, self.cap
         self._swap(self.g_records[n:n + c], self.ret_up, self.g_records[n + c:], self.ret_down)
         return self.merge()
+
+    def incomplete(self) -> torch.Tensor:
+        """device-side bool scalar: the last `select` dropped Gaussians (n_up or n_down > cap, or n_far > 0).
+        `splat_band_local` turns it into a NaN in its outputs, so `check()` is a diagnosis, not a duty."""
+        c = self.counts
+        return ((c[0] > self.cap) | (c[1] > self.cap) | (c[2] > 0)).reshape(1)
 
     def check(self) -> Tuple[int, int]:
         """Host-synchronising validity check of the last `exchange_forward`; returns (n_up, n_down)."""
@@ -292,6 +305,14 @@ class BandExchange:
         return n_up, n_down
 
 
+def _poison_if(flag: torch.Tensor, t: torch.Tensor) -> None:
+    """t.flat[0] = NaN where `flag` (a device scalar) is set: one element, no host synchronisation.  A band exchange
+    that dropped Gaussians (capacity overflow, or a footprint beyond the adjacent band) must not produce a
+    plausible-looking image or gradient: the NaN reaches the loss of that very step."""
+    first = t.view(-1)[:1]
+    first.copy_(torch.where(flag, torch.full_like(first, float("nan")), first))
+
+
 class _BandLocalSplat(Function):
     @staticmethod
     def forward(ctx, packed_local, ex):
@@ -299,15 +320,25 @@ class _BandLocalSplat(Function):
             ex.own.copy_(packed_local)
         records = ex.exchange_forward()
         slab, state = ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff)
-        ctx.ex, ctx.state = ex, state
+        ctx.ex, ctx.state, ctx.version = ex, state, ex.version
+        if slab.numel():
+            _poison_if(ex.incomplete(), slab)
         return slab
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_slab):
         ex = ctx.ex
+        if ex.version != ctx.version:
+            # the exchange's buffers (records, indices, counts) now belong to a later forward: gradients computed from
+            # them would silently be those of the wrong Gaussians
+            raise RuntimeError("BandExchange was used by another splat_band_local forward before this backward ran; "
+                               "use one BandExchange per forward that is in flight (e.g. per accumulation micro-step)")
         ex.backend.backward_packed(ctx.state, ex.records, grad_slab, ex.g_records)
-        return ex.exchange_backward().clone(), None
+        g = ex.exchange_backward().clone()
+        if g.numel():
+            _poison_if(ex.incomplete(), g)
+        return g, None
 
 
 def splat_band_local(packed_local: torch.Tensor, ex: BandExchange) -> torch.Tensor:

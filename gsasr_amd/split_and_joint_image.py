@@ -4,7 +4,7 @@
 The reference cuts the (reflect-padded) LR image into overlapping `split_size` tiles, runs encoder, decoder and
 rasterizer tile by tile, and pastes the SR tiles into one canvas, dropping `crop_size` rows/columns on the sides
 that overlap an earlier tile.  Here the encoder/decoder callables are still run per tile (they are the caller's),
-but the rasterizer runs ALL tiles of up to 64 at a time as one batched canvas (every tile has the same size,
+but the rasterizer runs ALL tiles, as many at a time as fit one batched canvas (64 slots, 32 767 rows), (every tile has the same size,
 `gsasr_amd.gaussian_splatting.generate_2D_gaussian_splatting_batch`), and the pasting is one rule instead of the
 reference's case tree -- including its one irregularity, kept on purpose: with a fractional scale factor the
 reference does not crop the top of a last-column tile (or the left of a last-row tile) that is neither in the
@@ -20,9 +20,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .gaussian_splatting import generate_2D_gaussian_splatting_batch, generate_2D_gaussian_splatting_step
-
-_MAX_BATCH = 64
+from .gaussian_splatting import generate_2D_gaussian_splatting_batch, generate_2D_gaussian_splatting_step, max_canvas_batch
 
 
 def _paste_rule(i, j, nh, nw, crop, fractional):
@@ -67,8 +65,10 @@ def split_and_joint_image(lq, scale_factor, split_size, overlap_size, model_g, m
     # rasterizer: all tiles have the same size and scale -> batched canvases of up to 64 tiles
     tiles = []
     if cuda_rendering and params and params[0].is_cuda and len(params) > 1:
-        for a in range(0, len(params), _MAX_BATCH):
-            chunk = params[a: a + _MAX_BATCH]
+        # tiles per canvas: 64 slots, 32 767 canvas rows (17 tiles of the reference's default 480-px tile at x4)
+        per_canvas = max_canvas_batch(size_sr)
+        for a in range(0, len(params), per_canvas):
+            chunk = params[a: a + per_canvas]
             if len(chunk) == 1:
                 break
             out = generate_2D_gaussian_splatting_batch([(size_sr, size_sr)] * len(chunk), torch.stack(chunk),

@@ -37,6 +37,13 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: these entry points are everything it exports */
+#if defined(__GNUC__) || defined(__clang__)
+#define GSASR_API __attribute__((visibility("default")))
+#else
+#define GSASR_API
+#endif
+
 #define GSASR_SPLAT_ABI_VERSION 3 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags */
 
 enum gsasr_status {
@@ -61,13 +68,14 @@ enum gsasr_status {
 #define GSASR_FLAG_CHW_GRAD 32u       /* backward reads grad_img as planar [3, row1-row0, w] (what autograd hands back for the
                                          planar image of GSASR_FLAG_CHW_IMAGE; batched canvas: [B, 3, grad_rows, w]) instead
                                          of [row1-row0, w, 3]: no permute pass in front of the backward.  Tile backward only */
-#define GSASR_FLAG_FORWARD_ONLY 64u   /* the plan will not be used by a backward: the workspace carries no partial-gradient
-                                         slots (32 * part_k bytes per Gaussian); a backward on it uses the
-                                         Gaussian-stationary kernel */
+#define GSASR_FLAG_FORWARD_ONLY 64u   /* the plan will not be used by a backward (no slots even if GSASR_FLAG_BWD_TILE is set) */
 #define GSASR_FLAG_BWD_GAUSSIAN 128u  /* backward kernel choice (default: the library picks): Gaussian-stationary
                                          (one wave per Gaussian sweeping its window through L1/L2) ...              */
 #define GSASR_FLAG_BWD_TILE 256u      /* ... or tile-stationary (one workgroup per 32x16-px tile, grad_img staged once
-                                         in LDS, deterministic partial-gradient slots + gather)                     */
+                                         in LDS, deterministic partial-gradient slots + gather).  Set it on the dims the
+                                         PLAN is made with: the workspace then carries the slots (32 * 8 or 16 bytes per
+                                         Gaussian) and the per-quadrant ellipse spans; a backward asked for this kernel
+                                         on a plan without slots accumulates with fp32 atomics instead (slower) */
 #define GSASR_FLAG_BWD_ATOMIC 512u    /* tile-stationary with ONE fp32 atomic set per (tile, Gaussian) instead of the
                                          slots (the measured alternative of DESIGN.md 3c; order-dependent rounding)  */
 
@@ -112,26 +120,26 @@ typedef struct gsasr_dims {
 #define GSASR_SPLAT_DEFAULT_EPS 1e-5f
 #define GSASR_SPLAT_EXACT_CUTOFF 104.0f
 
-int gsasr_abi_version(void);
-const char *gsasr_last_error(void);
+GSASR_API int gsasr_abi_version(void);
+GSASR_API const char *gsasr_last_error(void);
 
 /* Bytes of scratch the plan needs for these dims (0 on bad dims). 256-byte aligned base required. */
-size_t gsasr_splat_workspace_bytes(const gsasr_dims *dims);
+GSASR_API size_t gsasr_splat_workspace_bytes(const gsasr_dims *dims);
 
 /* Bin the Gaussians for [row0,row1) into `workspace` (classify -> scan -> scatter -> pack). */
-int gsasr_splat_plan(const float *sigmas /*[s,3]*/, const float *coords /*[s,2]*/,
+GSASR_API int gsasr_splat_plan(const float *sigmas /*[s,3]*/, const float *coords /*[s,2]*/,
                      const float *colors /*[s,3]*/, const gsasr_dims *dims, void *workspace,
                      size_t workspace_bytes, void *stream);
 
 /* img[row1-row0, w, 3] += splat (= splat with GSASR_FLAG_OVERWRITE_IMAGE).  `workspace` must hold the
  * plan of the same inputs and dims. */
-int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes,
+GSASR_API int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes,
                         float *img, void *stream);
 
 /* g_* += d(sum(grad_img*img))/d{sigmas,coords,colors} over rows [row0,row1).  Outputs must be
  * zero-initialised by the caller when a plain gradient is wanted (the reference wrapper does
  * torch.zeros_like, gs_cuda_dmax/gswrapper.py:40-42), unless GSASR_FLAG_OVERWRITE_GRADS is set. */
-int gsasr_splat_backward(const float *sigmas, const float *coords, const float *colors,
+GSASR_API int gsasr_splat_backward(const float *sigmas, const float *coords, const float *colors,
                          const float *grad_img /*[row1-row0, w, 3]*/, float *g_sigmas,
                          float *g_coords, float *g_colors, const gsasr_dims *dims,
                          const void *workspace, size_t workspace_bytes, void *stream);
@@ -143,9 +151,9 @@ int gsasr_splat_backward(const float *sigmas, const float *coords, const float *
  * elementwise launches.  `step_size` points at one float in DEVICE memory (default_step_size / scale, which
  * the reference holds as a 0-dim tensor), so no host sync is needed.  The backward applies the chain rule
  * and overwrites g_parameters[n,9]. */
-int gsasr_prologue_forward(const float *gs_parameters, const float *step_size, int n, int h, int w,
+GSASR_API int gsasr_prologue_forward(const float *gs_parameters, const float *step_size, int n, int h, int w,
                            float *sigmas, float *coords, float *colors, void *stream);
-int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, int n, int h, int w,
+GSASR_API int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, int n, int h, int w,
                             const float *g_sigmas, const float *g_coords, const float *g_colors,
                             float *g_parameters, void *stream);
 
@@ -154,10 +162,10 @@ int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, 
  * kernel-frame tensors and their gradients (gsasr_step_workspace_bytes >= gsasr_splat_workspace_bytes).
  * Forward honours dims.flags (OVERWRITE_IMAGE, CHW_IMAGE); backward always stores g_parameters[n,9] and
  * expects grad_img as [row1-row0, w, 3]. */
-size_t gsasr_step_workspace_bytes(const gsasr_dims *dims);
-int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+GSASR_API size_t gsasr_step_workspace_bytes(const gsasr_dims *dims);
+GSASR_API int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
                        size_t workspace_bytes, float *img, void *stream);
-int gsasr_step_backward(const float *gs_parameters, const float *step_size, const float *grad_img,
+GSASR_API int gsasr_step_backward(const float *gs_parameters, const float *step_size, const float *grad_img,
                         float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
                         void *stream);
 
@@ -179,29 +187,29 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
  *   sample_ws scratch of gsasr_sample_workspace_bytes(dims, n_points) bytes, 256-byte aligned: the sorted points.
  *             The backward re-sorts `points`, or, given points = NULL, uses what the forward call left there.
  * The step variants fuse the host prologue exactly as gsasr_step_forward / gsasr_step_backward do. */
-size_t gsasr_sample_workspace_bytes(const gsasr_dims *dims, int n_points);
-int gsasr_splat_sample_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, const int *points,
+GSASR_API size_t gsasr_sample_workspace_bytes(const gsasr_dims *dims, int n_points);
+GSASR_API int gsasr_splat_sample_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, const int *points,
                                int n_points, float *out, void *sample_ws, size_t sample_ws_bytes, void *stream);
-int gsasr_splat_sample_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_out,
+GSASR_API int gsasr_splat_sample_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_out,
                                 float *g_sigmas, float *g_coords, float *g_colors, const gsasr_dims *dims,
                                 const void *workspace, size_t workspace_bytes, const int *points, int n_points,
                                 void *sample_ws, size_t sample_ws_bytes, void *stream);
-int gsasr_step_sample_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+GSASR_API int gsasr_step_sample_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
                               size_t workspace_bytes, const int *points, int n_points, float *out, void *sample_ws,
                               size_t sample_ws_bytes, void *stream);
-int gsasr_step_sample_backward(const float *gs_parameters, const float *step_size, const float *grad_out,
+GSASR_API int gsasr_step_sample_backward(const float *gs_parameters, const float *step_size, const float *grad_out,
                                float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
                                const int *points, int n_points, void *sample_ws, size_t sample_ws_bytes, void *stream);
 
 /* Reference-shaped launchers (allocate their scratch stream-ordered, plan, run, free). */
-int gsasr_gs_render(const float *sigmas, const float *coords, const float *colors,
+GSASR_API int gsasr_gs_render(const float *sigmas, const float *coords, const float *colors,
                     float *rendered_img, int s, int h, int w, int c, void *stream);
-int gsasr_gs_render_backward(const float *sigmas, const float *coords, const float *colors,
+GSASR_API int gsasr_gs_render_backward(const float *sigmas, const float *coords, const float *colors,
                              const float *grads, float *grads_sigmas, float *grads_coords,
                              float *grads_colors, int s, int h, int w, int c, void *stream);
-int gsasr_gs_render_dmax(const float *sigmas, const float *coords, const float *colors,
+GSASR_API int gsasr_gs_render_dmax(const float *sigmas, const float *coords, const float *colors,
                          float *rendered_img, int s, int h, int w, int c, float dmax, void *stream);
-int gsasr_gs_render_backward_dmax(const float *sigmas, const float *coords, const float *colors,
+GSASR_API int gsasr_gs_render_backward_dmax(const float *sigmas, const float *coords, const float *colors,
                                   const float *grads, float *grads_sigmas, float *grads_coords,
                                   float *grads_colors, int s, int h, int w, int c, float dmax,
                                   void *stream);
@@ -221,17 +229,17 @@ int gsasr_gs_render_backward_dmax(const float *sigmas, const float *coords, cons
  *
  * gsasr_band_merge: g_packed[index[j], :] += g_up[j, :] for j < min(n_up, cap), same for down: adds the
  * partial gradients a neighbour computed for the records it was sent. */
-int gsasr_band_select(const float *packed, const gsasr_dims *dims, int rows_above, int rows_below, int cap,
+GSASR_API int gsasr_band_select(const float *packed, const gsasr_dims *dims, int rows_above, int rows_below, int cap,
                       float *up, float *down, int *up_index, int *down_index, int *counts, void *stream);
-int gsasr_band_merge(float *g_packed, int s, const float *g_up, const float *g_down, const int *up_index,
+GSASR_API int gsasr_band_merge(float *g_packed, int s, const float *g_up, const float *g_down, const int *up_index,
                      const int *down_index, const int *counts, int cap, void *stream);
 
 /* Process-wide default used when dims.cutoff == 0: 0 = adaptive (initial state), otherwise a fixed tau
  * (initially the value of the environment variable GSASR_SPLAT_CUTOFF if set).  gsasr_resolve_cutoff
  * returns the tau a plan with dims.cutoff = `cutoff` over `s` Gaussians uses. */
-void gsasr_set_default_cutoff(float tau);
-float gsasr_get_default_cutoff(void);
-float gsasr_resolve_cutoff(float cutoff, int s);
+GSASR_API void gsasr_set_default_cutoff(float tau);
+GSASR_API float gsasr_get_default_cutoff(void);
+GSASR_API float gsasr_resolve_cutoff(float cutoff, int s);
 
 #ifdef __cplusplus
 }

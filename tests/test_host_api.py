@@ -138,3 +138,50 @@ def test_compat_install_registers_reference_module_names():
     assert S is gsp.generate_2D_gaussian_splatting_step and T is tiled.split_and_joint_image
     for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "basicsr", "gscuda")]:
         del sys.modules[k]
+
+
+def test_config1_known_answer():
+    """BASELINE.json config 1 in full: `rendering_python` on torch.manual_seed(0) inputs, 4 096 Gaussians ->
+    256^2, x4, forward only -- mean 0.21793251, max 1.79732013 and the probes of tests/golden/
+    rendering_python_config1_stats.npz, captured from the imported reference (make_golden.py:176-184).  Both this
+    package's `cuda_rendering=False` branch and the oracle's restatement (the one bench.py times as `pytorch_path`)."""
+    from oracle import host_ref
+    z = np.load(os.path.join(GOLDEN, "rendering_python_config1_stats.npz"))
+    torch.manual_seed(0)
+    g = torch.randn(4096, 9)
+    g[:, 7:9] = torch.rand(4096, 2)
+    sm = torch.tensor([4.0, 4.0])
+    for out in (gsp.generate_2D_gaussian_splatting_step((256, 256), g.clone(), 4.0, sm, cuda_rendering=False),
+                host_ref.rendering_python(g.clone(), (256, 256), sm)):
+        assert tuple(out.shape) == (3, 256, 256)
+        assert float(out.mean()) == pytest.approx(0.21793251, abs=2e-6) and float(out.mean()) == pytest.approx(float(z["mean"]), abs=2e-6)
+        assert float(out.max()) == pytest.approx(1.79732013, abs=2e-5) and float(out.max()) == pytest.approx(float(z["max"]), abs=2e-5)
+        np.testing.assert_allclose(out.sum(dim=(0, 2)).numpy(), z["sum_rows"], rtol=2e-5, atol=1e-3)
+        np.testing.assert_allclose(out[:, ::37, ::41].numpy(), z["probe"], rtol=1e-4, atol=2e-5)
+
+
+def test_compat_install_keeps_real_packages_importable(tmp_path):
+    """install() must not shadow the reference's own packages -- `utils.rdn`, `basicsr.models` ... keep
+    importing after it, only the rasterizer leaves are replaced"""
+    import subprocess
+    import sys
+    (tmp_path / "utils").mkdir()
+    (tmp_path / "utils" / "__init__.py").write_text("")
+    (tmp_path / "utils" / "rdn.py").write_text("MARK = 'real rdn'\n")
+    (tmp_path / "utils" / "gs_cuda_dmax").mkdir()
+    (tmp_path / "utils" / "gs_cuda_dmax" / "gswrapper.py").write_text("raise RuntimeError('the reference wrapper must not be imported')\n")
+    (tmp_path / "basicsr").mkdir()
+    (tmp_path / "basicsr" / "__init__.py").write_text("")
+    (tmp_path / "basicsr" / "models.py").write_text("MARK = 'real models'\n")
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from gsasr_amd import compat; compat.install()\n"
+        "import utils.rdn, basicsr.models\n"
+        "assert utils.rdn.MARK == 'real rdn' and basicsr.models.MARK == 'real models'\n"
+        "from utils.gs_cuda_dmax.gswrapper import GSCUDA as A\n"
+        "from basicsr.utils.gs_cuda.gswrapper import GSCUDA as B\n"
+        "import gsasr_amd.gs_cuda_dmax.gswrapper as m1, gsasr_amd.gs_cuda.gswrapper as m0, gscuda\n"
+        "assert A is m1.GSCUDA and B is m0.GSCUDA and hasattr(gscuda, 'gs_render')\n"
+        "print('ok')\n" % (ROOT, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr

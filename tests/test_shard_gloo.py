@@ -229,6 +229,30 @@ def test_band_exchange_reports_overflow():
     out = mgr.dict()
     mp.spawn(_exchange_worker, args=(2, _free_port(), 2, out), nprocs=2, join=True)   # cap far too small
     assert any(out[r]["err"] and "enlarge cap" in out[r]["err"] for r in range(2))
+    # ... and cannot go unnoticed even if nobody calls check(): the rank's image and gradient carry a NaN
+    for r in range(2):
+        if out[r]["err"]:
+            assert np.isnan(out[r]["slab"]).any() and np.isnan(out[r]["g"]).any()
+
+
+def test_band_exchange_is_not_silently_reused():
+    """a second splat_band_local forward on the same BandExchange before the first backward would make
+    that backward use the later step's records and indices -- it raises instead"""
+    sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
+    mine = shard.pack(sig, xy, col)
+    ex = shard.BandExchange(mine.shape[0], 8, H, W, DMAX_X, backend=OraclePackedBackend, rank=0, world=1)
+    p1, p2 = mine.clone().requires_grad_(True), mine.clone().requires_grad_(True)
+    a = shard.splat_band_local(p1, ex)
+    b = shard.splat_band_local(p2, ex)
+    b.sum().backward()                       # the latest forward owns the buffers: fine
+    with pytest.raises(RuntimeError, match="one BandExchange per forward"):
+        a.sum().backward()
+    assert not torch.isnan(b).any() and not torch.isnan(p2.grad).any()
+
+
+def test_splat_band_default_reduction_gives_the_source_rank_the_whole_gradient():
+    import inspect
+    assert inspect.signature(shard.splat_band).parameters["grad_reduce"].default == "all_reduce"
 
 
 # ---------------------------------------------------------------------------------------------------

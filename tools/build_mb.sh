@@ -7,6 +7,6 @@ cd "$(dirname "$0")/.."
 name=mb
 if [ $# -gt 0 ] && [[ "$1" != -* ]]; then name=mb_$1; shift; fi
 mkdir -p tools/bin
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -fvisibility=hidden -Wno-unused-function \
       -Iinclude -Igsasr_amd/csrc "$@" tools/mb.hip -o tools/bin/$name
 echo tools/bin/$name
