@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--cutoff", type=float, default=0.0, help="support cutoff tau (0 = library default: adaptive ln(N/1e-5))")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-semantics (tau 104 / no cull) and drop-in legs of config 2")
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--exchange", default="halo", choices=["halo", "broadcast"],
                     help="multi-rank data path: neighbour halo swap (default) or broadcast + reduce_scatter")
@@ -187,6 +188,11 @@ class Step:
                                                       self.out.data_ptr(), self.sws.data_ptr(), self.sws.numel(),
                                                       c._stream(self.dev)), "gsasr_step_sample_forward")
             return
+        keep = self.bdims.flags & ~(c.FLAG_COUNTERS_CLEAN | c.FLAG_PARITY)      # (persistent workspace: see do_plan)
+        self.nplans = getattr(self, "nplans", 0) + 1
+        if torch.cuda.is_current_stream_capturing():
+            self.nplans = 0
+        self.bdims.flags = keep if self.nplans <= 1 else keep | c.FLAG_COUNTERS_CLEAN | (c.FLAG_PARITY if self.nplans % 2 == 0 else 0)
         c.check(c.lib().gsasr_step_forward(self.p.data_ptr(), self.steps.data_ptr(), ctypes.byref(self.bdims),
                                            self.ws.data_ptr(), self.ws.numel(), self.img.data_ptr(), c._stream(self.dev)),
                 "gsasr_step_forward")
@@ -208,9 +214,18 @@ class Step:
     def do_plan(self):
         import ctypes
         p = self.plan
+        # the workspace persists across steps: every plan zeroes the other parity's cell counters on the side, so after
+        # the first one no memset launch is needed (GSASR_FLAG_COUNTERS_CLEAN / GSASR_FLAG_PARITY alternate)
+        c = self.cabi
+        keep = p.dims.flags & ~(c.FLAG_COUNTERS_CLEAN | c.FLAG_PARITY)
+        self.nplans = getattr(self, "nplans", 0) + 1
+        if torch.cuda.is_current_stream_capturing():
+            self.nplans = 0         # a captured plan is replayed with the same parity: it must zero its own counters
+        p.dims.flags = keep if self.nplans <= 1 else keep | c.FLAG_COUNTERS_CLEAN | (c.FLAG_PARITY if self.nplans % 2 == 0 else 0)
         if self.halo:
-            self.cabi.plan_packed(self.ex.records, self.H, self.W, self.dmax, rows=self.rows, cutoff=self.cutoff,
-                                  workspace=p.workspace)
+            self.cabi.check(c.lib().gsasr_splat_plan(self.ex.records.data_ptr(), self.ex.records.data_ptr() + 12,
+                                                     self.ex.records.data_ptr() + 20, ctypes.byref(p.dims), p.workspace.data_ptr(),
+                                                     p.workspace.numel(), c._stream(self.dev)), "plan")
             return
         self.cabi.check(self.cabi.lib().gsasr_splat_plan(self.sig.data_ptr(), self.xy.data_ptr(), self.col.data_ptr(),
                                                          ctypes.byref(p.dims), p.workspace.data_ptr(),
@@ -313,6 +328,71 @@ def copy_bandwidth(dev):
     return 2.0 * 4.0 * n / (avg * 1e-3) / 1e9
 
 
+# VALU ceilings of the pair evaluation (instruction costs measured by tools/valu_rate.hip on this
+# chip: a wave64 VALU instruction -- packed fp32 included -- issues in 4 cycles per SIMD, v_exp_f32 in 8).  One packed
+# trip evaluates 128 (Gaussian, pixel) pairs:
+#   forward  : 12 VALU + 2 v_exp_f32 = 64 cycles   (fwd_eval_one in gsasr_splat.hip)
+#   backward : 14 VALU + 2 v_exp_f32 = 72 cycles   (bwd_trip: residual, exponent, <grad, colour>, 3 moments, 3 colour sums)
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+PAIR_CEILING = {"forward": {"valu": 12, "exp": 2, "cycles_per_128_pairs": 64},
+                "backward": {"valu": 14, "exp": 2, "cycles_per_128_pairs": 72}}
+for _k in PAIR_CEILING.values():
+    _k["pairs_per_s"] = SIMDS * CLOCK_HZ / _k["cycles_per_128_pairs"] * 128.0
+
+
+def wall_ms(fn, n, dev, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def exact_runs(args, dev, pixels):
+    """the SAME config-2 step with the support cull weakened to the reference's exact set of non-zero fp32 terms
+    (tau = 104) and switched off (tau < 0: every in-box pair, the reference's operation count; SURVEY.md 7 hard part 1)"""
+    import copy
+    out = {}
+    for name, tau in (("tau104_reference_nonzero_terms", 104.0), ("nocull_every_in_box_pair", -1.0)):
+        a = copy.copy(args)
+        a.cutoff = tau
+        st = Step(a, dev, 0, 1)
+        ms = wall_ms(st, 10, dev)
+        tau_eff = st.cabi.resolve_cutoff(tau, st.plan.dims.s)
+        in_box, swept = window_pairs(st.sig, st.xy, st.H, st.W, st.dmax, tau_eff, st.rows)
+        out[name] = {"cutoff_tau": tau, "ms_per_step": ms, "value": pixels / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+                     "pairs_swept_per_direction": swept, "pairs_in_dmax_box": in_box}
+        del st
+    return out
+
+
+def dropin_run(args, dev):
+    """what a user who only aliases the reference's imports gets: `GSCUDA.apply(sigmas, coords,
+    colors, torch.zeros(H,W,3), dmax)` + autograd, allocations, memset, read-modify-write image and all, wall clock"""
+    from gsasr_amd import synthetic
+    from gsasr_amd.gs_cuda.gswrapper import GSCUDA as G0
+    from gsasr_amd.gs_cuda_dmax.gswrapper import GSCUDA as G1
+    h_lr, w_lr, scale, _ = CONFIGS["c2"]
+    sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=0, device="cpu")
+    a, b, c = (t.to(dev).requires_grad_(True) for t in (sig, xy, col))
+    wgt = synthetic.grad_image(H, W, 1).to(dev)
+    dmax = None if args.dmax < 0 else args.dmax
+
+    def step():
+        a.grad = b.grad = c.grad = None
+        z = torch.zeros(H, W, 3, device=dev)
+        img = G0.apply(a, b, c, z) if dmax is None else G1.apply(a, b, c, z, dmax)
+        img.backward(wgt)
+
+    ms = wall_ms(step, 30, dev, warm=5)
+    return {"ms_per_step": ms, "value": H * W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+            "what": "GSCUDA.apply(sigmas, coords, colors, torch.zeros(H,W,3)[, dmax]) + .backward(grad) through torch autograd, "
+                    "wall clock incl. host launch overhead, allocations and the accumulate-into (+=) image"}
+
+
 def cpu_baseline(args):
     """The oracle's fp32 restatement of the reference kernels (OpenMP over the host cores) on a bounded
     sample of the SAME workload: a row band of config 2 (sized for ~10 s on this host) with all 65 536 Gaussians, forward + backward."""
@@ -322,7 +402,7 @@ def cpu_baseline(args):
     sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=0)
     dmax = None if args.dmax < 0 else args.dmax
     s, c, k = sig.numpy(), xy.numpy(), col.numpy()
-    cores = gs_oracle.num_threads()
+    cores = gs_oracle.num_threads()     # OpenMP team = physical cores of the host (logical CPUs: os.cpu_count())
     full_wgt = synthetic.grad_image(H, W, 1)
 
     def run(rows):
@@ -340,7 +420,7 @@ def cpu_baseline(args):
     rows = (H // 2 - nrows // 2, H // 2 - nrows // 2 + nrows)
     t0, t1, t2 = run(rows)
     px = (rows[1] - rows[0]) * W
-    out = {"value": px / (t2 - t0) / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
+    out = {"value": px / (t2 - t0) / 1e6, "unit": "HR Mpixels/s", "cores": cores, "logical_cpus": os.cpu_count(), "kind": "port",
            "sample": f"oracle/gs_ref.c fp32 restatement of gs_cuda{'_dmax' if dmax is not None else ''} (OpenMP, {cores} threads), "
                      f"config-2 inputs (N=65536, 1024^2 grid), HR rows [{rows[0]},{rows[1]}) = {px} px, fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s"}
     # the reference's pure-PyTorch path (utils/gaussian_splatting.py rendering_python), BASELINE.json config 1
@@ -349,12 +429,15 @@ def cpu_baseline(args):
         torch.manual_seed(0)
         g = torch.randn(4096, 9)
         g[:, 7:9] = torch.rand(4096, 2)
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(cores)            # the same thread count as the oracle's OpenMP team (physical cores)
         t0 = time.perf_counter()
-        host_ref.rendering_python(g, (256, 256), torch.tensor([4.0, 4.0]))
+        img1 = host_ref.rendering_python(g, (256, 256), torch.tensor([4.0, 4.0]))
         dt = time.perf_counter() - t0
+        # config 1's known answer (tests/golden/rendering_python_config1_stats.npz): what was timed is the path
+        assert abs(float(img1.mean()) - 0.21793251) <= 2e-6 and abs(float(img1.max()) - 1.79732013) <= 2e-5, \
+            (float(img1.mean()), float(img1.max()))
         out["pytorch_path"] = {"value": 256 * 256 / dt / 1e6, "unit": "HR Mpixels/s (fwd only)",
-                               "cores": os.cpu_count(), "kind": "port",
+                               "cores": cores, "kind": "port", "known_answer_checked": True,
                                "sample": f"rendering_python restatement (reference utils/gaussian_splatting.py:11-84), BASELINE.json "
                                          f"config 1 in full: 4096 Gaussians -> 256^2 HR, x4, forward only, {dt:.2f}s"}
     except Exception as e:  # never let the baseline break the bench line
@@ -417,7 +500,9 @@ def main():
                 fn()
             torch.cuda.synchronize(dev)
             return (time.perf_counter() - t0) / n
-        t_graph, t_eager = quick(run), quick(step)
+        t_graph = quick(run)
+        step.nplans = 0             # (replays left the counters of the captured parity used: the eager path starts over)
+        t_eager = quick(step)
         if t_eager < t_graph:
             run, launch = step, "eager (faster than hipgraph replay: %.1f vs %.1f us/step)" % (t_eager * 1e6, t_graph * 1e6)
         else:
@@ -444,6 +529,7 @@ def main():
     mpix = step.H * step.W / (dt / args.steps) / 1e6        # whole-job HR pixels per second (all ranks)
 
     # per-kernel device time, measured live (not part of the timed region)
+    step.nplans = 0
     kern = {}
     if step.batched:   # step-level entry points: the forward stage includes the prologue and the plan
         nb, px = 36 * step.n_rank, 12 * step.pix_rank
@@ -486,6 +572,13 @@ def main():
             valu = {"pairs_in_dmax_box": in_box, "pairs_in_swept_window": swept,
                     "Gpairs_per_s": {k: round(swept / (kern[k]["avg_ms"] * 1e-3) / 1e9, 1) for k in kern if k != "plan"},
                     "note": "pairs = (Gaussian, pixel) terms; box = what gs_cuda_dmax sums, swept window = box ∩ support cutoff"}
+            # fraction of the pair-evaluation ceiling (the roof that binds): swept pairs/s over SIMDs * clock / cycles per
+            # packed trip * 128 pairs, with the instruction counts the ceiling assumes
+            valu["ceiling"] = {k: PAIR_CEILING[k] for k in kern if k in PAIR_CEILING}
+            valu["ceiling_note"] = ("1024 SIMDs x 2.4 GHz; wave64 VALU (packed fp32 included) = 4 cycles, v_exp_f32 = 8 cycles "
+                                    "(tools/valu_rate.hip); one packed trip = 128 pairs")
+            roofline["valu_frac"] = {k: swept / (kern[k]["avg_ms"] * 1e-3) / PAIR_CEILING[k]["pairs_per_s"]
+                                     for k in kern if k in PAIR_CEILING}
             if os.path.exists(pmc) and args.config == "c2" and world == 1:
                 try:
                     j = json.load(open(pmc))
@@ -521,6 +614,17 @@ def main():
             out["config"]["exchange"] = ("halo swap with ranks g-1/g+1 (send/recv), "
                                          f"{step.halo_records} records max per edge, capacity {step.ex.cap}"
                                          if step.halo else "broadcast of all Gaussians + reduce_scatter of their gradients")
+        if step.dist:
+            # self-check of the first real multi-GPU run: how many ranks RCCL saw and what each moved per step
+            import torch.distributed as dist
+            per_rank = (2 * 2 * step.ex.cap * 32 if step.halo else 32 * step.n + 32 * step.n)
+            out["config"]["rccl"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                                     "bytes_sent_per_rank_per_step": per_rank if world > 1 else 0,
+                                     "pattern": "2 x batch_isend_irecv with ranks g-1/g+1 (forward records, backward gradients)"
+                                                if step.halo else "broadcast [N,8] + reduce_scatter_tensor [N,8]"}
+        if world == 1 and args.config == "c2" and not args.no_extras and not args.force_dist:
+            out["exact"] = exact_runs(args, dev, step.H * step.W)
+            out["dropin"] = dropin_run(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

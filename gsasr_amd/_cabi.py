@@ -37,6 +37,8 @@ FLAG_FORWARD_ONLY = 64     # GSASR_FLAG_FORWARD_ONLY
 FLAG_BWD_GAUSSIAN = 128    # GSASR_FLAG_BWD_GAUSSIAN
 FLAG_BWD_TILE = 256        # GSASR_FLAG_BWD_TILE
 FLAG_BWD_ATOMIC = 512      # GSASR_FLAG_BWD_ATOMIC
+FLAG_COUNTERS_CLEAN = 1024 # GSASR_FLAG_COUNTERS_CLEAN
+FLAG_PARITY = 2048         # GSASR_FLAG_PARITY
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -160,12 +162,50 @@ def _on(device: torch.device):
     return _NOP if idx == torch.cuda.current_device() else torch.cuda.device(device)
 
 
+class _WorkspacePool:
+    """Workspaces of the step entry points, kept between calls so that a plan can skip its counter memset: every plan
+    zeroes the per-cell counters of the OTHER parity on the side (GSASR_FLAG_COUNTERS_CLEAN / GSASR_FLAG_PARITY), so a
+    workspace that comes back from a finished step is clean for the flipped parity.  Keyed by (device, stream, size):
+    reuse is ordered by the stream, exactly like the caching allocator's own reuse."""
+    KEEP = 4          # free workspaces kept per key (forward and backward of a few steps in flight)
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, key, nbytes, dev):
+        lst = self.free.get(key)
+        if lst:
+            ws, parity = lst.pop()
+            return ws, parity, True
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False
+
+    def give(self, key, ws, parity):
+        lst = self.free.setdefault(key, [])
+        if len(lst) < self.KEEP:
+            lst.append((ws, parity))
+
+    def clear(self):
+        self.free.clear()
+
+
+_POOL = _WorkspacePool()
+
+
 @dataclass
 class Plan:
     """Binning workspace of one (sigmas, coords, colors, dims): shared by forward and backward."""
     dims: Dims
     workspace: torch.Tensor
     device: torch.device
+    pool_key: Optional[tuple] = None      # set for pooled workspaces: returned (with the parity flipped) when the plan dies
+    parity: int = 0
+
+    def __del__(self):
+        if self.pool_key is not None:
+            try:
+                _POOL.give(self.pool_key, self.workspace, self.parity ^ 1)
+            except Exception:      # interpreter shutdown
+                pass
 
 
 def make_dims(s: int, h: int, w: int, dmax: Optional[float], rows: Optional[Tuple[int, int]] = None,
@@ -200,7 +240,7 @@ def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
 
 
 def _dims_with(p: Plan, extra_flags: int) -> Dims:
-    if not extra_flags:
+    if not extra_flags or (p.dims.flags & extra_flags) == extra_flags:
         return p.dims
     d = Dims.from_buffer_copy(p.dims)
     d.flags |= extra_flags
@@ -336,6 +376,9 @@ def prologue_backward(gs_parameters, step, h: int, w: int, g_sigmas, g_coords, g
     return gp
 
 
+_STEP_DIMS = {}     # (n, h, w, dmax, flags) -> (Dims, workspace bytes) of the single-image step entry points
+
+
 def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float],
                  extra_flags: int = 0):
     """prologue + plan + forward in ONE call: raw `gs_parameters[N,9]` -> planar image `[3,h,w]` (fresh).
@@ -345,17 +388,33 @@ def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int
     if dmax is not None and not (float(dmax) >= 0.0):
         raise RuntimeError("dmax must be >= 0")
     dev = gs_parameters.device
-    d = make_dims(gs_parameters.shape[0], h, w, dmax, flags=FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE | int(extra_flags))
     L = lib()
-    nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
-    if nbytes == 0:
-        check(-1, "gsasr_step_workspace_bytes")
+    key = (gs_parameters.shape[0], int(h), int(w), dmax, int(extra_flags))
+    hit = _STEP_DIMS.get(key)
+    if hit is None:      # (dims structs + workspace size per shape: built once, not per call)
+        base = FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE | int(extra_flags)
+        variants = [make_dims(gs_parameters.shape[0], h, w, dmax, flags=base | f)
+                    for f in (0, FLAG_COUNTERS_CLEAN, FLAG_COUNTERS_CLEAN | FLAG_PARITY)]   # fresh / pooled parity 0 / 1
+        nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(variants[0]))
+        if nbytes == 0:
+            check(-1, "gsasr_step_workspace_bytes")
+        if len(_STEP_DIMS) > 256:
+            _STEP_DIMS.clear()
+        hit = _STEP_DIMS[key] = (variants, nbytes)
+    variants, nbytes = hit
     with _on(dev):
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        stream = _stream(dev)
+        if torch.cuda.is_current_stream_capturing():
+            # a captured plan is replayed on the same workspace with the same parity: it must zero its own counters
+            ws, parity, clean, pool_key = torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False, None
+        else:
+            pool_key = (dev.index, stream, nbytes)
+            ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
+        d = variants[1 + parity] if clean else variants[0]
         img = torch.empty(3, int(h), int(w), dtype=torch.float32, device=dev)
-        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), _stream(dev)),
+        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
               "gsasr_step_forward")
-    return img, Plan(d, ws, dev)
+    return img, Plan(d, ws, dev, pool_key, parity)
 
 
 def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad: torch.Tensor, chw: bool = False) -> torch.Tensor:
@@ -409,11 +468,18 @@ def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax:
         check(-1, "gsasr_step_workspace_bytes")
     dev = gs_parameters.device
     with _on(dev):
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        stream = _stream(dev)
+        if torch.cuda.is_current_stream_capturing():
+            ws, parity, clean, pool_key = torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False, None
+        else:
+            pool_key = (dev.index, stream, nbytes)
+            ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
+        if clean:      # (these two bits do not change the layout)
+            d.flags |= FLAG_COUNTERS_CLEAN | (FLAG_PARITY if parity else 0)
         img = torch.empty(B, 3, d.slot, w_max, dtype=torch.float32, device=dev)
-        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), _stream(dev)),
+        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
               "gsasr_step_forward")
-    return img, Plan(d, ws, dev)
+    return img, Plan(d, ws, dev, pool_key, parity)
 
 
 def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, grad: torch.Tensor, chw: bool = False) -> torch.Tensor:

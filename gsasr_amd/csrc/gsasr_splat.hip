@@ -100,7 +100,8 @@ __device__ __forceinline__ int stride2(const Params &P) { return (P.flags & GSAS
 struct PlanView {
     int4 *geo;              // [GSASR_MAX_BATCH] {h_b, w_b, first canvas row, px-table offset} (batched canvas only)
     unsigned *hdr;          // [HDR_WORDS]
-    unsigned *cell_count;   // [ncells+2]   (ncells = "large" class, ncells+1 = "dead" class)
+    unsigned *cell_count;   // [ncells+2]   (ncells = "large" class, ncells+1 = "dead" class); the array of this plan's parity
+    unsigned *cell_count_next;  // the other parity's array: zeroed by k_classify for the next plan on this workspace
     unsigned *cell_start;   // [ncells+3]   exclusive scan of cell_count, last = s
     float *px, *py;         // [w], [h]
     unsigned *key;          // [s] class/cell of Gaussian i
@@ -133,7 +134,7 @@ __device__ __forceinline__ Geo sample_geo(const Params &P, const PlanView &V, in
 struct Layout {
     size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox, off_win, off_part, off_qspan;
     int part_k;
-    size_t zero_bytes;  // header + per-cell counts are zeroed by one memset at the start of plan
+    size_t count_bytes;  // one array of per-cell counters (there are two, used alternately: GSASR_FLAG_PARITY)
     size_t total;
     int ncx, ncy, ncells;
 };
@@ -199,8 +200,8 @@ Layout make_layout(const gsasr_dims *d)
     const size_t ncls = (size_t)L.ncells + 2, s = (size_t)d->s;
     size_t o = 0;
     L.off_hdr = o;    o += HDR_WORDS * 4;
-    L.off_count = o;  o += align_up(ncls * 4, 256);
-    L.zero_bytes = o;
+    L.count_bytes = align_up(ncls * 4, 256);
+    L.off_count = o;  o += 2 * L.count_bytes;
     L.off_geo = o;    o += GSASR_MAX_BATCH * 16;   // (outside the zeroed region: written once by k_batch_geo)
     L.off_start = o;  o += align_up((ncls + 1) * 4, 256);
     L.off_px = o;     o += align_up((size_t)d->w * 4 * (size_t)batch_of(d), 256);
@@ -222,13 +223,14 @@ Layout make_layout(const gsasr_dims *d)
     return L;
 }
 
-PlanView make_view(const Layout &L, void *ws)
+PlanView make_view(const Layout &L, void *ws, unsigned flags = 0u)
 {
     char *b = (char *)ws;
     PlanView V;
     V.geo = (int4 *)(b + L.off_geo);
     V.hdr = (unsigned *)(b + L.off_hdr);
-    V.cell_count = (unsigned *)(b + L.off_count);
+    V.cell_count = (unsigned *)(b + L.off_count + ((flags & GSASR_FLAG_PARITY) ? L.count_bytes : 0));
+    V.cell_count_next = (unsigned *)(b + L.off_count + ((flags & GSASR_FLAG_PARITY) ? 0 : L.count_bytes));
     V.cell_start = (unsigned *)(b + L.off_start);
     V.px = (float *)(b + L.off_px);
     V.py = (float *)(b + L.off_py);
@@ -379,12 +381,40 @@ __global__ __launch_bounds__(64) void k_batch_geo(BatchSizes S, int batch, int s
     if (b < batch) geo[b] = make_int4((int)S.h[b], (int)S.w[b], b * slot, b * w);
 }
 
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// The reference's host prologue for one Gaussian (utils/gaussian_splatting.py:174-180 activations, :121-123 kernel
+// frame): q = raw decoder output [sigma_x, sigma_y, rho, alpha, r, g, b, mu_x, mu_y] -> o = {sx, sy, rho | x, y | r, g, b}
+__device__ __forceinline__ void prologue_one(const float *__restrict__ q, float step, int h, int w, float (&o)[8])
+{
+    const float sx = 0.99999f * sigmoidf_(q[0]) + 1e-6f;  // the network's sigma_x is the ROW std
+    const float sy = 0.99999f * sigmoidf_(q[1]) + 1e-6f;
+    const float alpha = sigmoidf_(q[3]);
+    const float W = (float)w, H = (float)h;
+    o[0] = sy / step * 2.f / (W - 1.f);     // kernel's first sigma pairs with WIDTH (:121)
+    o[1] = sx / step * 2.f / (H - 1.f);
+    o[2] = 0.999999f * tanhf(q[2]);
+    const float c0 = q[7] * 2.f - 1.f, c1 = q[8] * 2.f - 1.f;
+    o[3] = (c0 + 1.f - 1.f / W) * W / (W - 1.f) - 1.f;   // align_corners=False -> True (:122-123)
+    o[4] = (c1 + 1.f - 1.f / H) * H / (H - 1.f) - 1.f;
+    o[5] = sigmoidf_(q[4]) * alpha;
+    o[6] = sigmoidf_(q[5]) * alpha;
+    o[7] = sigmoidf_(q[6]) * alpha;
+}
+
+// PROLOGUE: the step entry points hand over the RAW decoder parameters; the kernel-frame tensors are formed here (and
+// stored for k_bin and the backward) instead of by a separate k_prologue_fwd launch in front of the plan.
+template <bool PROLOGUE>
 __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restrict__ sigmas,
-                                                  const float *__restrict__ coords, PlanView V)
+                                                  const float *__restrict__ coords, PlanView V,
+                                                  const float *__restrict__ raw, const float *__restrict__ step_ptr,
+                                                  float *__restrict__ o_sig, float *__restrict__ o_xy, float *__restrict__ o_col)
 {
     __shared__ unsigned s_rx[4], s_ry[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
+    for (int k = i; k < P.ncells + 2; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
@@ -395,10 +425,20 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     }
     unsigned rx = 0, ry = 0, key = 0xffffffffu;
     if (i < P.s) {
-        const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
-        const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1];
-        const float x = coords[i2 + 0], y = coords[i2 + 1];
         const Geo g = sample_geo(P, V, P.batch > 1 ? i / P.nper : 0);
+        float sx, sy, x, y;
+        if (PROLOGUE) {
+            float o[8];
+            prologue_one(raw + (size_t)i * 9, step_ptr[P.batch > 1 ? i / P.nper : 0], g.h, g.w, o);
+            o_sig[i * 3 + 0] = o[0]; o_sig[i * 3 + 1] = o[1]; o_sig[i * 3 + 2] = o[2];
+            o_xy[i * 2 + 0] = o[3]; o_xy[i * 2 + 1] = o[4];
+            o_col[i * 3 + 0] = o[5]; o_col[i * 3 + 1] = o[6]; o_col[i * 3 + 2] = o[7];
+            sx = o[0]; sy = o[1]; x = o[3]; y = o[4];
+        } else {
+            const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
+            sx = sigmas[i3 + 0]; sy = sigmas[i3 + 1];
+            x = coords[i2 + 0]; y = coords[i2 + 1];
+        }
         const Box b = gaussian_box(sx, sy, x, y, P, g);
         if (b.cls == 2) {
             key = (unsigned)P.ncells + 1u;
@@ -2379,8 +2419,6 @@ __global__ __launch_bounds__(256) void k_sample_bwd(Params P, PlanView V, PtView
 // ---------------------------------------------------------------------------------------------------
 // fused host prologue (reference utils/gaussian_splatting.py:174-180 and :121-123) and its backward
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
-
 __global__ __launch_bounds__(256) void k_prologue_fwd(const float *__restrict__ p, const float *__restrict__ step_ptr,
                                                       int n, int h, int w, float *__restrict__ sigmas,
                                                       float *__restrict__ coords, float *__restrict__ colors,
@@ -2393,22 +2431,11 @@ __global__ __launch_bounds__(256) void k_prologue_fwd(const float *__restrict__ 
         h = g.x;
         w = g.y;
     }
-    const float step = step_ptr[geo ? i / nper : 0];
-    const float *q = p + (size_t)i * 9;
-    const float sx = 0.99999f * sigmoidf_(q[0]) + 1e-6f;  // the network's sigma_x is the ROW std
-    const float sy = 0.99999f * sigmoidf_(q[1]) + 1e-6f;
-    const float rho = 0.999999f * tanhf(q[2]);
-    const float alpha = sigmoidf_(q[3]);
-    const float W = (float)w, H = (float)h;
-    sigmas[i * 3 + 0] = sy / step * 2.f / (W - 1.f);     // kernel's first sigma pairs with WIDTH (:121)
-    sigmas[i * 3 + 1] = sx / step * 2.f / (H - 1.f);
-    sigmas[i * 3 + 2] = rho;
-    const float c0 = q[7] * 2.f - 1.f, c1 = q[8] * 2.f - 1.f;
-    coords[i * 2 + 0] = (c0 + 1.f - 1.f / W) * W / (W - 1.f) - 1.f;   // align_corners=False -> True (:122-123)
-    coords[i * 2 + 1] = (c1 + 1.f - 1.f / H) * H / (H - 1.f) - 1.f;
-    colors[i * 3 + 0] = sigmoidf_(q[4]) * alpha;
-    colors[i * 3 + 1] = sigmoidf_(q[5]) * alpha;
-    colors[i * 3 + 2] = sigmoidf_(q[6]) * alpha;
+    float o[8];
+    prologue_one(p + (size_t)i * 9, step_ptr[geo ? i / nper : 0], h, w, o);
+    sigmas[i * 3 + 0] = o[0]; sigmas[i * 3 + 1] = o[1]; sigmas[i * 3 + 2] = o[2];
+    coords[i * 2 + 0] = o[3]; coords[i * 2 + 1] = o[4];
+    colors[i * 3 + 0] = o[5]; colors[i * 3 + 1] = o[6]; colors[i * 3 + 2] = o[7];
 }
 
 // chain rule of k_prologue_fwd for one Gaussian: q = its raw parameters, gs/gc/gk = d/d{sigmas, coords, colors}
@@ -2465,6 +2492,30 @@ __global__ __launch_bounds__(256) void k_prologue_bwd_gather(Params P, PlanView 
         step = step_ptr[i / (unsigned)P.nper];
     }
     prologue_chain(p + (size_t)i * 9, step, h, w, o[2], o[3], o[4], o[0], o[1], o[5], o[6], o[7], gp + (size_t)i * 9);
+}
+
+// planar [3, rows, w] (batched canvas: [B, 3, grad_rows, w], sample b's rows at the top of its planes) -> interleaved
+// [rows, w, 3] / [B * slot, w, 3]: what autograd hands back for the planar image -> what k_render_bwd sweeps.  One
+// thread per pixel: three coalesced plane reads, one 12-byte store.  Rows of a slot beyond grad_rows are left alone:
+// the backward never reads outside a sample's own grid.
+__global__ __launch_bounds__(256) void k_chw_to_hwc(const float *__restrict__ src, float *__restrict__ dst, int w, int rows,
+                                                    int batch, int slot, int grad_rows)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int X = (int)(i % (size_t)w);
+    const size_t Y = i / (size_t)w;
+    if (Y >= (size_t)rows) return;
+    size_t plane = (size_t)rows * w, at = Y * w + X;
+    if (batch > 1) {
+        const int b = (int)(Y / (size_t)slot), y = (int)(Y - (size_t)b * slot);
+        if (y >= grad_rows) return;
+        plane = (size_t)grad_rows * w;
+        at = (size_t)b * 3 * plane + (size_t)y * w + X;
+    }
+    float *o = dst + (Y * w + X) * 3;
+    o[0] = src[at];
+    o[1] = src[at + plane];
+    o[2] = src[at + 2 * plane];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2594,19 +2645,30 @@ size_t gsasr_splat_workspace_bytes(const gsasr_dims *dims)
     return make_layout(dims).total;
 }
 
-int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colors, const gsasr_dims *dims,
-                     void *workspace, size_t workspace_bytes, void *stream)
+}  // extern "C"
+
+namespace {
+// The plan: [memset of this parity's counters unless the caller vouches for them] -> classify (with the host prologue
+// fused in when `raw` is given: sigmas/coords/colors are then OUTPUTS) -> [scan] -> bin.
+int plan_impl(const float *sigmas, const float *coords, const float *colors, const gsasr_dims *dims, void *workspace,
+              size_t workspace_bytes, void *stream, const float *raw, const float *step_size)
 {
     Layout L;
     if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
     if (dims->s > 0 && (!sigmas || !coords || !colors)) return fail(GSASR_ERR_ARG, "null input pointer");
     hipStream_t st = (hipStream_t)stream;
     const Params P = make_params(dims, L);
-    const PlanView V = make_view(L, workspace);
-    HIP_TRY(hipMemsetAsync(workspace, 0, L.zero_bytes, st));
-    if (int rc = launch_batch_geo(dims, V, st)) return rc;
+    const PlanView V = make_view(L, workspace, dims->flags);
+    if (!(dims->flags & GSASR_FLAG_COUNTERS_CLEAN)) HIP_TRY(hipMemsetAsync(V.cell_count, 0, L.count_bytes, st));
+    if (!raw)
+        if (int rc = launch_batch_geo(dims, V, st)) return rc;   // (a step call has published the geometry already)
     const int nblk = classify_blocks(dims);
-    hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V);
+    if (raw)
+        hipLaunchKernelGGL(k_classify<true>, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V, raw, step_size,
+                           const_cast<float *>(sigmas), const_cast<float *>(coords), const_cast<float *>(colors));
+    else
+        hipLaunchKernelGGL(k_classify<false>, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V, (const float *)nullptr,
+                           (const float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
     const int ncls = L.ncells + 2;
     const unsigned nbin = (unsigned)((dims->s + 255) / 256);
     if (ncls <= FUSED_CELLS && dims->s > 0) {
@@ -2627,6 +2689,15 @@ int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colo
     }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colors, const gsasr_dims *dims,
+                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    return plan_impl(sigmas, coords, colors, dims, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, float *img,
@@ -2795,7 +2866,7 @@ int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, 
 // ---- whole-step entry points ----------------------------------------------------------------------
 namespace {
 struct StepLayout {
-    size_t plan_bytes, off_sig, off_xy, off_col, off_gsig, off_gxy, off_gcol, total;
+    size_t plan_bytes, off_sig, off_xy, off_col, off_gsig, off_gxy, off_gcol, off_ghwc, total;
 };
 StepLayout make_step_layout(const gsasr_dims *d)
 {
@@ -2809,6 +2880,11 @@ StepLayout make_step_layout(const gsasr_dims *d)
     S.off_gsig = o; o += align_up(n * 12, 256);
     S.off_gxy = o;  o += align_up(n * 8, 256);
     S.off_gcol = o; o += align_up(n * 12, 256);
+    // a planar upstream gradient (GSASR_FLAG_CHW_GRAD) in front of the Gaussian-stationary backward is interleaved into
+    // this scratch by k_chw_to_hwc (the tile-stationary backward stages the planes directly and needs none)
+    S.off_ghwc = o;
+    if ((d->flags & GSASR_FLAG_CHW_GRAD) && !(d->flags & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC | GSASR_FLAG_FORWARD_ONLY)))
+        o += align_up((size_t)(d->row1 - d->row0) * (size_t)d->w * 12, 256);
     S.total = o;
     return S;
 }
@@ -2835,19 +2911,13 @@ int step_prologue_plan(const float *gs_parameters, const float *step_size, const
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
     char *b = (char *)workspace;
     float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
-    if (dims->batch > 1) {  // the geometry must be in place before the prologue reads it
-        if (dims->s > 0) {
-            if (!gs_parameters || !step_size) return fail(GSASR_ERR_ARG, "null pointer");
-            const PlanView V = make_view(make_layout(dims), workspace);
-            if (int rc = launch_batch_geo(dims, V, (hipStream_t)stream)) return rc;
-            hipLaunchKernelGGL(k_prologue_fwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                               gs_parameters, step_size, dims->s, 0, 0, sig, xy, col, dims->s / dims->batch,
-                               (const int4 *)V.geo);
-            HIP_TRY(hipGetLastError());
-        }
-    } else if (int rc = gsasr_prologue_forward(gs_parameters, step_size, dims->s, dims->h, dims->w, sig, xy, col, stream))
-        return rc;
-    return gsasr_splat_plan(sig, xy, col, dims, workspace, S.plan_bytes, stream);
+    if (dims->s > 0 && (!gs_parameters || !step_size)) return fail(GSASR_ERR_ARG, "null pointer");
+    if (dims->batch > 1 && dims->s > 0) {  // the per-sample geometry must be in place before the classify kernel reads it
+        const PlanView V = make_view(make_layout(dims), workspace, dims->flags);
+        if (int rc = launch_batch_geo(dims, V, (hipStream_t)stream)) return rc;
+    }
+    // (the prologue runs inside the plan's first kernel: k_classify<true>)
+    return plan_impl(sig, xy, col, dims, workspace, S.plan_bytes, stream, dims->s > 0 ? gs_parameters : nullptr, step_size);
 }
 }  // namespace
 
@@ -2873,6 +2943,19 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
     float *gs = (float *)(b + S.off_gsig), *gc = (float *)(b + S.off_gxy), *gk = (float *)(b + S.off_gcol);
     gsasr_dims d = *dims;
     d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
+    if ((d.flags & GSASR_FLAG_CHW_GRAD) && S.total > S.off_ghwc && dims->s > 0 && d.row1 > d.row0) {
+        // Gaussian-stationary kernel behind a planar gradient: interleave it into the scratch first
+        if (!grad_img) return fail(GSASR_ERR_ARG, "null pointer");
+        float *hwc = (float *)(b + S.off_ghwc);
+        const int rows = d.row1 - d.row0;
+        const size_t px = (size_t)rows * d.w;
+        hipLaunchKernelGGL(k_chw_to_hwc, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_img, hwc,
+                           d.w, rows, batch_of(&d), d.batch > 1 ? d.slot : rows, d.grad_rows > 0 ? d.grad_rows : (d.batch > 1 ? d.slot : rows));
+        HIP_TRY(hipGetLastError());
+        grad_img = hwc;
+        d.flags &= ~GSASR_FLAG_CHW_GRAD;
+        d.flags |= GSASR_FLAG_BWD_GAUSSIAN;
+    }
     int mode = 0;
     if (int rc = splat_backward(sig, xy, col, grad_img, gs, gc, gk, &d, workspace, S.plan_bytes, stream, false, &mode)) return rc;
     if (dims->s == 0) return GSASR_OK;

@@ -91,11 +91,14 @@ class _FusedStep(torch.autograd.Function):
     @fp32_boundary_fwd
     def forward(ctx, gs_parameters, step, H, W, dmax):
         from . import _cabi
+        # the planar gradient autograd hands back goes to the C call as it is (GSASR_FLAG_CHW_GRAD): the
+        # tile-stationary backward stages the planes directly, the Gaussian-stationary one behind one interleaving
+        # kernel inside the same call -- no torch permute / allocation on the host path either way
         tile = _tile_backward(H * W, gs_parameters.shape[0])
-        flags = (_cabi.FLAG_BWD_TILE if tile else 0) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
+        flags = (_cabi.FLAG_CHW_GRAD | (_cabi.FLAG_BWD_TILE if tile else 0)) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
         img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax, flags)   # one C call: prologue + plan + splat
         ctx.save_for_backward(gs_parameters, step)
-        ctx.plan, ctx.tile = plan, tile
+        ctx.plan = plan
         return img
 
     @staticmethod
@@ -104,10 +107,7 @@ class _FusedStep(torch.autograd.Function):
     def backward(ctx, grad_output):
         from . import _cabi
         gs_parameters, step = ctx.saved_tensors
-        if ctx.tile:   # the tile-stationary backward stages the planar gradient as it is
-            return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_output.contiguous(), chw=True), None, None, None, None
-        grad_hwc = grad_output.permute(1, 2, 0).contiguous()   # the Gaussian-stationary kernel sweeps 12-byte HWC pixels
-        return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_hwc), None, None, None, None
+        return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_output.contiguous(), chw=True), None, None, None, None
 
 
 class _FusedStepSampled(torch.autograd.Function):
@@ -180,10 +180,21 @@ def _fused_ok(gs_parameters) -> bool:
         and gs_parameters.shape[1] == 9
 
 
+_STEP_TENSORS = {}      # (value, device) -> [1] float32 device tensor of a python-number step size (read-only)
+
+
 def _step_tensor(step_size, dev):
     if torch.is_tensor(step_size):
         return step_size.detach().to(device=dev, dtype=torch.float32).reshape(1)   # stays on the device: no sync
-    return torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
+    key = (float(step_size), dev)
+    t = _STEP_TENSORS.get(key)
+    if t is None or torch.cuda.is_current_stream_capturing():
+        t = torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
+        if not torch.cuda.is_current_stream_capturing():
+            if len(_STEP_TENSORS) > 256:
+                _STEP_TENSORS.clear()
+            _STEP_TENSORS[key] = t
+    return t
 
 
 def _fused_render(gs_parameters, sr_size, step_size, dmax):
@@ -272,11 +283,59 @@ def rendering_python(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size,
     return final_image
 
 
+class _DeferredAsserts:
+    """The reference asserts `scale_modify[0] == scale_modify[1]` on every call (:169), which for a CUDA tensor is a
+    device-to-host synchronisation per call -- sixteen per training step in the reference's per-sample loop.  For
+    CUDA tensors the comparison is evaluated on the device, its result copied to pinned host memory without
+    blocking, and examined at a LATER call of the API (or by `flush()`), once the copy has landed: the same
+    AssertionError, at most a few calls late, and no pipeline drain.  Python numbers and CPU tensors are checked
+    on the spot, exactly as in the reference."""
+
+    RING = 256          # pinned result slots, reused round robin (allocating pinned memory per call costs more than the check)
+
+    def __init__(self):
+        self.pending = []
+        self.ring = None
+        self.next = 0
+
+    def add(self, ok: torch.Tensor, message: str) -> None:
+        if self.ring is None:
+            self.ring = torch.empty(self.RING, dtype=torch.bool, pin_memory=True)
+        if len(self.pending) >= self.RING:      # every slot in flight: wait for the oldest
+            self.poll_one(wait=True)
+        host = self.ring[self.next: self.next + 1]
+        self.next = (self.next + 1) % self.RING
+        host.copy_(ok.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ok.device))
+        self.pending.append((ev, host, message))
+        self.poll()
+
+    def poll_one(self, wait: bool) -> None:
+        ev, host, message = self.pending.pop(0)
+        if wait:
+            ev.synchronize()
+        assert bool(host[0]), message
+
+    def poll(self, wait: bool = False) -> None:
+        while self.pending and (wait or self.pending[0][0].query()):
+            self.poll_one(wait)
+
+    def flush(self) -> None:
+        self.poll(wait=True)
+
+
+deferred_asserts = _DeferredAsserts()
+
+
 def _step_size(scale, scale_modify, default_step_size, mode):
     if mode == 'scale':
         final_scale = scale
     elif mode == 'scale_modify':
-        assert scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify}"
+        if torch.is_tensor(scale_modify) and scale_modify.is_cuda and not torch.cuda.is_current_stream_capturing():
+            deferred_asserts.add(scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify.shape}")
+        elif not (torch.is_tensor(scale_modify) and scale_modify.is_cuda):
+            assert scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify}"
         final_scale = scale_modify[0]
     else:  # the reference leaves final_scale unbound here (UnboundLocalError, a NameError subclass)
         raise UnboundLocalError(f"mode-{mode} must be scale or scale_modify")
@@ -360,10 +419,10 @@ class _FusedBatch(torch.autograd.Function):
     def forward(ctx, gs_parameters, steps, sizes, dmax):
         from . import _cabi
         tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1])
-        flags = (_cabi.FLAG_BWD_TILE if tile else 0) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
+        flags = (_cabi.FLAG_CHW_GRAD | (_cabi.FLAG_BWD_TILE if tile else 0)) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
         img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax, flags)
         ctx.save_for_backward(gs_parameters, steps)
-        ctx.plan, ctx.tile = plan, tile
+        ctx.plan = plan
         ctx.h_max = max(h for h, _ in sizes)
         return img[:, :, : ctx.h_max]          # the slot is h_max rounded up to whole 16-row tiles
 
@@ -373,12 +432,8 @@ class _FusedBatch(torch.autograd.Function):
     def backward(ctx, grad_output):
         from . import _cabi
         gs_parameters, steps = ctx.saved_tensors
-        d = ctx.plan.dims
-        if ctx.tile:   # [B,3,Hmax,Wmax] read in place: rows per plane = Hmax, pixels outside a sample's own grid never read
-            return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad_output.contiguous(), chw=True), None, None, None
-        grad = grad_output.new_zeros(d.batch, d.slot, d.w, 3)      # [B, slot, Wmax, 3]: what the backward sweeps
-        grad[:, : ctx.h_max] = grad_output.permute(0, 2, 3, 1)
-        return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad), None, None, None
+        # [B,3,Hmax,Wmax] read in place (rows per plane = Hmax <= slot): pixels outside a sample's own grid are never read
+        return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad_output.contiguous(), chw=True), None, None, None
 
 
 def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
@@ -392,8 +447,14 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
     if mode == 'scale':
         final = col(list(scales))
     elif mode == 'scale_modify':
-        a, b = col([sm[0] for sm in scale_modifies]), col([sm[1] for sm in scale_modifies])
-        assert bool((a == b).all()), f"scale_modify is not the same-{scale_modifies}"
+        if all(torch.is_tensor(sm) and sm.is_cuda for sm in scale_modifies):
+            both = torch.stack([sm.reshape(-1)[:2] for sm in scale_modifies]).to(device=dev, dtype=torch.float32)   # [B,2], one kernel
+            a, b = both[:, 0], both[:, 1]
+            if not torch.cuda.is_current_stream_capturing():      # the reference's assert, without draining the pipeline
+                deferred_asserts.add((a == b).all(), "scale_modify is not the same (batched step)")
+        else:
+            a, b = col([sm[0] for sm in scale_modifies]), col([sm[1] for sm in scale_modifies])
+            assert bool((a == b).all()), f"scale_modify is not the same-{scale_modifies}"
         final = a
     else:
         raise UnboundLocalError(f"mode-{mode} must be scale or scale_modify")

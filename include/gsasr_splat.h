@@ -78,6 +78,13 @@ enum gsasr_status {
                                          on a plan without slots accumulates with fp32 atomics instead (slower) */
 #define GSASR_FLAG_BWD_ATOMIC 512u    /* tile-stationary with ONE fp32 atomic set per (tile, Gaussian) instead of the
                                          slots (the measured alternative of DESIGN.md 3c; order-dependent rounding)  */
+#define GSASR_FLAG_COUNTERS_CLEAN 1024u /* plan: the caller keeps this workspace between plans and promises that the
+                                         per-cell counters of the parity given by GSASR_FLAG_PARITY are zero: the plan
+                                         skips its memset launch.  Every plan zeroes the OTHER parity's counters on the
+                                         side (in its first kernel), so a workspace that was used with parity p is clean
+                                         for parity 1-p: alternate the bit plan by plan.  (First use of a workspace: leave
+                                         CLEAN off.) */
+#define GSASR_FLAG_PARITY 2048u        /* which of the two counter arrays this plan counts in */
 
 typedef struct gsasr_dims {
     int s;        /* number of Gaussians                                              */
