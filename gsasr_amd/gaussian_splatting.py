@@ -75,9 +75,14 @@ BACKWARD_KERNEL = "auto"
 
 
 def _tile_backward(n_pixels: int, n_gaussians: int) -> bool:
+    """Measured through this API on MI355X (tools/e2e_modes.py, profiles/r02_e2e_modes.txt): with >= 4 HR pixels per
+    Gaussian (one Gaussian per LR pixel at x2 and up) the tile-stationary backward is level or ahead end to end -- it reads
+    the planar gradient in place, where the Gaussian-stationary kernel needs it interleaved first -- and it is
+    deterministic; at 16 Gaussians per LR pixel (the training crops: ~1 pixel per Gaussian) a tile holds thousands of
+    Gaussians and the Gaussian-stationary kernel is 15-50% faster.  Small images have too few tiles to fill the chip."""
     if BACKWARD_KERNEL != "auto":
         return BACKWARD_KERNEL == "tile"
-    return False
+    return n_pixels >= 4 * n_gaussians and n_pixels >= 128 * 1024
 
 
 class _FusedStep(torch.autograd.Function):
