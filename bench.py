@@ -43,6 +43,10 @@ CONFIGS = {
     # the same batch trained on `sample_coords` (sample_size = 2304 = 48^2 of the 192^2 pixels per sample): only those
     # pixels are evaluated; value = SAMPLED pixels per second
     "c5s": (48, 48, 4.0, "config5 rasterizer with sample_coords: batch 16 x (36864 Gaussians, 2304 of 192^2 pixels), prologue+fwd+bwd, sampled-pixel kernels"),
+    # BASELINE config 5 as stated: the END-TO-END training step -- EDSR-baseline-shaped encoder + Fea2GS-shaped producer
+    # (tools/c5_models.py) -> batched HIP splat -> per-sample crop -> L1 -> backward through the rasterizer -> Adam step
+    "c5e2e": (48, 48, 4.0, "config5 end-to-end training step: EDSR-baseline-shaped encoder + Fea2GS-shaped producer -> HIP splat "
+                           "(batch 16 x 48x48 LR crops x4, 16 Gaussians/LR px, dmax 0.5) -> L1 -> backward -> Adam"),
 }
 
 
@@ -445,6 +449,102 @@ def cpu_baseline(args):
     return out
 
 
+def run_c5e2e(args, dev, rank, world):
+    """BASELINE.json config 5 end to end.  One step = reference
+    `optimize_parameters` (TrainTestGSASR/basicsr/models/gsasr_model.py:175-245) with this package's batched rasterizer.
+    N > 1: independent replicas (one batch per rank, no collective: the rasterizer path itself does not shard here)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import c5_models
+    from gsasr_amd import gaussian_splatting as gsp
+    h_lr, w_lr, scale, desc = CONFIGS["c5e2e"]
+    B, H, W = 16, int(h_lr * scale), int(w_lr * scale)
+    torch.manual_seed(1234 + rank)
+    enc, dec = c5_models.EncoderEDSRShaped().to(dev), c5_models.Fea2GSShaped().to(dev)
+    opt = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=2e-4)
+    lq, gt = torch.rand(B, 3, h_lr, w_lr, device=dev), torch.rand(B, 3, H, W, device=dev)
+    sizes, scales = [(H, W)] * B, [scale] * B
+    dmax = 0.5 if args.dmax == 0.1 else args.dmax
+
+    def step():
+        return c5_models.training_step(enc, dec, opt, lq, gt, sizes, scales, batched=True, dmax=dmax)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, params = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    # the rasterizer's share: the same batched splat forward + backward alone, on the decoder's last output
+    pd = params.detach()
+    g = torch.rand(B, 3, H, W, device=dev)
+    sms = [(scale, scale)] * B
+
+    def raster():
+        pa = pd.requires_grad_(True)
+        gsp.generate_2D_gaussian_splatting_batch(sizes, pa, scales, sms, dmax=dmax).backward(g)
+        pa.grad = None
+
+    ms_raster = wall_ms(raster, 20, dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for a, b in evs:
+        a.record()
+        raster()
+        b.record()
+    torch.cuda.synchronize(dev)
+    dev_raster = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+    n_params = sum(p.numel() for p in list(enc.parameters()) + list(dec.parameters()))
+    if rank != 0:
+        return
+    out = {"metric": "HR Mpixels/sec, end-to-end training step (x4, 16 Gaussians/LR px, batch 16, L1, Adam)",
+           "value": world * B * H * W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s", "n_gpus": world, "steps": args.steps,
+           "warmup": max(args.warmup, 3), "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": desc, "batch": B, "lr": [h_lr, w_lr], "H": H, "W": W, "gaussians_per_sample": 16 * h_lr * w_lr,
+                      "dmax": dmax, "producer_parameters": n_params, "loss": float(loss),
+                      "parallelism": f"independent replicas x{world}" if world > 1 else "single",
+                      "producers": "tools/c5_models.py: EDSR-baseline-shaped encoder (16 res blocks, 64 ch) + Fea2GS-SHAPED "
+                                   "convolutional stand-in (same interface / layout / ordering; not the reference's attention decoder)"},
+           "rasterizer": {"ms_fwd_bwd_wall": ms_raster, "ms_fwd_bwd_device": dev_raster, "share_of_step": dev_raster / ms,
+                          "note": "generate_2D_gaussian_splatting_batch forward + backward alone on the decoder's output "
+                                  "(prologue + plan + splat, splat backward + chain rule), events on the launch stream"}}
+    if world == 1 and not args.no_cpu_baseline:
+        # one SAMPLE of the same step on the host cores with the oracle as the rasterizer back end (SURVEY.md 8(d) row C5)
+        from oracle import gs_oracle, host_ref
+        cores = gs_oracle.num_threads()
+        torch.set_num_threads(cores)
+        enc_c, dec_c = c5_models.EncoderEDSRShaped(), c5_models.Fea2GSShaped()
+        enc_c.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+        dec_c.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+        x, y = lq[:1].cpu(), gt[:1].cpu()
+        t0 = time.perf_counter()
+        p1 = dec_c(enc_c(x), torch.tensor([scale]))[0]
+        sig, xy, col, _ = host_ref.prologue(p1, (H, W), torch.tensor([scale, scale]), dmax=dmax)
+        img = torch.from_numpy(gs_oracle.forward_f32(sig.detach().numpy(), xy.detach().numpy(), col.detach().numpy(), H, W, dmax))
+        grad = torch.sign(img.permute(2, 0, 1)[None] - y) / img.numel()          # d L1 / d image
+        gk = gs_oracle.backward_f32(sig.detach().numpy(), xy.detach().numpy(), col.detach().numpy(),
+                                    grad[0].permute(1, 2, 0).contiguous().numpy(), dmax)
+        torch.autograd.backward([sig, xy, col], [torch.from_numpy(a) for a in gk])
+        t1 = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": H * W / t1 / 1e6, "unit": "HR Mpixels/s", "cores": cores, "logical_cpus": os.cpu_count(),
+                               "kind": "port", "sample": f"ONE sample of the step (encoder + producer in torch on the CPU, oracle/gs_ref.c "
+                               f"fp32 restatement of gs_cuda_dmax forward + backward, autograd to the producers; no optimizer step): {t1:.2f} s"}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -459,6 +559,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    if args.config == "c5e2e":
+        run_c5e2e(args, dev, rank, world)
+        if world > 1 or args.force_dist:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
 
     step = Step(args, dev, rank, world)
 
