@@ -183,11 +183,25 @@ int bwd_env()
 // below, 16 the larger scales; a Gaussian whose window spans more tiles than it has slots adds into `sums` with
 // fp32 atomics instead (any input stays correct).  The window sizes live on the device, so the host picks by HR pixels
 // per Gaussian, as for the Gaussian-stationary kernel's unrolling.
+// Does this plan carry slots, i.e. will its backward be the tile-stationary kernel?  Explicitly (GSASR_FLAG_BWD_TILE),
+// or by default where it is the faster one on this chip: measured the two backward kernels are level at
+// GSASR's x4 (one Gaussian per 16 HR pixels; the Gaussian-stationary one 10% ahead), and the tile-stationary one wins
+// from ~32 pixels per Gaussian up (x8: -7%), where a window holds enough quadrants to amortise the per-tile search.
+bool bwd_wants_tile(const gsasr_dims *d)
+{
+    if (d->flags & (GSASR_FLAG_FORWARD_ONLY | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_ATOMIC)) return false;
+    if ((d->flags & GSASR_FLAG_BWD_TILE) || bwd_env() == 2) return true;
+    if (bwd_env() != 0 || d->batch > 1) return false;
+    // (a row band of a sharded image plans ALL the Gaussians for its rows: the density that matters is the whole grid's)
+    const double px_per_gaussian = (double)d->h * (double)d->w / (double)(d->s > 0 ? d->s : 1);
+    return px_per_gaussian >= 32.0 && (double)(d->row1 - d->row0) * (double)d->w >= 524288.0;
+}
+
 int bwd_part_k(const gsasr_dims *d)
 {
     // only plans made for the tile-stationary backward carry slots (32 * part_k bytes per Gaussian)
-    if ((d->flags & GSASR_FLAG_FORWARD_ONLY) || !((d->flags & GSASR_FLAG_BWD_TILE) || bwd_env() == 2)) return 0;
-    const double px_per_gaussian = (double)(d->row1 - d->row0) * (double)d->w / (double)(d->s > 0 ? d->s : 1);
+    if (!bwd_wants_tile(d)) return 0;
+    const double px_per_gaussian = (double)d->h * (double)d->w / (double)(d->s > 0 ? d->s : 1);
     return px_per_gaussian >= 32.0 ? 16 : 8;
 }
 
@@ -677,7 +691,11 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
             // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
             const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
+#ifdef GSASR_DEV_NO_SPANS     // (development: how much of k_bin's run time is the span computation)
+            if (false) {
+#else
             if (P.kcut > 0.f && ty1 - ty0 < 8 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
+#endif
                 // (fp32 relative to the centre: the plan runs one wave per SIMD, so the length of this dependent
                 // chain is k_bin's run time; an ulp of a <= 128 px offset is far inside WINDOW_EPS.  Only the absolute
                 // pixel coordinates stay in double.)
@@ -721,7 +739,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 spans(SUBY_SHIFT, ty0, ty1 - ty0 + 1, lo4, hi4);
                 // the same per band of 8 rows, for the 8x8-px quadrants of the tile-stationary backward
                 const int q0 = (b.r0 - P.row0) >> 3, q1 = (b.r1 - P.row0) >> 3;
-                if ((P.flags & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)) && V.qspan && q1 - q0 < 8) {
+                if (V.qspan && q1 - q0 < 8) {   // (plans with slots only: the others never run the tile-stationary backward)
                     unsigned l8[2] = {0u, 0u}, h8[2] = {0u, 0u};
                     spans(3, q0, q1 - q0 + 1, l8, h8);
                     qs = make_uint4(l8[0], h8[0], l8[1], h8[1]);
@@ -2747,12 +2765,12 @@ namespace {
 // mode: 0 = Gaussian-stationary, 1 = tile-stationary with slots, 2 = tile-stationary with atomics
 int bwd_mode(const gsasr_dims *dims, const Layout &L)
 {
-    // Default: Gaussian-stationary.  Measured on MI355X the two kernels are within a few percent of each
-    // other at every scale -- both are bound by VALU issue -- and the Gaussian-stationary one is ahead for GSASR's LR-pixel
-    // sized Gaussians (x4: 38 vs 47 us at config 2); the tile-stationary one is deterministic and reads the planar
-    // gradient autograd returns, which is worth more than that to a caller who would otherwise permute it.
+    // Default: whatever the plan was made for (bwd_wants_tile).  Measured on MI355X the two kernels are
+    // within ~10% of each other at every scale -- both are bound by VALU issue: Gaussian-stationary ahead for GSASR's
+    // LR-pixel sized Gaussians at x4 (38.4 vs 38.8 + 5.0 us gather at config 2), tile-stationary ahead from x8 up
+    // (config 4: 1.67 vs 1.79 ms); the tile-stationary one is deterministic and reads the planar gradient autograd returns.
     const unsigned f = dims->flags;
-    int mode = 0;
+    int mode = L.part_k > 0 ? 1 : 0;      // a plan with slots was made for the tile-stationary kernel (bwd_wants_tile)
     if (f & GSASR_FLAG_BWD_GAUSSIAN) mode = 0;
     else if (f & GSASR_FLAG_BWD_ATOMIC) mode = 2;
     else if (f & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_CHW_GRAD)) mode = 1;
