@@ -392,7 +392,27 @@ def dropin_run(args, dev):
         img.backward(wgt)
 
     ms = wall_ms(step, 30, dev, warm=5)
+    # ... and the pybind-shaped module underneath it (`gscuda.gs_render` / `gs_render_backward`, reference
+    # gswrapper.cpp:9-73 -> the C launchers gsasr_gs_render_dmax / _backward_dmax: scratch allocated stream-ordered and the
+    # Gaussians binned in BOTH calls, as a maintainer who rebinds only the two launchers would get it)
+    from gsasr_amd import gscuda
+    ad, bd, cd = a.detach(), b.detach(), c.detach()
+    g = [torch.zeros_like(t) for t in (ad, bd, cd)]
+
+    def launchers():
+        z = torch.zeros(H, W, 3, device=dev)
+        for t in g:
+            t.zero_()
+        if dmax is None:
+            gscuda.gs_render(ad, bd, cd, z, ad.shape[0], H, W, 3)
+            gscuda.gs_render_backward(ad, bd, cd, wgt, *g, ad.shape[0], H, W, 3)
+        else:
+            gscuda.gs_render(ad, bd, cd, z, ad.shape[0], H, W, 3, dmax)
+            gscuda.gs_render_backward(ad, bd, cd, wgt, *g, ad.shape[0], H, W, 3, dmax)
+
+    ms_l = wall_ms(launchers, 30, dev, warm=5)
     return {"ms_per_step": ms, "value": H * W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+            "launchers_ms_per_step": ms_l, "launchers_value": H * W / (ms_l * 1e-3) / 1e6,
             "what": "GSCUDA.apply(sigmas, coords, colors, torch.zeros(H,W,3)[, dmax]) + .backward(grad) through torch autograd, "
                     "wall clock incl. host launch overhead, allocations and the accumulate-into (+=) image"}
 

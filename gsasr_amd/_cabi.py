@@ -166,26 +166,42 @@ class _WorkspacePool:
     """Workspaces of the step entry points, kept between calls so that a plan can skip its counter memset: every plan
     zeroes the per-cell counters of the OTHER parity on the side (GSASR_FLAG_COUNTERS_CLEAN / GSASR_FLAG_PARITY), so a
     workspace that comes back from a finished step is clean for the flipped parity.  Keyed by (device, stream, size):
-    reuse is ordered by the stream, exactly like the caching allocator's own reuse."""
-    KEEP = 4          # free workspaces kept per key (forward and backward of a few steps in flight)
+    reuse is ordered by the stream, exactly like the caching allocator's own reuse.  Bounded: a few workspaces per
+    key, MAX_BYTES in all (least recently used keys go first -- training on ragged sizes meets many sizes)."""
+    KEEP = 4                    # free workspaces kept per key (forward and backward of a few steps in flight)
+    MAX_BYTES = 2 << 30
 
     def __init__(self):
-        self.free = {}
+        self.free = {}          # key -> [(tensor, parity)]; dict order = least recently used first
+        self.bytes = 0
 
     def take(self, key, nbytes, dev):
         lst = self.free.get(key)
         if lst:
             ws, parity = lst.pop()
+            self.bytes -= ws.numel()
+            if lst:
+                self.free[key] = self.free.pop(key)     # most recently used
+            else:
+                del self.free[key]
             return ws, parity, True
         return torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False
 
     def give(self, key, ws, parity):
-        lst = self.free.setdefault(key, [])
-        if len(lst) < self.KEEP:
+        lst = self.free.pop(key, [])
+        if len(lst) < self.KEEP and ws.numel() <= self.MAX_BYTES:
             lst.append((ws, parity))
+            self.bytes += ws.numel()
+        if lst:
+            self.free[key] = lst
+        while self.bytes > self.MAX_BYTES and self.free:
+            old = next(iter(self.free))
+            for t, _ in self.free.pop(old):
+                self.bytes -= t.numel()
 
     def clear(self):
         self.free.clear()
+        self.bytes = 0
 
 
 _POOL = _WorkspacePool()

@@ -253,3 +253,35 @@ def test_config2_full_size_tile_backward_against_oracle(dev):
     ref = _backward(s, c, k, g, H, W, 0.1, dev, _flags()["gaussian"])
     for a, b, name in zip(full, ref, ("sigmas", "coords", "colors")):
         per_gaussian_ok(a, b, name, rho=s[:, 2])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSASR_FUZZ_SEEDS", "12"))))   # more seeds: set the variable
+def test_fuzz_extreme_parameters_tile_backward(seed, dev):
+    """the fuzz of test_hip_parity.py::test_fuzz_extreme_parameters for the tile-stationary backward: random sizes and
+    parameter ranges far outside what the decoder emits -- sigma over five decades, |rho| up to 0.9995, centres far off
+    the image, dmax from sub-pixel to larger than the image, all three cutoff modes"""
+    from oracle import gs_oracle
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(2, 90)), int(rng.integers(2, 90))
+    s = int(rng.integers(1, 400))
+    sig = np.stack([10 ** rng.uniform(-4, 0.7, s), 10 ** rng.uniform(-4, 0.7, s),
+                    np.clip(rng.normal(0, 0.6, s), -0.9995, 0.9995)], 1).astype(np.float32)
+    xy = rng.uniform(-1.6, 1.6, (s, 2)).astype(np.float32)
+    col = rng.uniform(0, 1, (s, 3)).astype(np.float32)
+    wgt = rng.uniform(-1, 1, (h, w, 3)).astype(np.float32)
+    dmax = [None, float(10 ** rng.uniform(-2.5, 0.5))][seed % 2]
+    cutoff = [0.0, 104.0, -1.0][seed % 3]
+    grads = _backward(sig, xy, col, wgt, h, w, dmax, dev, _flags()["tile"], cutoff=cutoff)
+    gref = gs_oracle.backward_f64(sig, xy, col, wgt, dmax)
+    g32 = gs_oracle.backward_f32(sig, xy, col, wgt, dmax, use_fma=True)   # the reference's own fp32 arithmetic
+    for got, want, r32, name in zip(grads, gref, g32, ("sigmas", "coords", "colors")):
+        assert np.isfinite(got).all(), name
+        # (criterion of the Gaussian-stationary fuzz: per Gaussian, relative to that Gaussian's own gradient magnitude,
+        # never demanding more than twice the accuracy the reference arithmetic itself achieves)
+        tol = (5e-4 * np.abs(want).max(axis=1, keepdims=True) + 2.0 * np.abs(r32 - want) + 1e-5 * np.abs(want).max() + 1e-6)
+        err = np.abs(got - want)
+        assert err.max() <= GRAD_RTOL * np.abs(want).max() + 1e-30, name
+        well = (1.0 - sig[:, 2].astype(np.float64) ** 2) >= 0.02
+        bad = (err > tol) & well[:, None]
+        assert not bad.any(), (name, int(np.argwhere(bad)[0][0]), float(err[bad].max()), float(np.abs(want).max()),
+                               sig[np.argwhere(bad)[0][0]].tolist())
