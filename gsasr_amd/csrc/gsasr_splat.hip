@@ -191,10 +191,11 @@ bool bwd_wants_tile(const gsasr_dims *d)
 {
     if (d->flags & (GSASR_FLAG_FORWARD_ONLY | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_ATOMIC)) return false;
     if ((d->flags & GSASR_FLAG_BWD_TILE) || bwd_env() == 2) return true;
-    if (bwd_env() != 0 || d->batch > 1) return false;
-    // (a row band of a sharded image plans ALL the Gaussians for its rows: the density that matters is the whole grid's)
+    // (by default only for whole images: a row band of a sharded image may hold all the Gaussians or just its own, so
+    // its pixels per Gaussian say nothing about the window size -- the shard's caller knows the scale and sets the flag)
+    if (bwd_env() != 0 || d->batch > 1 || d->row0 != 0 || d->row1 != d->h) return false;
     const double px_per_gaussian = (double)d->h * (double)d->w / (double)(d->s > 0 ? d->s : 1);
-    return px_per_gaussian >= 32.0 && (double)(d->row1 - d->row0) * (double)d->w >= 524288.0;
+    return px_per_gaussian >= 32.0 && (double)d->h * (double)d->w >= 524288.0;
 }
 
 int bwd_part_k(const gsasr_dims *d)
