@@ -692,11 +692,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
             // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
             const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
-#ifdef GSASR_DEV_NO_SPANS     // (development: how much of k_bin's run time is the span computation)
-            if (false) {
-#else
             if (P.kcut > 0.f && ty1 - ty0 < 8 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
-#endif
                 // (fp32 relative to the centre: the plan runs one wave per SIMD, so the length of this dependent
                 // chain is k_bin's run time; an ulp of a <= 128 px offset is far inside WINDOW_EPS.  Only the absolute
                 // pixel coordinates stay in double.)
@@ -1806,10 +1802,6 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
     __syncthreads();
 
     for (unsigned base = 0; base < nchunks; base += (unsigned)(BT_WAVES * BT_CHUNKS)) {
-#ifdef BT_DEBUG
-        for (int i = tid; i < BT_LIST * 8; i += BT_THREADS) s_items[i] = 0xffffu;
-        __syncthreads();
-#endif
         // ---- level 1: candidates -> survivors + items ----------------------------------------------------
         unsigned cj[BT_CHUNKS];
         uint2 cw[BT_CHUNKS];
@@ -1881,11 +1873,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
         __syncthreads();
         const unsigned nsurv = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[0]);
         const unsigned nitems = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[1]);
-#ifdef BT_DEBUG
-        if (tid == 0) { atomicAdd(&V.done[0], nitems); atomicAdd(&V.done[2], nsurv); }
-#else
         (void)nsurv;
-#endif
         // ---- level 2: this wave's run of items, cut where a Gaussian's items end ---------------------------
         // run boundaries: nitems * w / 4 moved up to the next item that starts a Gaussian
         unsigned run[2];
@@ -1934,13 +1922,6 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
             // supplies 0 to its neighbour)
             const unsigned prev = (unsigned)__shfl_up((int)key, 1);
             const bool head = valid && (lane == 0 || prev != key);
-#ifdef BT_DEBUG
-            {
-                const unsigned long long vm = __ballot(valid), hm = __ballot(head), um = __ballot(valid && it == 0xffffu);
-                if (um && lane == 0) atomicAdd(&V.done[4], (unsigned)__builtin_popcountll(um));
-                if (lane == 0) { atomicAdd(&V.done[1], (unsigned)__builtin_popcountll(vm)); atomicAdd(&V.done[3], (unsigned)__builtin_popcountll(hm)); }
-            }
-#endif
             if (head) {
                 const unsigned slot = s_slot[lidx];
                 if (slot != BT_WIDE && !use_atomics) {
