@@ -269,6 +269,40 @@ int main(void)
         CK(hipFree(ws)); CK(hipFree(sws)); CK(hipFree(d_pts)); CK(hipFree(d_go)); CK(hipFree(d_out));
         free(pts); free(go); free(out); free(wsp);
     }
+    /* tile-stationary backward (GSASR_FLAG_BWD_TILE on the plan's dims: the workspace carries the slots), planar upstream
+     * gradient (GSASR_FLAG_CHW_GRAD), and a workspace kept across two plans without a memset in the second
+     * (GSASR_FLAG_COUNTERS_CLEAN | GSASR_FLAG_PARITY) */
+    {
+        const float dmax = 0.3f;
+        float *chw = malloc(sizeof(float) * 3 * h * w), *d_chw;
+        for (int i = 0; i < h * w; ++i)
+            for (int k = 0; k < 3; ++k) chw[(size_t)k * h * w + i] = wgt[(size_t)i * 3 + k];
+        CK(hipMalloc((void **)&d_chw, sizeof(float) * 3 * h * w));
+        CK(hipMemcpy(d_chw, chw, sizeof(float) * 3 * h * w, hipMemcpyHostToDevice));
+        gsasr_dims d = {s, h, w, 3, dmax, 0, h, 0.f, GSASR_FLAG_OVERWRITE_GRADS | GSASR_FLAG_BWD_TILE};
+        gsasr_dims plain = d;
+        plain.flags = GSASR_FLAG_OVERWRITE_GRADS;
+        const size_t bytes = gsasr_splat_workspace_bytes(&d);
+        if (!(bytes > gsasr_splat_workspace_bytes(&plain))) { printf("tile-backward plan carries no slots\n"); bad = 1; }
+        void *ws;
+        CK(hipMalloc(&ws, bytes));
+        gsref_backward_f64(sig, xy, col, wgt, rs, rc, rk, s, h, w, dmax, 0, h);
+        for (int pass = 0; pass < 2; ++pass) {
+            gsasr_dims dp = d;
+            if (pass == 1) dp.flags |= GSASR_FLAG_COUNTERS_CLEAN | GSASR_FLAG_PARITY | GSASR_FLAG_CHW_GRAD;
+            OK(gsasr_splat_plan(d_sig, d_xy, d_col, &dp, ws, bytes, st));
+            OK(gsasr_splat_backward(d_sig, d_xy, d_col, pass == 1 ? d_chw : d_wgt, d_gs, d_gc, d_gk, &dp, ws, bytes, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(gs, d_gs, sizeof(float) * 3 * s, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(gc, d_gc, sizeof(float) * 2 * s, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(gk, d_gk, sizeof(float) * 3 * s, hipMemcpyDeviceToHost));
+            const double e1 = maxrel(gs, rs, 3 * s), e2 = maxrel(gc, rc, 2 * s), e3 = maxrel(gk, rk, 3 * s);
+            printf("tile backward (%s): grad rel err %.2e %.2e %.2e\n", pass ? "planar gradient, kept workspace" : "interleaved gradient", e1, e2, e3);
+            if (!(e1 <= 2e-4) || !(e2 <= 2e-4) || !(e3 <= 2e-4)) bad = 1;
+        }
+        CK(hipFree(ws)); CK(hipFree(d_chw));
+        free(chw);
+    }
     /* error behaviour: status + message instead of a crash */
     if (gsasr_gs_render_dmax(d_sig, d_xy, d_col, d_img, s, h, w, 4, 0.1f, st) == 0) { printf("c=4 accepted\n"); bad = 1; }
     printf("%s\n", bad ? "C-ABI CHECK FAILED" : "C-ABI CHECK OK");
