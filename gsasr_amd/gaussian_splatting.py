@@ -448,7 +448,16 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
     def col(vals):
         if all(torch.is_tensor(v) for v in vals):
             return torch.stack([v.reshape(()) for v in vals]).to(device=dev, dtype=torch.float32)
-        return torch.tensor([float(v) for v in vals], dtype=torch.float32, device=dev)
+        # python numbers: one host-to-device copy per DISTINCT tuple of values, not per call
+        key = (tuple(float(v) for v in vals), dev)
+        t = _STEP_TENSORS.get(key)
+        if t is None or torch.cuda.is_current_stream_capturing():
+            t = torch.tensor(key[0], dtype=torch.float32, device=dev)
+            if not torch.cuda.is_current_stream_capturing():
+                if len(_STEP_TENSORS) > 256:
+                    _STEP_TENSORS.clear()
+                _STEP_TENSORS[key] = t
+        return t
     if mode == 'scale':
         final = col(list(scales))
     elif mode == 'scale_modify':

@@ -27,29 +27,46 @@ sm = [torch.tensor([scale, scale], device=dev)] * B
 wgt = torch.rand(B, 3, H, W, device=dev)
 
 
-def loop():
+def loop(sms, loss_style):
     pa = p.detach().requires_grad_(True)
     loss = 0
+    outs = []
     for b in range(B):
-        out = gsp.generate_2D_gaussian_splatting_step((H, W), pa[b], scale, sm[b], dmax=dmax)
-        loss = loss + (out * wgt[b]).sum()
-    loss.backward()
+        out = gsp.generate_2D_gaussian_splatting_step((H, W), pa[b], scale, sms[b], dmax=dmax)
+        if loss_style:
+            loss = loss + (out * wgt[b]).sum()
+        else:
+            outs.append(out)
+    if loss_style:
+        loss.backward()
+    else:
+        torch.autograd.backward(outs, [wgt[b] for b in range(B)])
 
 
-def batched():
+def batched(sms, loss_style):
     pa = p.detach().requires_grad_(True)
-    out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, [scale] * B, sm, dmax=dmax)
-    (out * wgt).sum().backward()
+    out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, [scale] * B, sms, dmax=dmax)
+    if loss_style:
+        (out * wgt).sum().backward()
+    else:
+        out.backward(wgt)
 
 
+sm_py = [(scale, scale)] * B
 for name, fn in (("per-sample loop", loop), ("batched", batched)):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 20
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    print(f"{name:16s} B={B} N={p.shape[1]} {H}x{W}: {dt * 1e3:7.3f} ms per fwd+bwd  ({B * H * W / dt / 1e6:.0f} HR Mpx/s)")
+    for sm_name, sms in (("scale_modify on the GPU", sm), ("scale_modify as numbers", sm_py)):
+        for loss_style in (True, False):
+            for _ in range(4):
+                fn(sms, loss_style)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                n = 20
+                for _ in range(n):
+                    fn(sms, loss_style)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / n)
+            print(f"{name:16s} {sm_name:24s} {'torch loss' if loss_style else 'direct grad':11s} B={B} N={p.shape[1]} {H}x{W}: "
+                  f"{best * 1e3:7.3f} ms per fwd+bwd  ({B * H * W / best / 1e6:.0f} HR Mpx/s)")
+gsp.deferred_asserts.flush()
