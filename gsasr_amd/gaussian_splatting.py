@@ -25,6 +25,11 @@ import torch.nn.functional as F
 from ._amp import fp32_boundary_bwd, fp32_boundary_fwd
 
 
+def _capturing() -> bool:
+    """is the current stream being captured into a graph (no caching of tensors created then, no deferred checks)"""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _hw(sr_size):
     # sr_size arrives as list, CPU tensor or GPU int tensor (gsasr_model.py:148,202); make ints once
     return int(sr_size[0]), int(sr_size[1])
@@ -193,9 +198,9 @@ def _step_tensor(step_size, dev):
         return step_size.detach().to(device=dev, dtype=torch.float32).reshape(1)   # stays on the device: no sync
     key = (float(step_size), dev)
     t = _STEP_TENSORS.get(key)
-    if t is None or torch.cuda.is_current_stream_capturing():
+    if t is None or _capturing():
         t = torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
-        if not torch.cuda.is_current_stream_capturing():
+        if not _capturing():
             if len(_STEP_TENSORS) > 256:
                 _STEP_TENSORS.clear()
             _STEP_TENSORS[key] = t
@@ -337,7 +342,7 @@ def _step_size(scale, scale_modify, default_step_size, mode):
     if mode == 'scale':
         final_scale = scale
     elif mode == 'scale_modify':
-        if torch.is_tensor(scale_modify) and scale_modify.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if torch.is_tensor(scale_modify) and scale_modify.is_cuda and not _capturing():
             deferred_asserts.add(scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify.shape}")
         elif not (torch.is_tensor(scale_modify) and scale_modify.is_cuda):
             assert scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify}"
@@ -451,9 +456,9 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
         # python numbers: one host-to-device copy per DISTINCT tuple of values, not per call
         key = (tuple(float(v) for v in vals), dev)
         t = _STEP_TENSORS.get(key)
-        if t is None or torch.cuda.is_current_stream_capturing():
+        if t is None or _capturing():
             t = torch.tensor(key[0], dtype=torch.float32, device=dev)
-            if not torch.cuda.is_current_stream_capturing():
+            if not _capturing():
                 if len(_STEP_TENSORS) > 256:
                     _STEP_TENSORS.clear()
                 _STEP_TENSORS[key] = t
@@ -464,7 +469,7 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
         if all(torch.is_tensor(sm) and sm.is_cuda for sm in scale_modifies):
             both = torch.stack([sm.reshape(-1)[:2] for sm in scale_modifies]).to(device=dev, dtype=torch.float32)   # [B,2], one kernel
             a, b = both[:, 0], both[:, 1]
-            if not torch.cuda.is_current_stream_capturing():      # the reference's assert, without draining the pipeline
+            if not _capturing():      # the reference's assert, without draining the pipeline
                 deferred_asserts.add((a == b).all(), "scale_modify is not the same (batched step)")
         else:
             a, b = col([sm[0] for sm in scale_modifies]), col([sm[1] for sm in scale_modifies])
