@@ -196,3 +196,50 @@ def test_batch_larger_than_one_canvas_is_split(dev):
     ref.square().sum().backward()
     assert float((out - ref).detach().abs().max()) <= 2e-5
     assert float((pa.grad - pb.grad).abs().max()) <= 2e-4 * float(pb.grad.abs().max())
+
+
+def test_config3_full_size_band_against_oracle(dev):
+    """BASELINE config 3 in full (512x512 LR -> x12 = 6144^2, 262 144 Gaussians, dmax 0.1, forward): a 16-row band of
+    the image against the oracle with every Gaussian (exact box semantics)"""
+    from gsasr_amd import _cabi, synthetic
+    from oracle import gs_oracle
+    sig, xy, col, H, W = synthetic.kernel_inputs(512, 512, 12.0, seed=0)
+    assert (H, W, sig.shape[0]) == (6144, 6144, 262144)
+    a, b, c = sig.to(dev), xy.to(dev), col.to(dev)
+    plan = _cabi.plan(a, b, c, H, W, 0.1, flags=_cabi.FLAG_FORWARD_ONLY)
+    img = torch.empty(H, W, 3, device=dev)
+    _cabi.forward(plan, img, overwrite=True)
+    for rows in ((3056, 3072), (0, 16)):
+        ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, 0.1, rows=rows)
+        assert np.abs(img[rows[0]:rows[1]].cpu().numpy() - ref).max() <= IMG_ATOL
+
+
+def test_config4_full_size_band_against_oracle(dev):
+    """BASELINE config 4 on one GPU (1024x1024 LR -> x8 = 8192^2, 1 048 576 Gaussians, dmax 0.1): a 16-row band of the
+    image, and the gradient of that band through BOTH backward kernels (the tile-stationary one is the library's
+    default at this scale), against the oracle with every Gaussian"""
+    from gsasr_amd import _cabi, synthetic
+    from oracle import gs_oracle
+    from test_bwd_tile import per_gaussian_ok
+    sig, xy, col, H, W = synthetic.kernel_inputs(1024, 1024, 8.0, seed=0)
+    assert (H, W, sig.shape[0]) == (8192, 8192, 1048576)
+    s, c, k = sig.numpy(), xy.numpy(), col.numpy()
+    a, b, d = sig.to(dev), xy.to(dev), col.to(dev)
+    rows = (4088, 4104)
+    wgt = synthetic.grad_image(rows[1] - rows[0], W, 3)
+    want = gs_oracle.backward_f64(s, c, k, wgt.numpy(), 0.1, h=H, rows=rows)
+    ref = gs_oracle.forward_f64(s, c, k, H, W, 0.1, rows=rows)
+    for flag in (_cabi.FLAG_BWD_TILE, _cabi.FLAG_BWD_GAUSSIAN):
+        band = _cabi.plan(a, b, d, H, W, 0.1, rows=rows, flags=flag)
+        img = torch.empty(rows[1] - rows[0], W, 3, device=dev)
+        _cabi.forward(band, img, overwrite=True)
+        assert np.abs(img.cpu().numpy() - ref).max() <= IMG_ATOL
+        g = [torch.empty_like(t) for t in (a, b, d)]
+        _cabi.backward(band, a, b, d, wgt.to(dev), *g, overwrite=True)
+        for got, w_, name in zip(g, want, ("sigmas", "coords", "colors")):
+            per_gaussian_ok(got.cpu().numpy(), w_, name, rho=s[:, 2])
+    # the whole image at this size plans for the tile-stationary backward by default (slots in the workspace)
+    import ctypes
+    whole, forced = _cabi.make_dims(sig.shape[0], H, W, 0.1), _cabi.make_dims(sig.shape[0], H, W, 0.1, flags=_cabi.FLAG_BWD_GAUSSIAN)
+    L = _cabi.lib()
+    assert L.gsasr_splat_workspace_bytes(ctypes.byref(whole)) > L.gsasr_splat_workspace_bytes(ctypes.byref(forced))
