@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--exchange", default="halo", choices=["halo", "broadcast"],
                     help="multi-rank data path: neighbour halo swap (default) or broadcast + reduce_scatter")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even at world size 1 (self-test)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend: nccl (= RCCL over xGMI, the measured configuration) or gloo -- a functional "
+                         "self-test of the multi-rank code path on a box with fewer GPUs than ranks (ranks then share devices)")
     return ap.parse_args()
 
 
@@ -574,13 +577,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count() if args.backend == "gloo" else local)
     torch.cuda.set_device(dev)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     if args.config == "c5e2e":

@@ -1,0 +1,28 @@
+"""The multi-rank code path of bench.py (row-band shard: halo exchange, and broadcast + reduce-scatter) executed for real
+with two processes -- on ONE GPU, over gloo, as a functional self-test: the development boxes have a single GPU and
+RCCL refuses two ranks on one device.  Timing from such a run means nothing; what is checked is that every rank gets
+through plan / exchange / forward / backward / exchange and that rank 0 prints the contract's JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--exchange", "halo"], ["--exchange", "broadcast"], ["--config", "c4"]],
+                         ids=["weak-halo", "weak-broadcast", "strong-c4"])
+def test_bench_two_ranks_functional(extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--no-cpu-baseline", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["config"]["rccl"]["ranks"] == 2 and d["config"]["rccl"]["bytes_sent_per_rank_per_step"] > 0
+    assert d["scaling"] == ("strong" if "c4" in extra else "weak")
+    assert set(("roofline", "kernels", "metric", "unit", "ms_per_step", "dtype", "data")) <= set(d)
