@@ -143,6 +143,8 @@ class Step:
         # row bands of the x8 config: the tile-stationary backward (the library's own default for whole images at this
         # scale; a band's pixels per Gaussian do not tell the library the scale, the caller does)
         band_flags = _cabi.FLAG_BWD_TILE if (self.strong and world > 1 and not self.fwd_only) else 0
+        if self.fwd_only:
+            band_flags |= _cabi.FLAG_FORWARD_ONLY        # (inference: no backward records in the plan)
         self.plan = _cabi.plan(self.sig, self.xy, self.col, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff, flags=band_flags)
         if self.dist:
             from gsasr_amd import shard

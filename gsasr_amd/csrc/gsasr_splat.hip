@@ -226,9 +226,11 @@ Layout make_layout(const gsasr_dims *d)
     L.off_bmax = o;   o += align_up((size_t)classify_blocks(d) * 8, 256);
     L.off_stot = o;   o += align_up((ncls / 4096 + 2) * 4, 256);
     L.off_rec = o;    o += align_up(s * 32, 256);
-    L.off_fin = o;    o += align_up(s * 32, 256);
-    L.off_sums = o;   o += align_up(s * 32, 256);
-    L.off_done = o;   o += align_up(s * 4, 256);
+    // (a forward-only plan -- inference -- carries none of the backward's records)
+    const size_t bw = (d->flags & GSASR_FLAG_FORWARD_ONLY) ? 0 : s;
+    L.off_fin = o;    o += align_up(bw * 32, 256);
+    L.off_sums = o;   o += align_up(bw * 32, 256);
+    L.off_done = o;   o += align_up(bw * 4, 256);
     L.off_bbox = o;   o += align_up(s * 32, 256);
     L.off_win = o;    o += align_up(s * 8, 256);
     L.part_k = bwd_part_k(d);
@@ -792,16 +794,21 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     const unsigned j = (FUSED_SCAN ? s_start[key] : V.cell_start[key]) + rnk;
     V.rec[2 * j + 0] = recA;
     V.rec[2 * j + 1] = recB;
-    V.fin[2 * j + 0] = finA;
-    V.fin[2 * j + 1] = finB;
+    const bool backward_records = !(P.flags & GSASR_FLAG_FORWARD_ONLY);
+    if (backward_records) {
+        V.fin[2 * j + 0] = finA;
+        V.fin[2 * j + 1] = finB;
+    }
     V.bbox[2 * j] = bb;
     V.bbox[2 * j + 1] = bc;
     V.win[j] = make_uint2(bb.x, bb.y);
     if (V.qspan) V.qspan[j] = qs;
     // the atomic accumulators (row chunks of a large Gaussian; windows wider than their slots in the tile backward) start from zero
-    reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (large) V.done[j] = 0u;
+    if (backward_records) {
+        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (large) V.done[j] = 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2772,6 +2779,7 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
     if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
     const int mode = bwd_mode(dims, L);
     if (mode_out) *mode_out = mode;
+    if (dims->flags & GSASR_FLAG_FORWARD_ONLY) return fail(GSASR_ERR_PLAN, "the plan was made with GSASR_FLAG_FORWARD_ONLY: it holds no backward records");
     if (dims->s == 0) return GSASR_OK;
     if (gather && (!g_sigmas || !g_coords || !g_colors)) return fail(GSASR_ERR_ARG, "null pointer");
     if (mode == 0 && (dims->flags & GSASR_FLAG_CHW_GRAD))
@@ -2877,9 +2885,10 @@ StepLayout make_step_layout(const gsasr_dims *d)
     S.off_sig = o;  o += align_up(n * 12, 256);
     S.off_xy = o;   o += align_up(n * 8, 256);
     S.off_col = o;  o += align_up(n * 12, 256);
-    S.off_gsig = o; o += align_up(n * 12, 256);
-    S.off_gxy = o;  o += align_up(n * 8, 256);
-    S.off_gcol = o; o += align_up(n * 12, 256);
+    const size_t nb = (d->flags & GSASR_FLAG_FORWARD_ONLY) ? 0 : n;   // (no gradient scratch for a forward-only step)
+    S.off_gsig = o; o += align_up(nb * 12, 256);
+    S.off_gxy = o;  o += align_up(nb * 8, 256);
+    S.off_gcol = o; o += align_up(nb * 12, 256);
     // a planar upstream gradient (GSASR_FLAG_CHW_GRAD) in front of the Gaussian-stationary backward is interleaved into
     // this scratch by k_chw_to_hwc (the tile-stationary backward stages the planes directly and needs none)
     S.off_ghwc = o;
@@ -3082,6 +3091,7 @@ int gsasr_splat_sample_backward(const float *sigmas, const float *coords, const 
     if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
     long n_total = 0;
     if (int rc = check_points(dims, n_points, sample_ws, sample_ws_bytes, n_total)) return rc;
+    if (dims->flags & GSASR_FLAG_FORWARD_ONLY) return fail(GSASR_ERR_PLAN, "the plan was made with GSASR_FLAG_FORWARD_ONLY: it holds no backward records");
     if (dims->s == 0) return GSASR_OK;
     if (!g_sigmas || !g_coords || !g_colors) return fail(GSASR_ERR_ARG, "null pointer");
     (void)sigmas; (void)coords; (void)colors;   // (everything the kernel needs is in the plan)

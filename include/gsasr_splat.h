@@ -68,7 +68,9 @@ enum gsasr_status {
 #define GSASR_FLAG_CHW_GRAD 32u       /* backward reads grad_img as planar [3, row1-row0, w] (what autograd hands back for the
                                          planar image of GSASR_FLAG_CHW_IMAGE; batched canvas: [B, 3, grad_rows, w]) instead
                                          of [row1-row0, w, 3]: no permute pass in front of the backward.  Tile backward only */
-#define GSASR_FLAG_FORWARD_ONLY 64u   /* the plan will not be used by a backward (no slots even if GSASR_FLAG_BWD_TILE is set) */
+#define GSASR_FLAG_FORWARD_ONLY 64u   /* the plan will not be used by a backward (inference): the workspace carries no backward
+                                         records, constants, accumulators, slots or gradient scratch (about half the bytes per
+                                         Gaussian) and the plan does not write them; a backward on it is GSASR_ERR_PLAN */
 #define GSASR_FLAG_BWD_GAUSSIAN 128u  /* backward kernel choice (default: the library picks): Gaussian-stationary
                                          (one wave per Gaussian sweeping its window through L1/L2) ...              */
 #define GSASR_FLAG_BWD_TILE 256u      /* ... or tile-stationary (one workgroup per 32x16-px tile, grad_img staged once
