@@ -804,7 +804,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     V.win[j] = make_uint2(bb.x, bb.y);
     if (V.qspan) V.qspan[j] = qs;
     // the atomic accumulators (row chunks of a large Gaussian; windows wider than their slots in the tile backward) start from zero
-    if (backward_records) {
+    // (needed by: the large class; a plan with slots, whose too-wide windows fall back to them; the atomic variant)
+    if (backward_records && (large || V.qspan || (P.flags & GSASR_FLAG_BWD_ATOMIC))) {
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (large) V.done[j] = 0u;
@@ -2816,6 +2817,10 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         HIP_TRY(hipGetLastError());
         return GSASR_OK;
     }
+    if (L.part_k == 0)
+        // the atomic variant, or a tile-stationary backward asked of a plan that was not made for it: the plan may have
+        // left the accumulators alone (k_bin zeroes them only where it knows they will be used)
+        HIP_TRY(hipMemsetAsync(V.sums, 0, (size_t)dims->s * 32, st));
     if (rows > 0) {
         const int tiles_x = (dims->w + BT_W - 1) / BT_W, tiles_y = (rows + BT_H - 1) / BT_H;
         const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(BT_THREADS);

@@ -22,8 +22,7 @@ grad = synthetic.grad_image(H, W, 1).to(dev)
 res = {}
 nrun = int(os.environ.get("NRUN", "1"))
 for name, flag in (("gaussian", _cabi.FLAG_BWD_GAUSSIAN), ("tile", _cabi.FLAG_BWD_TILE), ("atomic", _cabi.FLAG_BWD_ATOMIC)):
-    plan = _cabi.plan(sig, xy, col, H, W, None if dmax < 0 else dmax)     # a fresh workspace per mode
-    plan.dims.flags = flag
+    plan = _cabi.plan(sig, xy, col, H, W, None if dmax < 0 else dmax, flags=flag)     # a fresh workspace per mode
     g = [torch.full_like(t, float("nan")) for t in (sig, xy, col)]
     for _ in range(nrun):
         _cabi.backward(plan, sig, xy, col, grad, *g, overwrite=True)
