@@ -226,6 +226,7 @@ class Step:
     def do_plan(self):
         import ctypes
         p = self.plan
+        p.pool_key = None       # this workspace is re-planned by hand from here on: it must never go back to the package's pool
         # the workspace persists across steps: every plan zeroes the other parity's cell counters on the side, so after
         # the first one no memset launch is needed (GSASR_FLAG_COUNTERS_CLEAN / GSASR_FLAG_PARITY alternate)
         c = self.cabi

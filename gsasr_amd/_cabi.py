@@ -213,7 +213,9 @@ class Plan:
     dims: Dims
     workspace: torch.Tensor
     device: torch.device
-    pool_key: Optional[tuple] = None      # set for pooled workspaces: returned (with the parity flipped) when the plan dies
+    pool_key: Optional[tuple] = None      # set for pooled workspaces: returned (with the parity flipped) when the plan dies.
+    #                                       A caller that re-plans on `workspace` itself (C entry points with its own flags)
+    #                                       must set this to None: the pool's "counters clean" bookkeeping no longer holds
     parity: int = 0
 
     def __del__(self):
@@ -249,10 +251,31 @@ def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
         check(-1, "gsasr_splat_workspace_bytes")
     dev = sigmas.device
     with _on(dev):
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws, pool_key, parity = _pooled_workspace(d, nbytes, dev)
         check(L.gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), ws.data_ptr(), nbytes, _stream(dev)),
               "gsasr_splat_plan")
-    return Plan(d, ws, dev)
+    return Plan(d, ws, dev, pool_key, parity)
+
+
+def _pool_key(d: Dims, nbytes: int, dev):
+    """Workspaces are interchangeable only between plans of the SAME layout: "the counters of parity p are zero" is a
+    statement about where the counter arrays lie and how long they are (grid size), so the key carries everything the
+    layout depends on, not just the byte count (two small shapes easily round to the same size)."""
+    return (dev.index, _stream(dev), nbytes, d.s, d.h, d.w, d.batch, d.slot,
+            d.flags & (FLAG_FORWARD_ONLY | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN | FLAG_BWD_ATOMIC | FLAG_CHW_GRAD | FLAG_STRIDE8))
+
+
+def _pooled_workspace(d: Dims, nbytes: int, dev):
+    """a workspace for a plan with dims `d`: from the pool, with the flags that tell the plan its counters are clean
+    (set on `d`), or fresh.  Returns (workspace, pool key or None, parity)."""
+    if torch.cuda.is_current_stream_capturing():
+        # a captured plan is replayed on the same workspace with the same parity: it must zero its own counters
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev), None, 0
+    pool_key = _pool_key(d, nbytes, dev)
+    ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
+    if clean:      # (these two bits do not change the layout)
+        d.flags |= FLAG_COUNTERS_CLEAN | (FLAG_PARITY if parity else 0)
+    return ws, pool_key, parity
 
 
 def _dims_with(p: Plan, extra_flags: int) -> Dims:
@@ -311,12 +334,16 @@ def plan_packed(packed: torch.Tensor, h: int, w: int, dmax: Optional[float],
         check(-1, "gsasr_splat_workspace_bytes")
     dev = packed.device
     with _on(dev):
-        ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        pool_key, parity = None, 0
+        if workspace is not None:
+            ws = workspace
+        else:
+            ws, pool_key, parity = _pooled_workspace(d, nbytes, dev)
         if ws.numel() < nbytes:
             raise RuntimeError("workspace smaller than gsasr_splat_workspace_bytes()")
         check(L.gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), ws.data_ptr(), ws.numel(), _stream(dev)),
               "gsasr_splat_plan")
-    return Plan(d, ws, dev)
+    return Plan(d, ws, dev, pool_key, parity)
 
 
 def backward_packed(p: Plan, packed: torch.Tensor, grad_img: torch.Tensor, g_packed: torch.Tensor,
@@ -424,7 +451,7 @@ def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int
             # a captured plan is replayed on the same workspace with the same parity: it must zero its own counters
             ws, parity, clean, pool_key = torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False, None
         else:
-            pool_key = (dev.index, stream, nbytes)
+            pool_key = _pool_key(variants[0], nbytes, dev)
             ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
         d = variants[1 + parity] if clean else variants[0]
         img = torch.empty(3, int(h), int(w), dtype=torch.float32, device=dev)
@@ -485,13 +512,7 @@ def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax:
     dev = gs_parameters.device
     with _on(dev):
         stream = _stream(dev)
-        if torch.cuda.is_current_stream_capturing():
-            ws, parity, clean, pool_key = torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False, None
-        else:
-            pool_key = (dev.index, stream, nbytes)
-            ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
-        if clean:      # (these two bits do not change the layout)
-            d.flags |= FLAG_COUNTERS_CLEAN | (FLAG_PARITY if parity else 0)
+        ws, pool_key, parity = _pooled_workspace(d, nbytes, dev)
         img = torch.empty(B, 3, d.slot, w_max, dtype=torch.float32, device=dev)
         check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
               "gsasr_step_forward")

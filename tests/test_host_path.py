@@ -83,3 +83,28 @@ def test_forward_only_plan_under_no_grad(dev):
     full = _cabi.make_dims(256, 64, 64, 0.3, flags=_cabi.FLAG_CHW_GRAD | _cabi.FLAG_BWD_TILE)
     L = _cabi.lib()
     assert L.gsasr_step_workspace_bytes(ctypes.byref(fwd)) < L.gsasr_step_workspace_bytes(ctypes.byref(full))
+
+
+def test_pooled_workspaces_are_not_shared_between_layouts(dev):
+    """two grids whose workspaces have the same byte count (64x64 and 48x64 with the same N) but different cell
+    counts: a workspace that comes back from one must not be handed to the other as 'counters clean'"""
+    import ctypes
+    from gsasr_amd import _cabi, gaussian_splatting as gsp, synthetic
+    da, db = _cabi.make_dims(256, 64, 64, 0.3), _cabi.make_dims(256, 48, 64, 0.3)
+    L = _cabi.lib()
+    assert L.gsasr_splat_workspace_bytes(ctypes.byref(da)) == L.gsasr_splat_workspace_bytes(ctypes.byref(db))
+    p = synthetic.gs_parameters(16, 16, seed=9).to(dev)
+    ref = {}
+    for it in range(6):
+        for (H, W) in ((48, 64), (64, 64)):
+            with torch.no_grad():
+                out = gsp.generate_2D_gaussian_splatting_step((H, W), p, 4.0, (4.0, 4.0), dmax=0.3)
+            sig, xy, col, _, _ = gsp._to_kernel_frame(*gsp._activate(p), (H, W), 1.2 / 4.0)
+            plan = _cabi.plan(sig, xy, col, H, W, 0.3)                 # the plan-API pool as well
+            img = torch.empty(H, W, 3, device=dev)
+            _cabi.forward(plan, img, overwrite=True)
+            del plan
+            if (H, W) not in ref:
+                ref[(H, W)] = out.clone()
+            assert float((out - ref[(H, W)]).abs().max()) <= 1e-5
+            assert float((img.permute(2, 0, 1) - ref[(H, W)]).abs().max()) <= 1e-5
