@@ -37,6 +37,9 @@ pass pmc_fetch_tile_bwd "FETCH_SIZE" $BENCH
 pass pmc_write_tile_bwd "WRITE_SIZE" $BENCH
 rocprofv3 --kernel-trace --stats -d /tmp/ktt4_$TAG -o kt -- $BENCH --config c4 --steps 5 --warmup 2 > /dev/null 2> $OUT/ktt4.err
 python $R/tools/rocpd_summary.py /tmp/ktt4_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c4_tile_bwd.txt
+export GSASR_SPLAT_BWD=gaussian
+rocprofv3 --kernel-trace --stats -d /tmp/ktg4_$TAG -o kt -- $BENCH --config c4 --steps 5 --warmup 2 > /dev/null 2> $OUT/ktg4.err
+python $R/tools/rocpd_summary.py /tmp/ktg4_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c4_gaussian_bwd.txt
 unset GSASR_SPLAT_BWD
 rocprofv3 --kernel-trace --stats -d /tmp/kt4_$TAG -o kt -- $BENCH --config c4 --steps 5 --warmup 2 > /dev/null 2> $OUT/kt4.err
 python $R/tools/rocpd_summary.py /tmp/kt4_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c4.txt
@@ -48,6 +51,7 @@ tail -c 3000 $OUT/bench.json
 python bench.py --no-cpu-baseline --config c3 --steps 10 --warmup 3 > $OUT/bench_c3.json 2>> $OUT/bench.err
 python bench.py --no-cpu-baseline --config c4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2>> $OUT/bench.err
 GSASR_SPLAT_BWD=tile python bench.py --no-cpu-baseline --config c4 --steps 5 --warmup 2 > $OUT/bench_c4_tile_bwd.json 2>> $OUT/bench.err
+GSASR_SPLAT_BWD=gaussian python bench.py --no-cpu-baseline --config c4 --steps 5 --warmup 2 > $OUT/bench_c4_gaussian_bwd.json 2>> $OUT/bench.err
 GSASR_SPLAT_BWD=tile python bench.py --no-cpu-baseline --no-extras > $OUT/bench_c2_tile_bwd.json 2>> $OUT/bench.err
 python bench.py --no-cpu-baseline --no-extras --dmax 0.5 > $OUT/bench_c2_dmax0p5.json 2>> $OUT/bench.err
 python bench.py --no-cpu-baseline --no-extras --dmax -1 > $OUT/bench_c2_unbounded.json 2>> $OUT/bench.err
