@@ -285,3 +285,40 @@ def test_fuzz_extreme_parameters_tile_backward(seed, dev):
         bad = (err > tol) & well[:, None]
         assert not bad.any(), (name, int(np.argwhere(bad)[0][0]), float(err[bad].max()), float(np.abs(want).max()),
                                sig[np.argwhere(bad)[0][0]].tolist())
+
+
+def test_packed_records_tile_backward(dev):
+    """GSASR_FLAG_STRIDE8 (the wire format of the multi-GPU exchange) through the tile-stationary backward: inputs and
+    gradients as columns of one [N,8] array, row band, dead (NaN) padding records"""
+    from gsasr_amd import _cabi, shard, synthetic
+    from oracle import gs_oracle
+    sig, xy, col, H, W = synthetic.kernel_inputs(40, 36, 4.0, seed=95)
+    wgt = synthetic.grad_image(H, W, 96)
+    rec = shard.pack(sig, xy, col)
+    pad = torch.full((37, 8), float("nan"))
+    rec_dev = torch.cat([rec, pad]).to(dev)
+    rows = (40, 120)
+    plan = _cabi.plan_packed(rec_dev, H, W, 0.25, rows=rows)
+    assert not (plan.dims.flags & _cabi.FLAG_BWD_TILE)
+    flagged = _cabi.Dims.from_buffer_copy(plan.dims)
+    del plan
+    # the same with the tile-stationary backward asked for at plan time
+    import ctypes
+    d = _cabi.make_dims(rec_dev.shape[0], H, W, 0.25, rows, 0.0, _cabi.FLAG_STRIDE8 | _cabi.FLAG_BWD_TILE | _cabi.FLAG_OVERWRITE_GRADS)
+    L = _cabi.lib()
+    nbytes = L.gsasr_splat_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    base = rec_dev.data_ptr()
+    _cabi.check(L.gsasr_splat_plan(base, base + 12, base + 20, ctypes.byref(d), ws.data_ptr(), nbytes, _cabi._stream(dev)), "plan")
+    g = torch.full_like(rec_dev, float("nan"))
+    gw = wgt[rows[0]:rows[1]].contiguous().to(dev)
+    gb = g.data_ptr()
+    _cabi.check(L.gsasr_splat_backward(base, base + 12, base + 20, gw.data_ptr(), gb, gb + 12, gb + 20, ctypes.byref(d), ws.data_ptr(),
+                                       nbytes, _cabi._stream(dev)), "backward")
+    torch.cuda.synchronize()
+    got = g.cpu().numpy()
+    assert np.all(got[rec.shape[0]:] == 0.0)                 # dead padding: zero gradient, not NaN
+    want = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt[rows[0]:rows[1]].numpy(), 0.25, h=H, rows=rows)
+    n = rec.shape[0]
+    for cols, w_, name in ((slice(0, 3), want[0], "sigmas"), (slice(3, 5), want[1], "coords"), (slice(5, 8), want[2], "colors")):
+        per_gaussian_ok(got[:n, cols], w_, name, rho=sig.numpy()[:, 2])
