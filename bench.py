@@ -119,7 +119,9 @@ class Step:
             self.ex = shard.BandExchange(n_local, cap, H, W, self.dmax, self.cutoff, device=dev)
             self.ex.own.copy_(mine)
             self.n_rank = n_local
-            self.plan = _cabi.plan_packed(self.ex.records, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff)
+            # (x8 row bands: the tile-stationary backward, the library's own choice for whole images at this scale)
+            self.plan = _cabi.plan_packed(self.ex.records, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff,
+                                          flags=_cabi.FLAG_BWD_TILE if (self.strong and not args.fwd_only) else 0)
             ok = 1.0
             try:    # one trial swap each way before anything is timed: a transport that cannot do grouped
                     # send/recv shows up here and the collective pattern takes over
@@ -353,6 +355,18 @@ for _k in PAIR_CEILING.values():
     _k["pairs_per_s"] = SIMDS * CLOCK_HZ / _k["cycles_per_128_pairs"] * 128.0
 
 
+def emit(out):
+    """the ONE JSON line, as the LAST thing on stdout: libraries in the process (RCCL prints a version banner through C
+    stdio) have their buffered output flushed first, so that it cannot land behind the line at exit"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+
+
 def wall_ms(fn, n, dev, warm=3):
     for _ in range(warm):
         fn()
@@ -571,7 +585,7 @@ def run_c5e2e(args, dev, rank, world):
         out["cpu_baseline"] = {"value": H * W / t1 / 1e6, "unit": "HR Mpixels/s", "cores": cores, "logical_cpus": os.cpu_count(),
                                "kind": "port", "sample": f"ONE sample of the step (encoder + producer in torch on the CPU, oracle/gs_ref.c "
                                f"fp32 restatement of gs_cuda_dmax forward + backward, autograd to the producers; no optimizer step): {t1:.2f} s"}
-    print(json.dumps(out))
+    emit(out)
 
 
 def main():
@@ -766,7 +780,7 @@ def main():
             out["dropin"] = dropin_run(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
+        emit(out)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         dist.destroy_process_group()

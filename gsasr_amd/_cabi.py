@@ -322,12 +322,13 @@ def _cols(packed: torch.Tensor, name: str):
 
 
 def plan_packed(packed: torch.Tensor, h: int, w: int, dmax: Optional[float],
-                rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0, workspace: Optional[torch.Tensor] = None) -> Plan:
+                rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0, workspace: Optional[torch.Tensor] = None,
+                flags: int = 0) -> Plan:
     """`plan` for Gaussians held as one `[N,8]` tensor {sx,sy,rho,x,y,r,g,b}; no unpacking copies."""
     ps, pc, pk = _cols(packed, "packed")
     if dmax is not None and not (float(dmax) >= 0.0):
         raise RuntimeError("dmax must be >= 0")
-    d = make_dims(packed.shape[0], h, w, dmax, rows, cutoff, FLAG_STRIDE8)
+    d = make_dims(packed.shape[0], h, w, dmax, rows, cutoff, FLAG_STRIDE8 | int(flags))
     L = lib()
     nbytes = L.gsasr_splat_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
