@@ -355,14 +355,19 @@ for _k in PAIR_CEILING.values():
     _k["pairs_per_s"] = SIMDS * CLOCK_HZ / _k["cycles_per_128_pairs"] * 128.0
 
 
-def emit(out):
-    """the ONE JSON line, as the LAST thing on stdout: libraries in the process (RCCL prints a version banner through C
-    stdio) have their buffered output flushed first, so that it cannot land behind the line at exit"""
+def flush_c_stdio():
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+
+
+def emit(out):
+    """the ONE JSON line, as the LAST thing on stdout: libraries in the process (RCCL prints a version banner through C
+    stdio when NCCL_DEBUG=VERSION, as on this image) have their buffered output flushed first, so that it cannot land
+    behind the line at exit (the other ranks flush theirs before the final barrier, see main)"""
+    flush_c_stdio()
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
 
@@ -742,6 +747,11 @@ def main():
                     pass
             roofline["valu"] = valu
 
+    if world > 1:      # every rank's C-stdio output (RCCL banner) is out before rank 0 prints the line
+        import torch.distributed as dist
+        flush_c_stdio()
+        sys.stdout.flush()
+        dist.barrier()
     if rank == 0:
         h_lr, w_lr, scale, desc = CONFIGS[args.config]
         out = {
