@@ -61,6 +61,7 @@ namespace {
 
 constexpr int CELL = 16;        // binning cell side in pixels
 constexpr int CELL_SHIFT = 4;
+constexpr int NDEAD = 64;       // "dead" (nothing to draw) sub-classes: spreads the classify atomics of off-band Gaussians
 constexpr int SUBX = 8;         // forward sub-tile: 8 px wide x 16 px tall per wave64 (2 px per lane)
 constexpr int SUBY = 16;
 constexpr int SUBX_SHIFT = 3, SUBY_SHIFT = 4;
@@ -100,14 +101,14 @@ __device__ __forceinline__ int stride2(const Params &P) { return (P.flags & GSAS
 struct PlanView {
     int4 *geo;              // [GSASR_MAX_BATCH] {h_b, w_b, first canvas row, px-table offset} (batched canvas only)
     unsigned *hdr;          // [HDR_WORDS]
-    unsigned *cell_count;   // [ncells+2]   (ncells = "large" class, ncells+1 = "dead" class); the array of this plan's parity
+    unsigned *cell_count;   // [ncells+1+NDEAD] (ncells = "large" class, ncells+1.. = "dead" sub-classes); this plan's parity
     unsigned *cell_count_next;  // the other parity's array: zeroed by k_classify for the next plan on this workspace
     unsigned *cell_start;   // [ncells+3]   exclusive scan of cell_count, last = s
     float *px, *py;         // [w], [h]
     unsigned *key;          // [s] class/cell of Gaussian i
     unsigned *rank;         // [s] position of Gaussian i inside its cell
     unsigned *blockmax;     // [2*nblk] per-classify-block max half-extents
-    unsigned *scan_tot;     // [ceil((ncells+2)/4096)] per-chunk totals of the two-pass scan
+    unsigned *scan_tot;     // [ceil((ncells+1+NDEAD)/4096)] per-chunk totals of the two-pass scan
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
     float4 *fin;            // [2*s] backward constants {1/(1-rho^2), 1-rho^2, rho, 1/sx}, {1/sy, -, -, original index}
     float *sums;            // [8*s] raw backward sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb}: atomic accumulators of the large class
@@ -212,7 +213,7 @@ Layout make_layout(const gsasr_dims *d)
     L.ncx = (d->w + CELL - 1) / CELL;
     L.ncy = (d->h + CELL - 1) / CELL;
     L.ncells = L.ncx * L.ncy;
-    const size_t ncls = (size_t)L.ncells + 2, s = (size_t)d->s;
+    const size_t ncls = (size_t)L.ncells + 1 + NDEAD, s = (size_t)d->s;
     size_t o = 0;
     L.off_hdr = o;    o += HDR_WORDS * 4;
     L.count_bytes = align_up(ncls * 4, 256);
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
-    for (int k = i; k < P.ncells + 2; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
+    for (int k = i; k < P.ncells + 1 + NDEAD; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
@@ -458,7 +459,9 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
         }
         const Box b = gaussian_box(sx, sy, x, y, P, g);
         if (b.cls == 2) {
-            key = (unsigned)P.ncells + 1u;
+            // NDEAD counters instead of one: a row band of a large image sees most of the Gaussians here, and one
+            // returning atomic per wave on a single word serialises (203 us for 1 M Gaussians, 7/8 dead)
+            key = (unsigned)P.ncells + 1u + (unsigned)((i >> 6) & (NDEAD - 1));
         } else if (b.cls == 1) {
             key = (unsigned)P.ncells;
         } else {
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
 #pragma unroll
         for (int k = 0; k < FUSED_PER_THREAD; ++k) {
             const int q = (int)threadIdx.x * FUSED_PER_THREAD + k;
-            c[k] = q < P.ncells + 2 ? V.cell_count[q] : 0u;
+            c[k] = q < P.ncells + 1 + NDEAD ? V.cell_count[q] : 0u;
         }
     }
     unsigned key = 0u, rnk = 0u;
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         }
     }
     if (FUSED_SCAN) {
-        const int t = threadIdx.x, ncls = P.ncells + 2;
+        const int t = threadIdx.x, ncls = P.ncells + 1 + NDEAD;
         const int b0 = t * FUSED_PER_THREAD;
         unsigned sum = 0;
 #pragma unroll
@@ -792,20 +795,26 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     }
     if (!valid) return;
     const unsigned j = (FUSED_SCAN ? s_start[key] : V.cell_start[key]) + rnk;
-    V.rec[2 * j + 0] = recA;
-    V.rec[2 * j + 1] = recB;
+    // A dead Gaussian (off the image, off this row band, non-finite) is never a candidate of any tile; all that is ever read
+    // of it is its (empty) window and its original index, by the backward that writes its zero gradient.  A row band of
+    // a sharded image plans every Gaussian of the image: most of them are dead there, and their records are not written.
+    const bool live = key <= (unsigned)P.ncells;
     const bool backward_records = !(P.flags & GSASR_FLAG_FORWARD_ONLY);
+    if (live) {
+        V.rec[2 * j + 0] = recA;
+        V.rec[2 * j + 1] = recB;
+        V.bbox[2 * j + 1] = bc;
+        if (V.qspan) V.qspan[j] = qs;
+    }
     if (backward_records) {
-        V.fin[2 * j + 0] = finA;
+        if (live) V.fin[2 * j + 0] = finA;
         V.fin[2 * j + 1] = finB;
     }
     V.bbox[2 * j] = bb;
-    V.bbox[2 * j + 1] = bc;
     V.win[j] = make_uint2(bb.x, bb.y);
-    if (V.qspan) V.qspan[j] = qs;
     // the atomic accumulators (row chunks of a large Gaussian; windows wider than their slots in the tile backward) start from zero
     // (needed by: the large class; a plan with slots, whose too-wide windows fall back to them; the atomic variant)
-    if (backward_records && (large || V.qspan || (P.flags & GSASR_FLAG_BWD_ATOMIC))) {
+    if (backward_records && live && (large || V.qspan || (P.flags & GSASR_FLAG_BWD_ATOMIC))) {
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j] = make_float4(0.f, 0.f, 0.f, 0.f);
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (large) V.done[j] = 0u;
@@ -2677,7 +2686,7 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
     else
         hipLaunchKernelGGL(k_classify<false>, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V, (const float *)nullptr,
                            (const float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
-    const int ncls = L.ncells + 2;
+    const int ncls = L.ncells + 1 + NDEAD;
     const unsigned nbin = (unsigned)((dims->s + 255) / 256);
     if (ncls <= FUSED_CELLS && dims->s > 0) {
         // small grid: k_bin rebuilds the scan per block (no separate scan launch)
