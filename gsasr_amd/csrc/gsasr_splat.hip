@@ -69,6 +69,15 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #ifndef BWD_WAVES_N
 #define BWD_WAVES_N 2
 #endif
+#ifndef BWD_OCC
+#define BWD_OCC 7
+#endif
+#ifndef BWD_UNROLL_OCC
+#define BWD_UNROLL_OCC 6
+#endif
+#ifndef BWD_UNROLL_MIN
+#define BWD_UNROLL_MIN 32.0
+#endif
 constexpr int BWD_WAVES = BWD_WAVES_N;  // waves (= consecutive cell-ordered Gaussians) per backward workgroup
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y
@@ -1268,7 +1277,8 @@ __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V,
 // address clamps, the ragged last trip is peeled.
 // acc[] = {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} (per lane, summed over the wave by the caller).
 struct BwdRow {
-    v2f m0, m1, m2, k01, k20, k12;  // moments; colour sums in the mixed pairing of two HWC pixels
+    v2f m1, m2, k01;         // moments N1, N2 (row pair); colour sums r, g of the first row
+    float ka2, kb0, kb1, kb2;  // colour sums: b of the first row, r g b of the second
 };
 
 struct Grad6 {  // the three gradient channels of the two pixels (rows Y, Y+RPI) a lane owns in one trip
@@ -1282,8 +1292,13 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 // VALU instruction on addressing, and reads past the end of the slab return 0 instead of faulting.
 __device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff_a, int soff_b)
 {
+#ifdef BWD_EXP_NOLOAD   // what-if experiment (tools/build_mb.sh): no gradient traffic at all
+    const u3v a = {(unsigned)voff | 0x3f000000u, (unsigned)soff_a | 0x3f000000u, 0x3f000000u};
+    const u3v b = {(unsigned)voff | 0x3f100000u, (unsigned)soff_b | 0x3f000000u, 0x3f200000u};
+#else
     const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
     const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_b, 0);
+#endif
     Grad6 g;
     g.a0 = __uint_as_float(a.x); g.a1 = __uint_as_float(a.y); g.a2 = __uint_as_float(a.z);
     g.b0 = __uint_as_float(b.x); g.b1 = __uint_as_float(b.y); g.b2 = __uint_as_float(b.z);
@@ -1298,6 +1313,11 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     // quadratic form completes to  u^2 - 2 rho u v + v^2 = (1-rho^2) u^2 + B^2,  so the exponent is
     //   log2(e) w1 (...) = K0 - K1 B^2,   K0 = -log2(e)/2 u^2 (lane constant),  K1 = log2(e)/2 / (1-rho^2),
     // and the same B feeds the gradient moments: nothing here cancels as |rho| -> 1.
+#ifdef BWD_EXP_NOMATH   // what-if experiment: the loads are consumed, nothing is computed
+    R.k01 += (v2f){g.a0, g.a1};
+    R.ka2 += g.a2; R.kb0 += g.b0; R.kb1 += g.b1; R.kb2 += g.b2;
+    return;
+#endif
     const v2f Bv = dyn - rho_u;
     const v2f pw = (Bv * nK1) * Bv + K0;
     v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
@@ -1308,12 +1328,16 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     // six consecutive-in-memory floats per pixel pair are used as they land: no register shuffling
     const v2f gp = {fmaf(g.a2, cb, fmaf(g.a1, cg, g.a0 * cr)), fmaf(g.b2, cb, fmaf(g.b1, cg, g.b0 * cr))};  // gs.cu:150
     const v2f q = gp * v, qB = q * Bv;
-    R.m0 += q;
+    // (M0 = sum q is not accumulated: it is <colour, colour sums>, formed once per column strip)
     R.m1 += qB;
     R.m2 += qB * Bv;
+    // Only {a0, a1} is an aligned register pair as the two 12-byte loads land; the other four take scalar FMAs
+    // (pairing them up costs five v_mov per trip -- more than the two packed operations save).
     R.k01 += (v2f){g.a0, g.a1} * v.x;
-    R.k20 += (v2f){g.a2, g.b0} * v;
-    R.k12 += (v2f){g.b1, g.b2} * v.y;
+    R.ka2 = fmaf(g.a2, v.x, R.ka2);
+    R.kb0 = fmaf(g.b0, v.y, R.kb0);
+    R.kb1 = fmaf(g.b1, v.y, R.kb1);
+    R.kb2 = fmaf(g.b2, v.y, R.kb2);
 }
 
 template <bool TEST, int LXLOG, bool UNROLL>
@@ -1329,25 +1353,33 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     const size_t rowpitch = (size_t)P.w * 3;
     const float nK1 = -HALF_LOG2E * cinv;
     // issued together with the px load below: one round trip for both tables instead of two dependent ones
-    const float py_first = pyt[min(r0 + lane, r1)];
+#ifdef BWD_EXP_NOTABLE   // what-if experiment: no table round trip (values are NOT the reference's)
+#define BWD_PX(X) ((float)(X) * (2.f / (float)(P.w - 1)) - 1.f)
+#define BWD_PY(Y) ((float)(Y) * (2.f / (float)(P.h - 1)) - 1.f)
+#else
+#define BWD_PX(X) pxt[X]
+#define BWD_PY(Y) pyt[Y]
+#endif
+    const float py_first = BWD_PY(min(r0 + lane, r1));
     for (int strip = 0; strip < bw; strip += 64) {
         const int cc = strip + col;
         const int X = c0 + min(cc, bw - 1);
-        const float dx = pxt[X] - x;
+        const float dx = BWD_PX(X) - x;
         // lanes outside the window (or, with TEST, outside the dmax box in x) are switched off through K0:
         // the exponent becomes -inf, v = 0 exactly, and every product with it is 0
         const bool inx = cc < bw && (!TEST || fabsf(dx) <= P.dmax);
         const float u = dx * isx, rho_u = rho * u;
         const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;
         BwdRow R;
-        R.m0 = R.m1 = R.m2 = R.k01 = R.k20 = R.k12 = (v2f){0.f, 0.f};
+        R.m1 = R.m2 = R.k01 = (v2f){0.f, 0.f};
+        R.ka2 = R.kb0 = R.kb1 = R.kb2 = 0.f;
         const int voff = (int)(((size_t)X * 3 + (size_t)rsub * rowpitch) * sizeof(float));
         const int halfb = (int)((size_t)RPI * rowpitch * sizeof(float));
         for (int rb = r0; rb <= r1; rb += 64) {
             const int rend = min(r1, rb + 63);
             __builtin_amdgcn_wave_barrier();
             {   // per-row values of the block in LDS: v = dy/sy, and (TEST only) the raw dy for the exact box test
-                const float dyr = (rb == r0 ? py_first : pyt[min(rb + lane, r1)]) - y;
+                const float dyr = (rb == r0 ? py_first : BWD_PY(min(rb + lane, r1))) - y;
                 spy[lane] = dyr * isy;
                 if (TEST) spy[64 + lane] = dyr;
             }
@@ -1395,12 +1427,13 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
         // A = u - rho v = u kappa - rho B, v = B + rho u):  sum qA, sum qB, sum q u A, sum q v B, sum q A B.
         // Every difference is formed between quantities of its own size, so nothing cancels as |rho| -> 1
         // (the plain monomial moments sum q dx^2, q dx dy, q dy^2 lose 1/(1-rho) digits there).
-        const float M0 = R.m0.x + R.m0.y, N1 = R.m1.x + R.m1.y, N2 = R.m2.x + R.m2.y;
+        const float Kr = R.k01.x + R.kb0, Kg = R.k01.y + R.kb1, Kb = R.ka2 + R.kb2;
+        const float M0 = fmaf(Kb, cb, fmaf(Kg, cg, Kr * cr)), N1 = R.m1.x + R.m1.y, N2 = R.m2.x + R.m2.y;
         // (switched-off lanes have M0 = N1 = N2 = 0, but their u is meaningless: use 0)
         const float ue = inx ? u : 0.f, uk = ue * kappa;
         const float sA = uk * M0 - rho * N1;
         const float e[8] = {sA, N1, ue * sA, N2 + rho * ue * N1, uk * N1 - rho * N2,
-                            R.k01.x + R.k20.y, R.k01.y + R.k12.x, R.k20.x + R.k12.y};
+                            Kr, Kg, Kb};
         // the first (usually only) 64-column strip assigns, so acc[] is not live during its sweep
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = strip == 0 ? e[k] : acc[k] + e[k];
@@ -1576,7 +1609,7 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
 // (occupancy targets: the unrolled sweep fits 6 waves per SIMD at the price of five spilled dwords, -2.7% at config 4;
 // forcing the plain sweep to 8 costs more in spills than it gains)
 template <bool BOUNDED, bool UNROLL>
-__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(UNROLL ? 6 : 7))) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
+__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(UNROLL ? BWD_UNROLL_OCC : BWD_OCC))) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
                                                     float *__restrict__ g_sigmas, float *__restrict__ g_coords,
                                                     float *__restrict__ g_colors)
 {
@@ -1597,7 +1630,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     // (two or four Gaussians per wave, one after the other, measured the same: wave launch is not the cost)
     BwdRec G;
     u2v lim;
+#ifdef BWD_EXP_NOFETCH   // what-if experiment: a synthetic record instead of the scalar fetch (results are meaningless)
+    {
+        const unsigned c0 = (gw * 4u) % 1000u, r0 = ((gw >> 8) * 4u) % 1000u;
+        G.bb = (u4v){c0 | ((c0 + 22u) << 16), r0 | ((r0 + 22u) << 16), 0u, 0u};
+        const float fx = (float)(c0 + 11u) * (2.f / 1023.f) - 1.f, fy = (float)(r0 + 11u) * (2.f / 1023.f) - 1.f;
+        G.rec = (u8v){__float_as_uint(fx), __float_as_uint(fy), 0u, 0u, 0u, 0x3f000000u, 0x3f000000u, 0x3f000000u};
+        G.fin = (u8v){0x3f800000u, 0x3f800000u, 0u, __float_as_uint(150.f), __float_as_uint(150.f), 0u, 0u, gw};
+        lim = (u2v){(unsigned)P.s, (unsigned)P.s};
+    }
+#else
     bwd_fetch_first(V, V.cell_start + P.ncells, min(gw, (unsigned)P.s - 1u), G, lim);  // speculative: class checked below
+#endif
     const unsigned large_beg = lim.x, large_end = lim.y;
     if (gw < large_beg)
         bwd_item<BOUNDED, UNROLL>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
@@ -2818,7 +2862,7 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         // Two instantiations of the same sweep (identical results): with the two-trip unrolled loop (88 VGPRs, 5 waves
         // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
         // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
-        const bool unroll = (double)rows * (double)dims->w >= 32.0 * (double)dims->s;
+        const bool unroll = (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
 #define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
         if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
         else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
