@@ -759,6 +759,20 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 bc.x = lo4[1]; bc.y = hi4[1];
                 bb.y |= 0x8000u;
             }
+            {   // Rows the Gaussian-stationary backward sweeps: the window's rows rounded up to a whole number of trips
+                // (8/4/2 rows for 16/32/64-lane columns) when the band has room -- the extra rows lie outside the window
+                // (their terms are < exp(-tau), or fail the dmax test), and the ragged, masked last trip disappears.
+                // Batched canvas: inside the sample's own rows (whatever gradient the caller left in the padding of the
+                // slot must not be read).  Worked out here, once, instead of by every backward wave on its scalar unit.
+                const int bwid = b.c1 - b.c0 + 1, nr = b.r1 - b.r0 + 1;
+                const int rpt = bwid <= 16 ? 8 : (bwid <= 32 ? 4 : 2);
+                const int pad = (rpt - (nr & (rpt - 1))) & (rpt - 1);
+                const int lo = max(P.row0, g.base), hi = min(P.row1, g.base + g.h) - 1;
+                int r0p = b.r0, r1p = b.r1;
+                if (r1p + pad <= hi) r1p += pad;
+                else if (r0p - pad >= lo) r0p -= pad;
+                bc.z = (unsigned)r0p | ((unsigned)r1p << 16);
+            }
         }
     }
     if (FUSED_SCAN) {
@@ -1287,17 +1301,20 @@ struct Grad6 {  // the three gradient channels of the two pixels (rows Y, Y+RPI)
 
 typedef unsigned u3v __attribute__((ext_vector_type(3)));
 
-// Two 12-byte pixels through a raw buffer resource: address = base(SGPR x4) + per-lane byte offset (VGPR,
-// constant over the sweep) + running row offset (SGPR, advanced by the scalar unit), so a trip spends no
-// VALU instruction on addressing, and reads past the end of the slab return 0 instead of faulting.
-__device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff_a, int soff_b)
+// Two 12-byte pixels through a raw buffer resource: address = base(SGPR x4) + per-lane byte offset (one VGPR per
+// row of the pair, constant over the sweep) + ONE running row offset (SGPR), so a trip spends no VALU instruction and
+// a single scalar add on addressing, and reads past the end of the slab return 0 instead of faulting.  (This kernel
+// is bound by instruction issue of ANY kind: a scalar instruction per trip costs what a vector one does, 0.35 us at
+// config 2 -- DESIGN.md 3c.)
+__device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int voff_b, int soff_a)
 {
+    const int soff_b = soff_a;
 #ifdef BWD_EXP_NOLOAD   // what-if experiment (tools/build_mb.sh): no gradient traffic at all
     const u3v a = {(unsigned)voff | 0x3f000000u, (unsigned)soff_a | 0x3f000000u, 0x3f000000u};
-    const u3v b = {(unsigned)voff | 0x3f100000u, (unsigned)soff_b | 0x3f000000u, 0x3f200000u};
+    const u3v b = {(unsigned)voff_b | 0x3f100000u, (unsigned)soff_b | 0x3f000000u, 0x3f200000u};
 #else
     const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
-    const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_b, 0);
+    const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff_b, soff_b, 0);
 #endif
     Grad6 g;
     g.a0 = __uint_as_float(a.x); g.a1 = __uint_as_float(a.y); g.a2 = __uint_as_float(a.z);
@@ -1334,6 +1351,20 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     // Only {a0, a1} is an aligned register pair as the two 12-byte loads land; the other four take scalar FMAs
     // (pairing them up costs five v_mov per trip -- more than the two packed operations save).
     R.k01 += (v2f){g.a0, g.a1} * v.x;
+#ifdef BWD_EXP_VPAD      // what-if experiment: extra (useless, independent) VALU instructions per trip
+    {
+        float pad0 = q.x, pad1 = q.y;
+#pragma unroll
+        for (int k = 0; k < BWD_EXP_VPAD / 2; ++k) asm volatile("v_mul_f32 %0, %0, %0\n\tv_mul_f32 %1, %1, %1" : "+v"(pad0), "+v"(pad1));
+    }
+#endif
+#ifdef BWD_EXP_SPAD      // ... extra scalar instructions per trip
+    {
+        int sp0 = 1;
+#pragma unroll
+        for (int k = 0; k < BWD_EXP_SPAD; ++k) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sp0) : : "scc");
+    }
+#endif
     R.ka2 = fmaf(g.a2, v.x, R.ka2);
     R.kb0 = fmaf(g.b0, v.y, R.kb0);
     R.kb1 = fmaf(g.b1, v.y, R.kb1);
@@ -1350,7 +1381,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     constexpr int LX = 1 << LXLOG, RPI = 64 >> LXLOG;
     constexpr float HALF_LOG2E = 0.72134752044448170368f;
     const int col = lane & (LX - 1), rsub = lane >> LXLOG;
-    const size_t rowpitch = (size_t)P.w * 3;
+    const unsigned pitchb = (unsigned)P.w * 12u;   // bytes per gradient row (< 2^19); all offsets below are unsigned 32 x 32 -> 64
     const float nK1 = -HALF_LOG2E * cinv;
     // issued together with the px load below: one round trip for both tables instead of two dependent ones
 #ifdef BWD_EXP_NOTABLE   // what-if experiment: no table round trip (values are NOT the reference's)
@@ -1373,8 +1404,8 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
         BwdRow R;
         R.m1 = R.m2 = R.k01 = (v2f){0.f, 0.f};
         R.ka2 = R.kb0 = R.kb1 = R.kb2 = 0.f;
-        const int voff = (int)(((size_t)X * 3 + (size_t)rsub * rowpitch) * sizeof(float));
-        const int halfb = (int)((size_t)RPI * rowpitch * sizeof(float));
+        const int voff = (int)((unsigned)X * 12u + (unsigned)rsub * pitchb);
+        const int halfb = (int)((unsigned)RPI * pitchb);
         for (int rb = r0; rb <= r1; rb += 64) {
             const int rend = min(r1, rb + 63);
             __builtin_amdgcn_wave_barrier();
@@ -1386,12 +1417,15 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             __builtin_amdgcn_wave_barrier();
             const float *sp = spy + rsub;
             // buffer resource over the slab from row `rb` on (offsets stay far below 2^31 within a 64-row block)
-            const float *blk = grad + (size_t)(rb - P.row0) * rowpitch;
-            const size_t left = (size_t)(P.row1 - rb) * rowpitch * sizeof(float);
+            const char *blk = reinterpret_cast<const char *>(grad) + (unsigned long long)(unsigned)(rb - P.row0) * pitchb;
+            const unsigned long long left = (unsigned long long)(unsigned)(P.row1 - rb) * pitchb;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
+                const_cast<char *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
             int soff = 0;
-            int Yb = rb;
+            // trip counts up front: the loops below count down (one scalar add + compare + branch per iteration)
+            constexpr int TRIP_SHIFT = 7 - LXLOG;                 // log2(rows per trip) = log2(2 RPI)
+            const int nrows = rend - rb + 1, ntrip = nrows >> TRIP_SHIFT;
+            const int voff_b = voff + halfb;
             // Lanes outside the window sit the trips out (exec mask): the backward is co-limited by the CU's
             // vector-memory pipe (two 768-byte loads per trip and wave, four SIMDs behind one L1), and idle
             // lanes would fetch gradient pixels only to multiply them by zero.
@@ -1399,26 +1433,28 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             // UNROLL: two trips per iteration, four gradient loads in flight before the first is consumed.  Pays
             // for windows of many trips (x8 and up); costs 18 VGPRs = two waves per SIMD, which small windows
             // (x4, 6 trips) need more: the host picks the instantiation (gsasr_splat_backward).
-            for (; UNROLL && Yb + 4 * RPI - 1 <= rend; Yb += 4 * RPI, soff += 4 * halfb, sp += 4 * RPI) {
-                const Grad6 g0 = bwd_load(rsrc, voff, soff, soff + halfb);
-                const Grad6 g1 = bwd_load(rsrc, voff, soff + 2 * halfb, soff + 3 * halfb);
+            int t = ntrip;
+            for (; UNROLL && t >= 2; t -= 2, soff += 4 * halfb, sp += 4 * RPI) {
+                const Grad6 g0 = bwd_load(rsrc, voff, voff_b, soff);
+                const Grad6 g1 = bwd_load(rsrc, voff, voff_b, soff + 2 * halfb);
                 const v2f n0 = {sp[0], sp[RPI]}, n1 = {sp[2 * RPI], sp[3 * RPI]};
                 const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0, w1 = TEST ? (v2f){sp[64 + 2 * RPI], sp[64 + 3 * RPI]} : n1;
                 bwd_trip<TEST, false>(R, g0, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
                 bwd_trip<TEST, false>(R, g1, n1, w1, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
             }
-            for (; Yb + 2 * RPI - 1 <= rend; Yb += 2 * RPI, soff += 2 * halfb, sp += 2 * RPI) {
+            for (; t > 0; --t, soff += 2 * halfb, sp += 2 * RPI) {
                 const v2f n0 = {sp[0], sp[RPI]};
                 const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0;
-                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, soff, soff + halfb), n0, w0, true, true, K0, nK1, rho_u, cr,
+                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr,
                                       cg, cb, P.dmax);
             }
-            if (Yb <= rend) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
+            if (nrows & ((1 << TRIP_SHIFT) - 1)) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
+                const int Yb = rb + (ntrip << TRIP_SHIFT);
                 const int Ya = Yb + rsub, Yc = Ya + RPI;
                 const int ia = min(Ya, rend) - rb, ic = min(Yc, rend) - rb;
                 const v2f n0 = {spy[ia], spy[ic]};
                 const v2f w0 = TEST ? (v2f){spy[64 + ia], spy[64 + ic]} : n0;
-                bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, soff, soff + halfb), n0, w0, Ya <= rend, Yc <= rend, K0, nK1,
+                bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, voff_b, soff), n0, w0, Ya <= rend, Yc <= rend, K0, nK1,
                                      rho_u, cr, cg, cb, P.dmax);
             }
             }
@@ -1473,7 +1509,7 @@ __device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane, float 
 //   d/dx = c/sx qA,  d/dy = c/sy qB,  d/dsx = c/sx quA,  d/dsy = c/sy qvB,  d/drho = c^2 qAB,  c = 1/(1-rho^2),
 // and the colour gradients are the sums themselves.  The constants are applied to the per-lane partials
 // (bwd_scale, five full-wave multiplies by a scalar) so that after the wave reduction lane 8k simply holds
-// output k of {x, y | sx, sy, rho | r, g, b}: three exec-masked stores off scalar bases, no per-lane selects.
+// output k of {x, y | sx, sy, rho | r, g, b} and stores it through a per-lane pointer (bwd_write).
 __device__ __forceinline__ void bwd_scale(float (&a)[8], float c, float isx, float isy)
 {
     const float fx = c * isx, fy = c * isy;
@@ -1485,13 +1521,13 @@ __device__ __forceinline__ void bwd_write(float v, int lane, const Params &P, un
 {
     if (lane & 7) return;
     const int k = lane >> 3;
+    // one store (or atomic) through a per-lane pointer: the three arrays' bases are wave-uniform, pre-biased so that each
+    // is indexed by k, and selected per lane -- three exec-masked branches cost twice the instructions
     float *pc = g_coords + (size_t)i * stride2(P), *ps = g_sigmas + (size_t)i * stride3(P) - 2,
-          *pk = g_colors + (size_t)i * stride3(P) - 5;   // wave-uniform, pre-biased so that every array is indexed by k
-    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) {
-        if (k < 2) pc[k] = v; else if (k < 5) ps[k] = v; else pk[k] = v;
-    } else {  // fire-and-forget atomics: the wave must not end on a load-add-store round trip
-        if (k < 2) atomicAdd(pc + k, v); else if (k < 5) atomicAdd(ps + k, v); else atomicAdd(pk + k, v);
-    }
+          *pk = g_colors + (size_t)i * stride3(P) - 5;
+    float *dst = (k < 2 ? pc : (k < 5 ? ps : pk)) + k;
+    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) *dst = v;
+    else atomicAdd(dst, v);   // fire-and-forget: the wave must not end on a load-add-store round trip
 }
 
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
@@ -1503,7 +1539,7 @@ typedef unsigned u8v __attribute__((ext_vector_type(8)));
 // it will not use the non-coherent scalar cache) issued as three dependent round trips, which was most of a
 // wave's life.  The plan was written by an earlier kernel, so the scalar cache is coherent for it.
 struct BwdRec {
-    u4v bb;    // bbox word 0
+    u8v bb;    // both bbox words: {c0|test|c1, r0|r1, spans.. | spans.., padded rows r0|r1 of the sweep, -}
     u8v rec;   // {x, y, A, B | C, r, g, b}
     u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, px-table offset, sample, index}
 };
@@ -1512,7 +1548,7 @@ __device__ __forceinline__ void bwd_fetch(const PlanView &V, unsigned j, BwdRec 
 {
     const uint4 *pb = V.bbox + 2 * (size_t)j;
     const float4 *pr = V.rec + 2 * (size_t)j, *pf = V.fin + 2 * (size_t)j;
-    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\t"
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\t"
                  "s_load_dwordx8 %1, %4, 0x0\n\t"
                  "s_load_dwordx8 %2, %5, 0x0\n\t"
                  "s_waitcnt lgkmcnt(0)"
@@ -1527,7 +1563,7 @@ __device__ __forceinline__ void bwd_fetch_first(const PlanView &V, const unsigne
     const uint4 *pb = V.bbox + 2 * (size_t)j;
     const float4 *pr = V.rec + 2 * (size_t)j, *pf = V.fin + 2 * (size_t)j;
     asm volatile("s_load_dwordx2 %3, %7, 0x0\n\t"
-                 "s_load_dwordx4 %0, %4, 0x0\n\t"
+                 "s_load_dwordx8 %0, %4, 0x0\n\t"
                  "s_load_dwordx8 %1, %5, 0x0\n\t"
                  "s_load_dwordx8 %2, %6, 0x0\n\t"
                  "s_waitcnt lgkmcnt(0)"
@@ -1542,16 +1578,21 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
                                          float *__restrict__ g_sigmas, float *__restrict__ g_coords,
                                          float *__restrict__ g_colors)
 {
-    const u4v bb = G.bb;
-    const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
-    int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+    const unsigned bbx = G.bb[0];
+    const int c0 = (int)(bbx & 0x7fffu), c1 = (int)(bbx >> 16);
     if (c0 > c1) return;  // dead class (handled by the caller)
+    int r0, r1;
     bool empty = false;
-    if (chunk >= 0) {
+    if (chunk >= 0) {  // (row chunks of a large Gaussian must not overlap: they split the window's own rows)
+        r0 = (int)(G.bb[1] & 0x7fffu);
+        r1 = (int)(G.bb[1] >> 16);
         const int rpc = (r1 - r0 + NCH) / NCH;
         r0 = r0 + chunk * rpc;
         r1 = min(r1, r0 + rpc - 1);
         empty = r0 > r1;   // still counted as a finished chunk below
+    } else {           // the plan's padded row range (whole trips; k_bin)
+        r0 = (int)(G.bb[6] & 0xffffu);
+        r1 = (int)(G.bb[6] >> 16);
     }
     const float x = __uint_as_float(G.rec[0]), y = __uint_as_float(G.rec[1]);
     const float cr = __uint_as_float(G.rec[5]), cg = __uint_as_float(G.rec[6]), cb = __uint_as_float(G.rec[7]);
@@ -1560,24 +1601,7 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
     const float4 fb = make_float4(__uint_as_float(G.fin[4]), 0.f, 0.f, 0.f);   // {1/sy, ..}
     float a[8];
     const int bw = c1 - c0 + 1;
-    if (chunk < 0) {  // (row chunks of a large Gaussian must not overlap: they keep their ragged tail)
-        // Round the row count up to a whole number of trips (8/4/2 rows for 16/32/64-lane columns) when the
-        // band has room: the extra rows lie outside the window (their terms are < exp(-tau), or fail the
-        // dmax test), and the ragged, masked last trip disappears.
-        const int rows_per_trip = bw <= 16 ? 8 : (bw <= 32 ? 4 : 2);
-        const int pad = (rows_per_trip - ((r1 - r0 + 1) & (rows_per_trip - 1))) & (rows_per_trip - 1);
-        // (batched canvas: stay inside the sample's own rows -- whatever gradient the caller left in the padding
-        // of the slot must not be read)
-        int lo = P.row0, hi = P.row1 - 1;
-        if (P.batch > 1) {
-            const int4 gg = V.geo[G.fin[6]];
-            lo = gg.z;
-            hi = gg.z + gg.x - 1;
-        }
-        if (r1 + pad <= hi) r1 += pad;
-        else if (r0 - pad >= lo) r0 -= pad;
-    }
-    const bool test = BOUNDED && (bb.x & 0x8000u);
+    const bool test = BOUNDED && (bbx & 0x8000u);
     float d = 0.f;
     if (!empty) {
 #define GSASR_SWEEP(T, L) \
@@ -1633,7 +1657,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #ifdef BWD_EXP_NOFETCH   // what-if experiment: a synthetic record instead of the scalar fetch (results are meaningless)
     {
         const unsigned c0 = (gw * 4u) % 1000u, r0 = ((gw >> 8) * 4u) % 1000u;
-        G.bb = (u4v){c0 | ((c0 + 22u) << 16), r0 | ((r0 + 22u) << 16), 0u, 0u};
+        G.bb = (u8v){c0 | ((c0 + 22u) << 16), r0 | ((r0 + 22u) << 16), 0u, 0u, 0u, 0u, r0 | ((r0 + 23u) << 16), 0u};
         const float fx = (float)(c0 + 11u) * (2.f / 1023.f) - 1.f, fy = (float)(r0 + 11u) * (2.f / 1023.f) - 1.f;
         G.rec = (u8v){__float_as_uint(fx), __float_as_uint(fy), 0u, 0u, 0u, 0x3f000000u, 0x3f000000u, 0x3f000000u};
         G.fin = (u8v){0x3f800000u, 0x3f800000u, 0u, __float_as_uint(150.f), __float_as_uint(150.f), 0u, 0u, gw};
