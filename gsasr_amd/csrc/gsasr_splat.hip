@@ -75,6 +75,12 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #ifndef BWD_UNROLL_OCC
 #define BWD_UNROLL_OCC 6
 #endif
+#ifndef BWD_PAIR
+#define BWD_PAIR 0
+#endif
+#ifndef BWD_PAIR_OCC
+#define BWD_PAIR_OCC 6
+#endif
 #ifndef BWD_UNROLL_MIN
 #define BWD_UNROLL_MIN 32.0
 #endif
@@ -895,6 +901,13 @@ __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int 
         const float4 a0 = st[2 * i], b0 = st[2 * i + 1], a1 = st[2 * i + 2], b1 = st[2 * i + 3];
         fwd_eval_one<TEST>(a0, b0, px, py, dmax, ar, ag, ab);
         fwd_eval_one<TEST>(a1, b1, px, py, dmax, ar, ag, ab);
+#ifdef FWD_EXP_SPAD      // what-if experiment: extra scalar instructions per record pair
+        {
+            int sp0 = 1;
+#pragma unroll
+            for (int k = 0; k < FWD_EXP_SPAD; ++k) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sp0) : : "scc");
+        }
+#endif
     }
     if (i < end) fwd_eval_one<TEST>(st[2 * i], st[2 * i + 1], px, py, dmax, ar, ag, ab);
 }
@@ -1682,6 +1695,191 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
         bwd_item<BOUNDED, UNROLL>(j, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
     }
 }
+
+#if BWD_PAIR
+// ---------------------------------------------------------------------------------------------------
+// backward, Gaussian-stationary, TWO Gaussians per wave (k_render_bwd_pair).
+//
+// MEASURED DEAD END, compiled only with -DBWD_PAIR=1 (tools/build_mb.sh pair -DBWD_PAIR=1): 39.9 us against 37.0 us at
+// config 2, 294 against 296 us at config 5 -- although it issues 22% fewer instructions per Gaussian.  The backward is
+// bound by the CU's texture path, which spends ~17 cycles on every 96/128-bit wave-load whatever its lane mask
+// (tools/ta_rate.hip; TA 83% / TD 94% busy), and a pair's load instruction still carries two window rows.  DESIGN.md 3c.
+//
+// At x4 about half of a wave's instructions are per-Gaussian fixed work:
+// launch, fetch, window decode, tables, expansion, wave reduction, store.  Here the two halves of a wave take the two
+// cell-adjacent Gaussians of slots 2p and 2p+1 (windows of at most 32 columns and 64 rows -- 95% of the pairs at x4),
+// so all of that is issued once per PAIR: what was wave-uniform (SGPR) per Gaussian becomes per-lane data loaded by
+// each half, lane = (half, column), two adjacent rows per trip in packed fp32 exactly as in bwd_sweep's 32-column
+// layout (same bwd_trip, same residual-form sums, same expansion).  The halves run min(trips) trips together and the
+// one with the taller window finishes alone under an exec mask set once.  The wave reduction through LDS yields the
+// eight sums of each half in lanes 8k (first Gaussian) and 8k+4 (second).  Pairs that do not qualify, the large and
+// the dead class fall back to bwd_item, one slot after the other.
+// ---------------------------------------------------------------------------------------------------
+template <bool TEST>
+__device__ __forceinline__ void bwd_pair(int lane, const Params &P, const PlanView &V, const float *__restrict__ grad,
+                                         float *spy, float *red, unsigned bbx, unsigned rowsw, float2 ra, float4 rb,
+                                         float4 fa, float4 fb, float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                         float *__restrict__ g_colors)
+{
+    constexpr float HALF_LOG2E = 0.72134752044448170368f;
+    constexpr float POISON = 1e18f;   // a row value that drives the exponent to -inf and keeps every product finite
+    const int h = lane >> 5, col = lane & 31;
+    const int c0 = (int)(bbx & 0x7fffu), bw = (int)(bbx >> 16) - c0 + 1;
+    const int r0 = (int)(rowsw & 0xffffu), r1 = (int)(rowsw >> 16), nrows = r1 - r0 + 1;
+    const float x = ra.x, y = ra.y, cr = rb.y, cg = rb.z, cb = rb.w;
+    const float cinv = fa.x, kappa = fa.y, rho = fa.z, isx = fa.w, isy = fb.x;
+    const float *pxt = V.px + __float_as_uint(fb.y);
+    const int X = c0 + min(col, bw - 1);
+    // the three table reads in one round trip
+    const float pxv = pxt[X];
+    const float py0 = V.py[min(r0 + col, r1)], py1 = V.py[min(r0 + 32 + col, r1)];
+    const float dx = pxv - x;
+    const bool inx = col < bw && (!TEST || fabsf(dx) <= P.dmax);
+    const float u = dx * isx, rho_u = rho * u;
+    const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;
+    const float nK1 = -HALF_LOG2E * cinv;
+    // per-row values of each half's window (<= 64 rows): v = dy/sy, and (TEST) the raw dy for the exact box test; rows
+    // past the window's end are poisoned (v = 0 exactly there: the second row of an odd window's last trip)
+    float *sp = spy + h * 64;
+    __builtin_amdgcn_wave_barrier();
+    sp[col] = col < nrows ? (py0 - y) * isy : POISON;
+    sp[32 + col] = 32 + col < nrows ? (py1 - y) * isy : POISON;
+    if (TEST) {
+        sp[128 + col] = col < nrows ? py0 - y : POISON;
+        sp[160 + col] = 32 + col < nrows ? py1 - y : POISON;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int ntrip = (nrows + 1) >> 1;
+    const int nA = __builtin_amdgcn_readlane(ntrip, 0), nB = __builtin_amdgcn_readlane(ntrip, 32);
+    const int nmin = min(nA, nB), nmax = max(nA, nB);
+    // one buffer resource over the whole slab (the caller checked that it is addressable with 31 bits)
+    const unsigned pitchb = (unsigned)P.w * 12u;
+    const unsigned long long slab = (unsigned long long)(unsigned)(P.row1 - P.row0) * pitchb;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad), 0, (int)slab, 0x00020000);
+    const int voff_a = (int)((unsigned)X * 12u + (unsigned)(r0 - P.row0) * pitchb), voff_b = voff_a + (int)pitchb;
+    const int step = (int)(2u * pitchb);
+    BwdRow R;
+    R.m1 = R.m2 = R.k01 = (v2f){0.f, 0.f};
+    R.ka2 = R.kb0 = R.kb1 = R.kb2 = 0.f;
+    if (inx) {
+        int soff = 0;
+        const float *q = sp;
+        for (int t = nmin; t > 0; --t, soff += step, q += 2) {
+            const v2f n0 = {q[0], q[1]};
+            const v2f w0 = TEST ? (v2f){q[128], q[129]} : n0;
+            bwd_trip<TEST, false>(R, bwd_load(rsrc, voff_a, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
+        }
+        if (ntrip > nmin) {   // the taller window of the two finishes alone
+            for (int t = nmax - nmin; t > 0; --t, soff += step, q += 2) {
+                const v2f n0 = {q[0], q[1]};
+                const v2f w0 = TEST ? (v2f){q[128], q[129]} : n0;
+                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff_a, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
+            }
+        }
+    }
+    // expansion of the column's sums, as in bwd_sweep, with per-lane Gaussian constants
+    const float Kr = R.k01.x + R.kb0, Kg = R.k01.y + R.kb1, Kb = R.ka2 + R.kb2;
+    const float M0 = fmaf(Kb, cb, fmaf(Kg, cg, Kr * cr)), N1 = R.m1.x + R.m1.y, N2 = R.m2.x + R.m2.y;
+    const float ue = inx ? u : 0.f, uk = ue * kappa;
+    const float sA = uk * M0 - rho * N1;
+    float a[8] = {sA, N1, ue * sA, N2 + rho * ue * N1, uk * N1 - rho * N2, Kr, Kg, Kb};
+    bwd_scale(a, cinv, isx, isy);
+    // wave reduction through LDS, per half: lane l adds the 8 consecutive partials {l&7} of value {l>>3} (source lanes
+    // 8(l&7) .. +7: the first Gaussian's for l&7 < 4), then two butterfly steps inside each 4-lane group
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k * 64 + lane] = a[k];
+    __builtin_amdgcn_wave_barrier();
+    const float4 s0 = *reinterpret_cast<const float4 *>(red + lane * 8);
+    const float4 s1 = *reinterpret_cast<const float4 *>(red + lane * 8 + 4);
+    float d = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w));
+    d += dpp_row_shl<2>(d);
+    d += dpp_row_shl<1>(d);
+    // lanes 8k hold component k of the first Gaussian, lanes 8k+4 of the second
+    if (lane & 3) return;
+    const unsigned iA = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(fb.w), 0);
+    const unsigned iB = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(fb.w), 32);
+    const unsigned i = (lane & 4) ? iB : iA;
+    const int k = lane >> 3;
+    float *pc = g_coords + (size_t)i * stride2(P), *ps = g_sigmas + (size_t)i * stride3(P) - 2,
+          *pk = g_colors + (size_t)i * stride3(P) - 5;
+    float *dst = (k < 2 ? pc : (k < 5 ? ps : pk)) + k;
+    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) *dst = d;
+    else atomicAdd(dst, d);
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(BWD_PAIR_OCC))) void k_render_bwd_pair(
+    Params P, PlanView V, const float *__restrict__ grad, float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+    float *__restrict__ g_colors)
+{
+    const int lane = threadIdx.x & 63;
+    // XCD-aware order as in k_render_bwd: each XCD sweeps a contiguous run of the cell-ordered Gaussians
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
+    const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned gw = t * (unsigned)BWD_WAVES + (unsigned)wv;      // this wave: slots 2 gw, 2 gw + 1
+    const unsigned nwaves = nb * (unsigned)BWD_WAVES;
+    __shared__ float s_py[BWD_WAVES][256];  // per wave and half: v = dy/sy of <= 64 rows, then (TEST) the raw dy
+    __shared__ __attribute__((aligned(16))) float s_red[BWD_WAVES][512];
+    float *spy = s_py[wv], *red = s_red[wv];
+    const unsigned j0 = 2u * gw, s = (unsigned)P.s;
+    // per-lane records of the half's Gaussian (speculative: the classes are checked below)
+    const unsigned j = min(j0 + (unsigned)(lane >> 5), s - 1u);
+    const unsigned bbx = reinterpret_cast<const unsigned *>(V.bbox)[8 * (size_t)j];
+    const unsigned rowsw = reinterpret_cast<const unsigned *>(V.bbox)[8 * (size_t)j + 6];
+    const float2 ra = *reinterpret_cast<const float2 *>(V.rec + 2 * (size_t)j);
+    const float4 rb = V.rec[2 * (size_t)j + 1];
+    const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
+    u2v lim;
+    {
+        const unsigned *bounds = V.cell_start + P.ncells;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(lim) : "s"(bounds) : "memory");
+    }
+    const unsigned large_beg = lim.x, large_end = lim.y;
+    bool paired = false;
+    if (j0 + 1u < large_beg) {   // both slots in the normal class
+        const int bw = (int)(bbx >> 16) - (int)(bbx & 0x7fffu) + 1;
+        const int nrows = (int)(rowsw >> 16) - (int)(rowsw & 0xffffu) + 1;
+        const bool fits = bw >= 1 && bw <= 32 && nrows <= 64;
+        if (__ballot(fits) == ~0ull) {
+            paired = true;
+            if (BOUNDED && __ballot((bbx & 0x8000u) != 0u) != 0ull)
+                bwd_pair<true>(lane, P, V, grad, spy, red, bbx, rowsw, ra, rb, fa, fb, g_sigmas, g_coords, g_colors);
+            else
+                bwd_pair<false>(lane, P, V, grad, spy, red, bbx, rowsw, ra, rb, fa, fb, g_sigmas, g_coords, g_colors);
+        }
+    }
+    BwdRec G;
+#ifdef BWD_EXP_PAIRONLY   // what-if experiment: no fallback (pairs that do not qualify are skipped: wrong results)
+    return;
+#endif
+    if (!paired) {
+#pragma unroll 1
+        for (unsigned k = 0; k < 2u; ++k) {
+            const unsigned jj = j0 + k;
+            if (jj >= s) break;
+            bwd_fetch(V, jj, G);
+            if (jj < large_beg)
+                bwd_item<BOUNDED, false>(jj, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+            else if (jj < large_end)
+                bwd_item<BOUNDED, false>(jj, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+            else if (P.flags & GSASR_FLAG_OVERWRITE_GRADS)   // dead class: the gradient is zero
+                bwd_write(0.f, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
+        }
+    }
+    // remaining row chunks of the large class, spread over all waves
+    const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
+    for (unsigned it = gw; it < extra; it += nwaves) {
+        const unsigned jl = large_beg + it / (unsigned)(NCH - 1);
+        const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
+        bwd_fetch(V, jl, G);
+        bwd_item<BOUNDED, false>(jl, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+    }
+}
+
+#endif  // BWD_PAIR
 
 // ---------------------------------------------------------------------------------------------------
 // backward, TILE-stationary (BASELINE.json north_star's shape: a workgroup owns an HR tile, stages its grad_img ONCE
@@ -2887,6 +3085,19 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
         // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
         const bool unroll = (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
+        // (experiment, off by default: two Gaussians per wave for small windows -- k_render_bwd_pair; its single buffer
+        // resource spans the slab, which must then be addressable with 31 bits)
+#if BWD_PAIR
+        const bool pair = !unroll && (double)rows * (double)dims->w * 12.0 < 2147483647.0;
+        if (pair) {
+            const unsigned per = 2u * (unsigned)BWD_WAVES;
+            const dim3 pgrid(((unsigned)dims->s + per - 1u) / per);
+            if (P.bounded) hipLaunchKernelGGL(k_render_bwd_pair<true>, pgrid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
+            else hipLaunchKernelGGL(k_render_bwd_pair<false>, pgrid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
+            HIP_TRY(hipGetLastError());
+            return GSASR_OK;
+        }
+#endif
 #define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
         if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
         else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
