@@ -78,6 +78,12 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #ifndef BWD_PAIR
 #define BWD_PAIR 0
 #endif
+#ifndef FWD_TALL_ROWS
+#define FWD_TALL_ROWS 4     // sub-tile rows per workgroup tile at large scale factors
+#endif
+#ifndef FWD_TALL_MIN
+#define FWD_TALL_MIN 200.0   // HR pixels per Gaussian from which the tall tile is used (x24: -11%; x12, x8: no gain)
+#endif
 #ifndef BWD_PAIR_OCC
 #define BWD_PAIR_OCC 6
 #endif
@@ -182,6 +188,17 @@ int classify_blocks(const gsasr_dims *d)
 }
 
 // which backward kernel: explicit flag > environment GSASR_SPLAT_BWD (gaussian | tile | atomic; development A/B) > default
+// development switch (like GSASR_SPLAT_BWD): GSASR_SPLAT_FWD_TALL=0 / 1 forces the tall forward tile off / on
+int fwd_tall_env()
+{
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("GSASR_SPLAT_FWD_TALL");
+        v = !e ? -1 : atoi(e) != 0;
+    }
+    return v;
+}
+
 int bwd_env()
 {
     static int v = -1;
@@ -896,6 +913,10 @@ template <bool TEST>
 __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int beg, int end, float px, v2f py,
                                              float dmax, v2f &ar, v2f &ag, v2f &ab)
 {
+#ifdef FWD_EXP_NOEVAL    // what-if experiment: everything but the evaluation (one record per call keeps the staging alive)
+    if (beg < end) fwd_eval_one<TEST>(st[2 * beg], st[2 * beg + 1], px, py, dmax, ar, ag, ab);
+    return;
+#endif
     int i = beg;
     for (; i + 1 < end; i += 2) {   // two records per iteration so their dependent chains interleave
         const float4 a0 = st[2 * i], b0 = st[2 * i + 1], a1 = st[2 * i + 2], b1 = st[2 * i + 3];
@@ -1048,22 +1069,32 @@ constexpr int COARSE_LIST = 4 * COARSE_CHUNKS * 64;       // candidates per roun
 
 // PARTS = 2: eight waves per workgroup, two per sub-tile taking alternate chunks of the survivor list (images with
 // fewer sub-tiles than the chip has wave slots); the caller adds the two partial sums.
-template <bool BOUNDED, int PARTS>
+// ROWS > 1 (large scale factors, single images): the workgroup's tile is 32 x 16 ROWS pixels -- the cooperative
+// level 1 runs once for ROWS sub-tile rows, and every wave then takes its column of ROWS sub-tiles one after the other
+// (same px, its own py, its own accumulators).  At x24 finding the hits was 37% of the forward (one candidate per
+// 2.3 cells, 17 x 17 cells within reach of a tile: segment table, candidate lookup and window tests are per TILE work).
+template <bool BOUNDED, int PARTS, int ROWS>
 __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, int bx0, int by0, int wv, int lane,
-                                          float4 *stage, unsigned *s_list, unsigned *s_cnt, v2f &ar, v2f &ag, v2f &ab)
+                                          float4 *stage, unsigned *s_list, unsigned *s_cnt, v2f (&ar)[ROWS], v2f (&ag)[ROWS],
+                                          v2f (&ab)[ROWS])
 {
-    const int bx1 = min(bx0 + 4 * SUBX - 1, P.w - 1), by1 = min(by0 + SUBY - 1, P.row1 - 1);
-    const int sx0 = bx0 + (wv & 3) * SUBX, sy0 = by0;
+    const int bx1 = min(bx0 + 4 * SUBX - 1, P.w - 1), by1 = min(by0 + ROWS * SUBY - 1, P.row1 - 1);
+    const int sx0 = bx0 + (wv & 3) * SUBX;
     const unsigned part = (unsigned)(wv >> 2);
     const bool live = sx0 < P.w;                              // wave-uniform (image width not a multiple of 32)
-    const int sx1 = min(sx0 + SUBX - 1, P.w - 1), sy1 = by1;
-    const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
-    const float px = V.px[(P.batch > 1 ? (sy0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
-    const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y1, P.h - 1)]};
+    const int sx1 = min(sx0 + SUBX - 1, P.w - 1);
+    const int X = sx0 + (lane & 7);
+    const float px = V.px[(P.batch > 1 ? (by0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
+    v2f pyr[ROWS];
+#pragma unroll
+    for (int sr = 0; sr < ROWS; ++sr) {
+        const int Y0 = by0 + sr * SUBY + (lane >> 3);
+        pyr[sr] = (v2f){V.py[min(Y0, P.h - 1)], V.py[min(Y0 + 8, P.h - 1)]};
+    }
     const float4 *__restrict__ rec = V.rec;
     const uint4 *__restrict__ bbox = V.bbox;
     const unsigned *__restrict__ cs = V.cell_start;
-    const int wty = (sy0 - P.row0) >> SUBY_SHIFT, wtx = sx0 >> SUBX_SHIFT;
+    const int wtx = sx0 >> SUBX_SHIFT;
 
     // segment table of the 32x16 tile (every wave builds the same one: a single vector round trip)
     const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
@@ -1123,8 +1154,13 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
         __syncthreads();
         if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0u;   // nobody touches the other counter before the next barrier
         const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)*cnt);
-        // ---- phase B: the full test of the tile's survivors against this wave's sub-tile ----------------
-        if (live) {
+        // ---- phase B: the full test of the tile's survivors against this wave's sub-tile(s) -------------
+#pragma unroll
+        for (int sr = 0; sr < ROWS; ++sr) {
+        const int sy0 = by0 + sr * SUBY, sy1 = min(sy0 + SUBY - 1, P.row1 - 1);
+        const int wty = (sy0 - P.row0) >> SUBY_SHIFT;
+        const v2f py = pyr[sr];
+        if (live && (ROWS == 1 || sy0 < P.row1)) {
             const unsigned q0 = part * 64u;
             unsigned j = q0 + lane < n ? s_list[q0 + lane] : 0xffffffffu;
             const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);
@@ -1164,11 +1200,12 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
                         stage[2 * slot + 1] = src[1];
                     }
                     __builtin_amdgcn_wave_barrier();
-                    fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
-                    if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
+                    fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar[sr], ag[sr], ab[sr]);
+                    if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar[sr], ag[sr], ab[sr]);
                 }
                 j = nj; bb = nbb; bs = nbs;
             }
+        }
         }
         __syncthreads();   // the list is rewritten in the next round
     }
@@ -1179,6 +1216,9 @@ __device__ __forceinline__ void fwd_store(const Params &P, const PlanView &V, fl
 {
     const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
     if (X >= P.w) return;
+#ifdef FWD_EXP_NOSTORE   // what-if experiment: (almost) no image traffic
+    if (ar.x != 12345.f) return;
+#endif
     const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
     bool ok0 = Y0 < P.row1, ok1 = Y1 < P.row1;
     // CHW: planar [3, rows, w]; batched canvas: [B, 3, slot, w] (HWC is simply the canvas [B*slot, w, 3])
@@ -1229,9 +1269,10 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nb)
 
 // Two-level walk (fwd_block).  PARTS = 1: large images, the workgroup shape of k_render_fwd.  PARTS = 2: images
 // with fewer sub-tiles than wave slots -- eight waves, two per sub-tile, partial sums combined through LDS.
-template <bool BOUNDED, int PARTS>
+template <bool BOUNDED, int PARTS, int ROWS>
 __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView V, float *__restrict__ img, int tiles_x)
 {
+    static_assert(PARTS == 1 || ROWS == 1, "two waves per sub-tile only with one sub-tile row");
     const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
     const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
     const int lane = threadIdx.x & 63;
@@ -1242,21 +1283,27 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView 
     __shared__ float s_part[PARTS > 1 ? 4 : 1][6][64];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
-    const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
-    fwd_block<BOUNDED, PARTS>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
+    v2f ar[ROWS], ag[ROWS], ab[ROWS];
+#pragma unroll
+    for (int sr = 0; sr < ROWS; ++sr) ar[sr] = ag[sr] = ab[sr] = (v2f){0.f, 0.f};
+    const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY * ROWS;
+    fwd_block<BOUNDED, PARTS, ROWS>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
     const int sub = wv & 3;
     if (PARTS > 1) {   // (fwd_block ends on a barrier)
         if (wv >= 4) {
             float (*o)[64] = s_part[sub];
-            o[0][lane] = ar.x; o[1][lane] = ar.y; o[2][lane] = ag.x; o[3][lane] = ag.y; o[4][lane] = ab.x; o[5][lane] = ab.y;
+            o[0][lane] = ar[0].x; o[1][lane] = ar[0].y; o[2][lane] = ag[0].x; o[3][lane] = ag[0].y; o[4][lane] = ab[0].x; o[5][lane] = ab[0].y;
         }
         __syncthreads();
         if (wv >= 4) return;
         float (*o)[64] = s_part[sub];
-        ar.x += o[0][lane]; ar.y += o[1][lane]; ag.x += o[2][lane]; ag.y += o[3][lane]; ab.x += o[4][lane]; ab.y += o[5][lane];
+        ar[0].x += o[0][lane]; ar[0].y += o[1][lane]; ag[0].x += o[2][lane]; ag[0].y += o[3][lane]; ab[0].x += o[4][lane]; ab[0].y += o[5][lane];
     }
-    if (bx0 + sub * SUBX < P.w) fwd_store(P, V, img, bx0 + sub * SUBX, by0, lane, ar, ag, ab);
+    if (bx0 + sub * SUBX < P.w) {
+#pragma unroll
+        for (int sr = 0; sr < ROWS; ++sr)
+            if (ROWS == 1 || by0 + sr * SUBY < P.row1) fwd_store(P, V, img, bx0 + sub * SUBX, by0 + sr * SUBY, lane, ar[sr], ag[sr], ab[sr]);
+    }
 }
 
 // Small images (fewer sub-tiles than the chip has wave slots, e.g. the 192x192 training crops of
@@ -3011,13 +3058,20 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         // of config 5) get two waves per sub-tile (measured -13% at 4608 sub-tiles, +2..14% above 8192)
         const int tx4 = (subs_x + 3) / 4;
         const bool two = nsub < 8192;
-        const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
+        // Large scale factors (from FWD_TALL_MIN HR pixels per Gaussian, single images with plenty of tiles): tiles of
+        // 32 x 64 pixels -- the per-tile search is shared by four sub-tile rows (fwd_block)
+        const bool tall = !two && dims->batch <= 1 && nsub >= 4 * 8192 && fwd_tall_env() != 0 &&
+                          (fwd_tall_env() == 1 || (double)rows * (double)dims->w >= FWD_TALL_MIN * (double)dims->s);
+        const int ty = tall ? (tiles_y + FWD_TALL_ROWS - 1) / FWD_TALL_ROWS : tiles_y;
+        const dim3 grid((unsigned)tx4 * (unsigned)ty), block(two ? 512 : 256);
         if (P.bounded) {
-            if (two) hipLaunchKernelGGL((k_render_fwd2<true, 2>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd2<true, 1>), grid, block, 0, st, P, V, img, tx4);
+            if (two) hipLaunchKernelGGL((k_render_fwd2<true, 2, 1>), grid, block, 0, st, P, V, img, tx4);
+            else if (tall) hipLaunchKernelGGL((k_render_fwd2<true, 1, FWD_TALL_ROWS>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd2<true, 1, 1>), grid, block, 0, st, P, V, img, tx4);
         } else {
-            if (two) hipLaunchKernelGGL((k_render_fwd2<false, 2>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd2<false, 1>), grid, block, 0, st, P, V, img, tx4);
+            if (two) hipLaunchKernelGGL((k_render_fwd2<false, 2, 1>), grid, block, 0, st, P, V, img, tx4);
+            else if (tall) hipLaunchKernelGGL((k_render_fwd2<false, 1, FWD_TALL_ROWS>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd2<false, 1, 1>), grid, block, 0, st, P, V, img, tx4);
         }
     }
     HIP_TRY(hipGetLastError());
