@@ -263,14 +263,21 @@ class BandExchange:
                            self.counts)
         return self.g_records[: self.n]
 
-    def _swap(self, to_above, from_above, to_below, from_below):
-        ops = []
-        if self.rank > 0:
-            ops += [dist.P2POp(dist.isend, to_above, self._peer(self.rank - 1), self.group),
-                    dist.P2POp(dist.irecv, from_above, self._peer(self.rank - 1), self.group)]
-        if self.rank < self.world - 1:
-            ops += [dist.P2POp(dist.isend, to_below, self._peer(self.rank + 1), self.group),
-                    dist.P2POp(dist.irecv, from_below, self._peer(self.rank + 1), self.group)]
+    def _swap(self, key, to_above, from_above, to_below, from_below):
+        # the four P2POps of a direction always name the same buffers and peers: built once (this runs twice per step
+        # on the host, in front of kernels that take tens of microseconds)
+        ops = self._ops.get(key) if hasattr(self, "_ops") else None
+        if ops is None:
+            ops = []
+            if self.rank > 0:
+                ops += [dist.P2POp(dist.isend, to_above, self._peer(self.rank - 1), self.group),
+                        dist.P2POp(dist.irecv, from_above, self._peer(self.rank - 1), self.group)]
+            if self.rank < self.world - 1:
+                ops += [dist.P2POp(dist.isend, to_below, self._peer(self.rank + 1), self.group),
+                        dist.P2POp(dist.irecv, from_below, self._peer(self.rank + 1), self.group)]
+            if not hasattr(self, "_ops"):
+                self._ops = {}
+            self._ops[key] = ops
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
@@ -282,14 +289,14 @@ class BandExchange:
         """own Gaussians are in `self.own`; returns `records` with the neighbours' halos in place."""
         self.version = getattr(self, "version", 0) + 1
         self.select()
-        self._swap(self.send_up, self.from_above, self.send_down, self.from_below)
+        self._swap("fwd", self.send_up, self.from_above, self.send_down, self.from_below)
         return self.records
 
     def exchange_backward(self) -> torch.Tensor:
         """`self.g_records` holds the local backward's output; returns the complete gradients of the own
         Gaussians (`[n_local,8]` view of `g_records`)."""
         n, c = self.n, self.cap
-        self._swap(self.g_records[n:n + c], self.ret_up, self.g_records[n + c:], self.ret_down)
+        self._swap("bwd", self.g_records[n:n + c], self.ret_up, self.g_records[n + c:], self.ret_down)
         return self.merge()
 
     def incomplete(self) -> torch.Tensor:
