@@ -43,6 +43,13 @@ python $R/tools/rocpd_summary.py /tmp/ktg4_$TAG/kt_results.db --skip 1 > $OUT/ke
 unset GSASR_SPLAT_BWD
 rocprofv3 --kernel-trace --stats -d /tmp/kt4_$TAG -o kt -- $BENCH --config c4 --steps 5 --warmup 2 > /dev/null 2> $OUT/kt4.err
 python $R/tools/rocpd_summary.py /tmp/kt4_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c4.txt
+# 3b. kernel traces of the other BASELINE configs (config 3: forward only; config 5: the batched canvas)
+if [ -z "${ONLY_EXTRA_TRACES:-}" ] || true; then
+rocprofv3 --kernel-trace --stats -d /tmp/kt3_$TAG -o kt -- $BENCH --config c3 --steps 10 --warmup 3 > /dev/null 2> $OUT/kt3.err
+python $R/tools/rocpd_summary.py /tmp/kt3_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c3.txt
+rocprofv3 --kernel-trace --stats -d /tmp/kt5_$TAG -o kt -- $BENCH --config c5 > /dev/null 2> $OUT/kt5.err
+python $R/tools/rocpd_summary.py /tmp/kt5_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c5.txt
+fi
 # 4. the plain bench line (with exact / dropin / cpu_baseline)
 cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/kernel_stats.txt $OUT/pmc_fetch.txt $OUT/pmc_write.txt
