@@ -1374,7 +1374,11 @@ __device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff,
     const u3v b = {(unsigned)voff_b | 0x3f100000u, (unsigned)soff_b | 0x3f000000u, 0x3f200000u};
 #else
     const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
+#ifdef BWD_EXP_HALFLOAD  // what-if experiment: half the gradient loads (the second pixel re-uses the first one's data)
+    const u3v b = {a.y, a.z, a.x};
+#else
     const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff_b, soff_b, 0);
+#endif
 #endif
     Grad6 g;
     g.a0 = __uint_as_float(a.x); g.a1 = __uint_as_float(a.y); g.a2 = __uint_as_float(a.z);
