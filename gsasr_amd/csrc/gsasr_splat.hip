@@ -75,17 +75,11 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #ifndef BWD_UNROLL_OCC
 #define BWD_UNROLL_OCC 6
 #endif
-#ifndef BWD_PAIR
-#define BWD_PAIR 0
-#endif
 #ifndef FWD_TALL_ROWS
 #define FWD_TALL_ROWS 4     // sub-tile rows per workgroup tile at large scale factors
 #endif
 #ifndef FWD_TALL_MIN
 #define FWD_TALL_MIN 200.0   // HR pixels per Gaussian from which the tall tile is used (x24: -11%; x12, x8: no gain)
-#endif
-#ifndef BWD_PAIR_OCC
-#define BWD_PAIR_OCC 6
 #endif
 #ifndef BWD_UNROLL_MIN
 #define BWD_UNROLL_MIN 32.0
@@ -191,20 +185,24 @@ int classify_blocks(const gsasr_dims *d)
 // development switch (like GSASR_SPLAT_BWD): GSASR_SPLAT_FWD_TALL=0 / 1 forces the tall forward tile off / on
 int fwd_tall_env()
 {
-    static int v = -2;
+    static std::atomic<int> cached{-2};   // -2 = not read yet; a race re-reads the same environment: benign
+    int v = cached.load(std::memory_order_relaxed);
     if (v == -2) {
         const char *e = getenv("GSASR_SPLAT_FWD_TALL");
         v = !e ? -1 : atoi(e) != 0;
+        cached.store(v, std::memory_order_relaxed);
     }
     return v;
 }
 
 int bwd_env()
 {
-    static int v = -1;
+    static std::atomic<int> cached{-1};
+    int v = cached.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("GSASR_SPLAT_BWD");
         v = !e ? 0 : !strcmp(e, "gaussian") ? 1 : !strcmp(e, "tile") ? 2 : !strcmp(e, "atomic") ? 3 : 0;
+        cached.store(v, std::memory_order_relaxed);
     }
     return v;
 }
@@ -913,22 +911,11 @@ template <bool TEST>
 __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int beg, int end, float px, v2f py,
                                              float dmax, v2f &ar, v2f &ag, v2f &ab)
 {
-#ifdef FWD_EXP_NOEVAL    // what-if experiment: everything but the evaluation (one record per call keeps the staging alive)
-    if (beg < end) fwd_eval_one<TEST>(st[2 * beg], st[2 * beg + 1], px, py, dmax, ar, ag, ab);
-    return;
-#endif
     int i = beg;
     for (; i + 1 < end; i += 2) {   // two records per iteration so their dependent chains interleave
         const float4 a0 = st[2 * i], b0 = st[2 * i + 1], a1 = st[2 * i + 2], b1 = st[2 * i + 3];
         fwd_eval_one<TEST>(a0, b0, px, py, dmax, ar, ag, ab);
         fwd_eval_one<TEST>(a1, b1, px, py, dmax, ar, ag, ab);
-#ifdef FWD_EXP_SPAD      // what-if experiment: extra scalar instructions per record pair
-        {
-            int sp0 = 1;
-#pragma unroll
-            for (int k = 0; k < FWD_EXP_SPAD; ++k) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sp0) : : "scc");
-        }
-#endif
     }
     if (i < end) fwd_eval_one<TEST>(st[2 * i], st[2 * i + 1], px, py, dmax, ar, ag, ab);
 }
@@ -1216,9 +1203,6 @@ __device__ __forceinline__ void fwd_store(const Params &P, const PlanView &V, fl
 {
     const int X = sx0 + (lane & 7), Y0 = sy0 + (lane >> 3), Y1 = Y0 + 8;
     if (X >= P.w) return;
-#ifdef FWD_EXP_NOSTORE   // what-if experiment: (almost) no image traffic
-    if (ar.x != 12345.f) return;
-#endif
     const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
     bool ok0 = Y0 < P.row1, ok1 = Y1 < P.row1;
     // CHW: planar [3, rows, w]; batched canvas: [B, 3, slot, w] (HWC is simply the canvas [B*slot, w, 3])
@@ -1369,17 +1353,8 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int voff_b, int soff_a)
 {
     const int soff_b = soff_a;
-#ifdef BWD_EXP_NOLOAD   // what-if experiment (tools/build_mb.sh): no gradient traffic at all
-    const u3v a = {(unsigned)voff | 0x3f000000u, (unsigned)soff_a | 0x3f000000u, 0x3f000000u};
-    const u3v b = {(unsigned)voff_b | 0x3f100000u, (unsigned)soff_b | 0x3f000000u, 0x3f200000u};
-#else
     const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
-#ifdef BWD_EXP_HALFLOAD  // what-if experiment: half the gradient loads (the second pixel re-uses the first one's data)
-    const u3v b = {a.y, a.z, a.x};
-#else
     const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff_b, soff_b, 0);
-#endif
-#endif
     Grad6 g;
     g.a0 = __uint_as_float(a.x); g.a1 = __uint_as_float(a.y); g.a2 = __uint_as_float(a.z);
     g.b0 = __uint_as_float(b.x); g.b1 = __uint_as_float(b.y); g.b2 = __uint_as_float(b.z);
@@ -1394,11 +1369,6 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     // quadratic form completes to  u^2 - 2 rho u v + v^2 = (1-rho^2) u^2 + B^2,  so the exponent is
     //   log2(e) w1 (...) = K0 - K1 B^2,   K0 = -log2(e)/2 u^2 (lane constant),  K1 = log2(e)/2 / (1-rho^2),
     // and the same B feeds the gradient moments: nothing here cancels as |rho| -> 1.
-#ifdef BWD_EXP_NOMATH   // what-if experiment: the loads are consumed, nothing is computed
-    R.k01 += (v2f){g.a0, g.a1};
-    R.ka2 += g.a2; R.kb0 += g.b0; R.kb1 += g.b1; R.kb2 += g.b2;
-    return;
-#endif
     const v2f Bv = dyn - rho_u;
     const v2f pw = (Bv * nK1) * Bv + K0;
     v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
@@ -1415,20 +1385,6 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     // Only {a0, a1} is an aligned register pair as the two 12-byte loads land; the other four take scalar FMAs
     // (pairing them up costs five v_mov per trip -- more than the two packed operations save).
     R.k01 += (v2f){g.a0, g.a1} * v.x;
-#ifdef BWD_EXP_VPAD      // what-if experiment: extra (useless, independent) VALU instructions per trip
-    {
-        float pad0 = q.x, pad1 = q.y;
-#pragma unroll
-        for (int k = 0; k < BWD_EXP_VPAD / 2; ++k) asm volatile("v_mul_f32 %0, %0, %0\n\tv_mul_f32 %1, %1, %1" : "+v"(pad0), "+v"(pad1));
-    }
-#endif
-#ifdef BWD_EXP_SPAD      // ... extra scalar instructions per trip
-    {
-        int sp0 = 1;
-#pragma unroll
-        for (int k = 0; k < BWD_EXP_SPAD; ++k) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sp0) : : "scc");
-    }
-#endif
     R.ka2 = fmaf(g.a2, v.x, R.ka2);
     R.kb0 = fmaf(g.b0, v.y, R.kb0);
     R.kb1 = fmaf(g.b1, v.y, R.kb1);
@@ -1448,18 +1404,11 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
     const unsigned pitchb = (unsigned)P.w * 12u;   // bytes per gradient row (< 2^19); all offsets below are unsigned 32 x 32 -> 64
     const float nK1 = -HALF_LOG2E * cinv;
     // issued together with the px load below: one round trip for both tables instead of two dependent ones
-#ifdef BWD_EXP_NOTABLE   // what-if experiment: no table round trip (values are NOT the reference's)
-#define BWD_PX(X) ((float)(X) * (2.f / (float)(P.w - 1)) - 1.f)
-#define BWD_PY(Y) ((float)(Y) * (2.f / (float)(P.h - 1)) - 1.f)
-#else
-#define BWD_PX(X) pxt[X]
-#define BWD_PY(Y) pyt[Y]
-#endif
-    const float py_first = BWD_PY(min(r0 + lane, r1));
+    const float py_first = pyt[min(r0 + lane, r1)];
     for (int strip = 0; strip < bw; strip += 64) {
         const int cc = strip + col;
         const int X = c0 + min(cc, bw - 1);
-        const float dx = BWD_PX(X) - x;
+        const float dx = pxt[X] - x;
         // lanes outside the window (or, with TEST, outside the dmax box in x) are switched off through K0:
         // the exponent becomes -inf, v = 0 exactly, and every product with it is 0
         const bool inx = cc < bw && (!TEST || fabsf(dx) <= P.dmax);
@@ -1474,7 +1423,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
             const int rend = min(r1, rb + 63);
             __builtin_amdgcn_wave_barrier();
             {   // per-row values of the block in LDS: v = dy/sy, and (TEST only) the raw dy for the exact box test
-                const float dyr = (rb == r0 ? py_first : BWD_PY(min(rb + lane, r1))) - y;
+                const float dyr = (rb == r0 ? py_first : pyt[min(rb + lane, r1)]) - y;
                 spy[lane] = dyr * isy;
                 if (TEST) spy[64 + lane] = dyr;
             }
@@ -1718,18 +1667,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     // (two or four Gaussians per wave, one after the other, measured the same: wave launch is not the cost)
     BwdRec G;
     u2v lim;
-#ifdef BWD_EXP_NOFETCH   // what-if experiment: a synthetic record instead of the scalar fetch (results are meaningless)
-    {
-        const unsigned c0 = (gw * 4u) % 1000u, r0 = ((gw >> 8) * 4u) % 1000u;
-        G.bb = (u8v){c0 | ((c0 + 22u) << 16), r0 | ((r0 + 22u) << 16), 0u, 0u, 0u, 0u, r0 | ((r0 + 23u) << 16), 0u};
-        const float fx = (float)(c0 + 11u) * (2.f / 1023.f) - 1.f, fy = (float)(r0 + 11u) * (2.f / 1023.f) - 1.f;
-        G.rec = (u8v){__float_as_uint(fx), __float_as_uint(fy), 0u, 0u, 0u, 0x3f000000u, 0x3f000000u, 0x3f000000u};
-        G.fin = (u8v){0x3f800000u, 0x3f800000u, 0u, __float_as_uint(150.f), __float_as_uint(150.f), 0u, 0u, gw};
-        lim = (u2v){(unsigned)P.s, (unsigned)P.s};
-    }
-#else
     bwd_fetch_first(V, V.cell_start + P.ncells, min(gw, (unsigned)P.s - 1u), G, lim);  // speculative: class checked below
-#endif
     const unsigned large_beg = lim.x, large_end = lim.y;
     if (gw < large_beg)
         bwd_item<BOUNDED, UNROLL>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
@@ -1747,190 +1685,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-#if BWD_PAIR
-// ---------------------------------------------------------------------------------------------------
-// backward, Gaussian-stationary, TWO Gaussians per wave (k_render_bwd_pair).
-//
-// MEASURED DEAD END, compiled only with -DBWD_PAIR=1 (tools/build_mb.sh pair -DBWD_PAIR=1): 39.9 us against 37.0 us at
-// config 2, 294 against 296 us at config 5 -- although it issues 22% fewer instructions per Gaussian.  The backward is
-// bound by the CU's texture path, which spends ~17 cycles on every 96/128-bit wave-load whatever its lane mask
-// (tools/ta_rate.hip; TA 83% / TD 94% busy), and a pair's load instruction still carries two window rows.  DESIGN.md 3c.
-//
-// At x4 about half of a wave's instructions are per-Gaussian fixed work:
-// launch, fetch, window decode, tables, expansion, wave reduction, store.  Here the two halves of a wave take the two
-// cell-adjacent Gaussians of slots 2p and 2p+1 (windows of at most 32 columns and 64 rows -- 95% of the pairs at x4),
-// so all of that is issued once per PAIR: what was wave-uniform (SGPR) per Gaussian becomes per-lane data loaded by
-// each half, lane = (half, column), two adjacent rows per trip in packed fp32 exactly as in bwd_sweep's 32-column
-// layout (same bwd_trip, same residual-form sums, same expansion).  The halves run min(trips) trips together and the
-// one with the taller window finishes alone under an exec mask set once.  The wave reduction through LDS yields the
-// eight sums of each half in lanes 8k (first Gaussian) and 8k+4 (second).  Pairs that do not qualify, the large and
-// the dead class fall back to bwd_item, one slot after the other.
-// ---------------------------------------------------------------------------------------------------
-template <bool TEST>
-__device__ __forceinline__ void bwd_pair(int lane, const Params &P, const PlanView &V, const float *__restrict__ grad,
-                                         float *spy, float *red, unsigned bbx, unsigned rowsw, float2 ra, float4 rb,
-                                         float4 fa, float4 fb, float *__restrict__ g_sigmas, float *__restrict__ g_coords,
-                                         float *__restrict__ g_colors)
-{
-    constexpr float HALF_LOG2E = 0.72134752044448170368f;
-    constexpr float POISON = 1e18f;   // a row value that drives the exponent to -inf and keeps every product finite
-    const int h = lane >> 5, col = lane & 31;
-    const int c0 = (int)(bbx & 0x7fffu), bw = (int)(bbx >> 16) - c0 + 1;
-    const int r0 = (int)(rowsw & 0xffffu), r1 = (int)(rowsw >> 16), nrows = r1 - r0 + 1;
-    const float x = ra.x, y = ra.y, cr = rb.y, cg = rb.z, cb = rb.w;
-    const float cinv = fa.x, kappa = fa.y, rho = fa.z, isx = fa.w, isy = fb.x;
-    const float *pxt = V.px + __float_as_uint(fb.y);
-    const int X = c0 + min(col, bw - 1);
-    // the three table reads in one round trip
-    const float pxv = pxt[X];
-    const float py0 = V.py[min(r0 + col, r1)], py1 = V.py[min(r0 + 32 + col, r1)];
-    const float dx = pxv - x;
-    const bool inx = col < bw && (!TEST || fabsf(dx) <= P.dmax);
-    const float u = dx * isx, rho_u = rho * u;
-    const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;
-    const float nK1 = -HALF_LOG2E * cinv;
-    // per-row values of each half's window (<= 64 rows): v = dy/sy, and (TEST) the raw dy for the exact box test; rows
-    // past the window's end are poisoned (v = 0 exactly there: the second row of an odd window's last trip)
-    float *sp = spy + h * 64;
-    __builtin_amdgcn_wave_barrier();
-    sp[col] = col < nrows ? (py0 - y) * isy : POISON;
-    sp[32 + col] = 32 + col < nrows ? (py1 - y) * isy : POISON;
-    if (TEST) {
-        sp[128 + col] = col < nrows ? py0 - y : POISON;
-        sp[160 + col] = 32 + col < nrows ? py1 - y : POISON;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int ntrip = (nrows + 1) >> 1;
-    const int nA = __builtin_amdgcn_readlane(ntrip, 0), nB = __builtin_amdgcn_readlane(ntrip, 32);
-    const int nmin = min(nA, nB), nmax = max(nA, nB);
-    // one buffer resource over the whole slab (the caller checked that it is addressable with 31 bits)
-    const unsigned pitchb = (unsigned)P.w * 12u;
-    const unsigned long long slab = (unsigned long long)(unsigned)(P.row1 - P.row0) * pitchb;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad), 0, (int)slab, 0x00020000);
-    const int voff_a = (int)((unsigned)X * 12u + (unsigned)(r0 - P.row0) * pitchb), voff_b = voff_a + (int)pitchb;
-    const int step = (int)(2u * pitchb);
-    BwdRow R;
-    R.m1 = R.m2 = R.k01 = (v2f){0.f, 0.f};
-    R.ka2 = R.kb0 = R.kb1 = R.kb2 = 0.f;
-    if (inx) {
-        int soff = 0;
-        const float *q = sp;
-        for (int t = nmin; t > 0; --t, soff += step, q += 2) {
-            const v2f n0 = {q[0], q[1]};
-            const v2f w0 = TEST ? (v2f){q[128], q[129]} : n0;
-            bwd_trip<TEST, false>(R, bwd_load(rsrc, voff_a, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
-        }
-        if (ntrip > nmin) {   // the taller window of the two finishes alone
-            for (int t = nmax - nmin; t > 0; --t, soff += step, q += 2) {
-                const v2f n0 = {q[0], q[1]};
-                const v2f w0 = TEST ? (v2f){q[128], q[129]} : n0;
-                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff_a, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
-            }
-        }
-    }
-    // expansion of the column's sums, as in bwd_sweep, with per-lane Gaussian constants
-    const float Kr = R.k01.x + R.kb0, Kg = R.k01.y + R.kb1, Kb = R.ka2 + R.kb2;
-    const float M0 = fmaf(Kb, cb, fmaf(Kg, cg, Kr * cr)), N1 = R.m1.x + R.m1.y, N2 = R.m2.x + R.m2.y;
-    const float ue = inx ? u : 0.f, uk = ue * kappa;
-    const float sA = uk * M0 - rho * N1;
-    float a[8] = {sA, N1, ue * sA, N2 + rho * ue * N1, uk * N1 - rho * N2, Kr, Kg, Kb};
-    bwd_scale(a, cinv, isx, isy);
-    // wave reduction through LDS, per half: lane l adds the 8 consecutive partials {l&7} of value {l>>3} (source lanes
-    // 8(l&7) .. +7: the first Gaussian's for l&7 < 4), then two butterfly steps inside each 4-lane group
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[k * 64 + lane] = a[k];
-    __builtin_amdgcn_wave_barrier();
-    const float4 s0 = *reinterpret_cast<const float4 *>(red + lane * 8);
-    const float4 s1 = *reinterpret_cast<const float4 *>(red + lane * 8 + 4);
-    float d = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w));
-    d += dpp_row_shl<2>(d);
-    d += dpp_row_shl<1>(d);
-    // lanes 8k hold component k of the first Gaussian, lanes 8k+4 of the second
-    if (lane & 3) return;
-    const unsigned iA = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(fb.w), 0);
-    const unsigned iB = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(fb.w), 32);
-    const unsigned i = (lane & 4) ? iB : iA;
-    const int k = lane >> 3;
-    float *pc = g_coords + (size_t)i * stride2(P), *ps = g_sigmas + (size_t)i * stride3(P) - 2,
-          *pk = g_colors + (size_t)i * stride3(P) - 5;
-    float *dst = (k < 2 ? pc : (k < 5 ? ps : pk)) + k;
-    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) *dst = d;
-    else atomicAdd(dst, d);
-}
-
-template <bool BOUNDED>
-__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(BWD_PAIR_OCC))) void k_render_bwd_pair(
-    Params P, PlanView V, const float *__restrict__ grad, float *__restrict__ g_sigmas, float *__restrict__ g_coords,
-    float *__restrict__ g_colors)
-{
-    const int lane = threadIdx.x & 63;
-    // XCD-aware order as in k_render_bwd: each XCD sweeps a contiguous run of the cell-ordered Gaussians
-    const unsigned nb = gridDim.x, b = blockIdx.x;
-    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
-    const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned gw = t * (unsigned)BWD_WAVES + (unsigned)wv;      // this wave: slots 2 gw, 2 gw + 1
-    const unsigned nwaves = nb * (unsigned)BWD_WAVES;
-    __shared__ float s_py[BWD_WAVES][256];  // per wave and half: v = dy/sy of <= 64 rows, then (TEST) the raw dy
-    __shared__ __attribute__((aligned(16))) float s_red[BWD_WAVES][512];
-    float *spy = s_py[wv], *red = s_red[wv];
-    const unsigned j0 = 2u * gw, s = (unsigned)P.s;
-    // per-lane records of the half's Gaussian (speculative: the classes are checked below)
-    const unsigned j = min(j0 + (unsigned)(lane >> 5), s - 1u);
-    const unsigned bbx = reinterpret_cast<const unsigned *>(V.bbox)[8 * (size_t)j];
-    const unsigned rowsw = reinterpret_cast<const unsigned *>(V.bbox)[8 * (size_t)j + 6];
-    const float2 ra = *reinterpret_cast<const float2 *>(V.rec + 2 * (size_t)j);
-    const float4 rb = V.rec[2 * (size_t)j + 1];
-    const float4 fa = V.fin[2 * (size_t)j], fb = V.fin[2 * (size_t)j + 1];
-    u2v lim;
-    {
-        const unsigned *bounds = V.cell_start + P.ncells;
-        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(lim) : "s"(bounds) : "memory");
-    }
-    const unsigned large_beg = lim.x, large_end = lim.y;
-    bool paired = false;
-    if (j0 + 1u < large_beg) {   // both slots in the normal class
-        const int bw = (int)(bbx >> 16) - (int)(bbx & 0x7fffu) + 1;
-        const int nrows = (int)(rowsw >> 16) - (int)(rowsw & 0xffffu) + 1;
-        const bool fits = bw >= 1 && bw <= 32 && nrows <= 64;
-        if (__ballot(fits) == ~0ull) {
-            paired = true;
-            if (BOUNDED && __ballot((bbx & 0x8000u) != 0u) != 0ull)
-                bwd_pair<true>(lane, P, V, grad, spy, red, bbx, rowsw, ra, rb, fa, fb, g_sigmas, g_coords, g_colors);
-            else
-                bwd_pair<false>(lane, P, V, grad, spy, red, bbx, rowsw, ra, rb, fa, fb, g_sigmas, g_coords, g_colors);
-        }
-    }
-    BwdRec G;
-#ifdef BWD_EXP_PAIRONLY   // what-if experiment: no fallback (pairs that do not qualify are skipped: wrong results)
-    return;
-#endif
-    if (!paired) {
-#pragma unroll 1
-        for (unsigned k = 0; k < 2u; ++k) {
-            const unsigned jj = j0 + k;
-            if (jj >= s) break;
-            bwd_fetch(V, jj, G);
-            if (jj < large_beg)
-                bwd_item<BOUNDED, false>(jj, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
-            else if (jj < large_end)
-                bwd_item<BOUNDED, false>(jj, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
-            else if (P.flags & GSASR_FLAG_OVERWRITE_GRADS)   // dead class: the gradient is zero
-                bwd_write(0.f, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
-        }
-    }
-    // remaining row chunks of the large class, spread over all waves
-    const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
-    for (unsigned it = gw; it < extra; it += nwaves) {
-        const unsigned jl = large_beg + it / (unsigned)(NCH - 1);
-        const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
-        bwd_fetch(V, jl, G);
-        bwd_item<BOUNDED, false>(jl, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
-    }
-}
-
-#endif  // BWD_PAIR
 
 // ---------------------------------------------------------------------------------------------------
 // backward, TILE-stationary (BASELINE.json north_star's shape: a workgroup owns an HR tile, stages its grad_img ONCE
@@ -3145,17 +2899,6 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         const bool unroll = (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
         // (experiment, off by default: two Gaussians per wave for small windows -- k_render_bwd_pair; its single buffer
         // resource spans the slab, which must then be addressable with 31 bits)
-#if BWD_PAIR
-        const bool pair = !unroll && (double)rows * (double)dims->w * 12.0 < 2147483647.0;
-        if (pair) {
-            const unsigned per = 2u * (unsigned)BWD_WAVES;
-            const dim3 pgrid(((unsigned)dims->s + per - 1u) / per);
-            if (P.bounded) hipLaunchKernelGGL(k_render_bwd_pair<true>, pgrid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
-            else hipLaunchKernelGGL(k_render_bwd_pair<false>, pgrid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
-            HIP_TRY(hipGetLastError());
-            return GSASR_OK;
-        }
-#endif
 #define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
         if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
         else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
