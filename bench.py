@@ -229,6 +229,9 @@ class Step:
         import ctypes
         p = self.plan
         p.pool_key = None       # this workspace is re-planned by hand from here on: it must never go back to the package's pool
+        if not getattr(self, "own_dims", False):     # (the package shares one dims struct between plans of a shape: take a copy to edit)
+            p.dims = type(p.dims).from_buffer_copy(p.dims)
+            self.own_dims = True
         # the workspace persists across steps: every plan zeroes the other parity's cell counters on the side, so after
         # the first one no memset launch is needed (GSASR_FLAG_COUNTERS_CLEAN / GSASR_FLAG_PARITY alternate)
         c = self.cabi

@@ -26,6 +26,7 @@ EXPORTS = (
     "gsasr_band_select", "gsasr_band_merge", "gsasr_resolve_cutoff",
     "gsasr_sample_workspace_bytes", "gsasr_splat_sample_forward", "gsasr_splat_sample_backward",
     "gsasr_step_sample_forward", "gsasr_step_sample_backward",
+    "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -94,6 +95,10 @@ def lib():
         L.gsasr_step_forward.argtypes = [vp, vp, dp, vp, sz, vp, vp]
         L.gsasr_step_backward.restype = i
         L.gsasr_step_backward.argtypes = [vp, vp, vp, vp, dp, vp, sz, vp]
+        L.gsasr_step_forward_sm.restype = i
+        L.gsasr_step_forward_sm.argtypes = [vp, vp, i, f, vp, dp, vp, sz, vp, vp]
+        L.gsasr_step_sample_forward_sm.restype = i
+        L.gsasr_step_sample_forward_sm.argtypes = [vp, vp, i, f, vp, dp, vp, sz, vp, i, vp, vp, sz, vp]
         L.gsasr_band_select.restype = i
         L.gsasr_band_select.argtypes = [vp, dp, i, i, i, vp, vp, vp, vp, vp, vp]
         L.gsasr_band_merge.restype = i
@@ -113,7 +118,7 @@ def lib():
         L.gsasr_get_default_cutoff.restype = f
         L.gsasr_resolve_cutoff.restype = f
         L.gsasr_resolve_cutoff.argtypes = [f, i]
-        if L.gsasr_abi_version() != 3:
+        if L.gsasr_abi_version() != 4:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
     return _lib
@@ -142,6 +147,13 @@ def _chk(t: torch.Tensor, name: str, shape_tail: Optional[Tuple[int, ...]] = Non
 
 def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr3(t: torch.Tensor, name: str, last: int) -> int:
+    """`_chk(t, name, (last,))` for the hot path: one combined test first, the explanatory ones only when it fails"""
+    if t.__class__ is torch.Tensor and t.is_cuda and t.dtype is torch.float32 and t.is_contiguous() and t.shape[-1] == last:
+        return t.data_ptr()
+    return _chk(t, name, (last,))
 
 
 class _Nop:
@@ -207,6 +219,12 @@ class _WorkspacePool:
 _POOL = _WorkspacePool()
 
 
+def clear_workspace_pool() -> None:
+    """Drop the pooled plan workspaces (up to `_WorkspacePool.MAX_BYTES` of device memory that `torch.cuda.empty_cache()`
+    cannot see as free while the pool holds it): call it next to `empty_cache()` when memory is tight."""
+    _POOL.clear()
+
+
 @dataclass
 class Plan:
     """Binning workspace of one (sigmas, coords, colors, dims): shared by forward and backward."""
@@ -233,36 +251,58 @@ def make_dims(s: int, h: int, w: int, dmax: Optional[float], rows: Optional[Tupl
                 float(cutoff), int(flags))
 
 
+_PLAN_DIMS = {}     # (s, h, w, dmax, rows, cutoff, flags) -> ([Dims fresh, pooled parity 0, pooled parity 1], workspace bytes)
+
+
+def _plan_dims(s: int, h: int, w: int, dmax, rows, cutoff: float, flags: int):
+    key = (s, h, w, dmax, rows, cutoff, flags)
+    hit = _PLAN_DIMS.get(key)
+    if hit is None:      # (dims structs + workspace size per shape: built once, not per call)
+        if dmax is not None and not (float(dmax) >= 0.0):
+            raise RuntimeError("dmax must be >= 0")
+        variants = [make_dims(s, h, w, dmax, rows, cutoff, int(flags) | f)
+                    for f in (0, FLAG_COUNTERS_CLEAN, FLAG_COUNTERS_CLEAN | FLAG_PARITY)]
+        nbytes = lib().gsasr_splat_workspace_bytes(ctypes.byref(variants[0]))
+        if nbytes == 0:
+            check(-1, "gsasr_splat_workspace_bytes")
+        if len(_PLAN_DIMS) > 512:
+            _PLAN_DIMS.clear()
+        hit = _PLAN_DIMS[key] = (variants, nbytes)
+    return hit
+
+
 def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: int, w: int,
          dmax: Optional[float], rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0,
          flags: int = 0) -> Plan:
-    ps = _chk(sigmas, "sigmas", (3,))
-    pc = _chk(coords, "coords", (2,))
-    pk = _chk(colors, "colors", (3,))
+    ps = _ptr3(sigmas, "sigmas", 3)
+    pc = _ptr3(coords, "coords", 2)
+    pk = _ptr3(colors, "colors", 3)
     s = sigmas.shape[0]
     if coords.shape[0] != s or colors.shape[0] != s:
         raise RuntimeError("sigmas, coords, colors disagree on the number of Gaussians")
-    if dmax is not None and not (float(dmax) >= 0.0):
-        raise RuntimeError("dmax must be >= 0")
-    d = make_dims(s, h, w, dmax, rows, cutoff, flags)
-    L = lib()
-    nbytes = L.gsasr_splat_workspace_bytes(ctypes.byref(d))
-    if nbytes == 0:
-        check(-1, "gsasr_splat_workspace_bytes")
+    variants, nbytes = _plan_dims(s, int(h), int(w), dmax, rows, cutoff, flags)
     dev = sigmas.device
     with _on(dev):
-        ws, pool_key, parity = _pooled_workspace(d, nbytes, dev)
-        check(L.gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), ws.data_ptr(), nbytes, _stream(dev)),
-              "gsasr_splat_plan")
+        stream = _stream(dev)
+        if torch.cuda.is_current_stream_capturing():
+            # a captured plan is replayed on the same workspace with the same parity: it must zero its own counters
+            ws, parity, clean, pool_key = torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False, None
+        else:
+            pool_key = (dev.index, stream, nbytes, s, h, w, 0, 0, flags & _LAYOUT_FLAGS)
+            ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
+        d = variants[1 + parity] if clean else variants[0]
+        check(lib().gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), ws.data_ptr(), nbytes, stream), "gsasr_splat_plan")
     return Plan(d, ws, dev, pool_key, parity)
+
+
+_LAYOUT_FLAGS = FLAG_FORWARD_ONLY | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN | FLAG_BWD_ATOMIC | FLAG_CHW_GRAD | FLAG_STRIDE8
 
 
 def _pool_key(d: Dims, nbytes: int, dev):
     """Workspaces are interchangeable only between plans of the SAME layout: "the counters of parity p are zero" is a
     statement about where the counter arrays lie and how long they are (grid size), so the key carries everything the
     layout depends on, not just the byte count (two small shapes easily round to the same size)."""
-    return (dev.index, _stream(dev), nbytes, d.s, d.h, d.w, d.batch, d.slot,
-            d.flags & (FLAG_FORWARD_ONLY | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN | FLAG_BWD_ATOMIC | FLAG_CHW_GRAD | FLAG_STRIDE8))
+    return (dev.index, _stream(dev), nbytes, d.s, d.h, d.w, d.batch, d.slot, d.flags & _LAYOUT_FLAGS)
 
 
 def _pooled_workspace(d: Dims, nbytes: int, dev):
@@ -279,20 +319,36 @@ def _pooled_workspace(d: Dims, nbytes: int, dev):
 
 
 def _dims_with(p: Plan, extra_flags: int) -> Dims:
-    if not extra_flags or (p.dims.flags & extra_flags) == extra_flags:
-        return p.dims
-    d = Dims.from_buffer_copy(p.dims)
-    d.flags |= extra_flags
+    """the plan's dims with `extra_flags` added (copies are cached on the Dims object, which plans of one shape share)"""
+    d0 = p.dims
+    if not extra_flags or (d0.flags & extra_flags) == extra_flags:
+        return d0
+    cache = d0.__dict__.get("_with")
+    if cache is None:
+        cache = d0.__dict__["_with"] = {}
+    d = cache.get(extra_flags)
+    if d is None or d.flags != (d0.flags | extra_flags):
+        d = Dims.from_buffer_copy(d0)
+        d.flags |= extra_flags
+        if hasattr(d0, "_keepalive"):
+            d._keepalive = d0._keepalive
+        cache[extra_flags] = d
     return d
 
 
 def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = False) -> torch.Tensor:
     """img += splat (reference contract), or img = splat when `overwrite` (img may be torch.empty).
     `chw`: img is planar [3, rows, W] instead of [rows, W, 3]."""
-    rows = p.dims.row1 - p.dims.row0
-    pi = _chk(img, "rendered_img", (rows, p.dims.w) if chw else (p.dims.w, 3))
-    if (img.shape[0] != (3 if chw else rows)) or img.dim() != 3 or img.device != p.device:
-        raise RuntimeError("rendered_img does not match the plan (shape / device)")
+    d0 = p.dims
+    rows = d0.row1 - d0.row0
+    if chw:
+        pi = _chk(img, "rendered_img", (rows, d0.w))
+        if img.shape[0] != 3 or img.dim() != 3 or img.device != p.device:
+            raise RuntimeError("rendered_img does not match the plan (shape / device)")
+    else:
+        pi = _ptr3(img, "rendered_img", 3)
+        if img.dim() != 3 or img.shape[0] != rows or img.shape[1] != d0.w or img.device != p.device:
+            raise RuntimeError("rendered_img does not match the plan (shape / device)")
     d = _dims_with(p, (FLAG_OVERWRITE_IMAGE if overwrite else 0) | (FLAG_CHW_IMAGE if chw else 0))
     with _on(p.device):
         check(lib().gsasr_splat_forward(ctypes.byref(d), p.workspace.data_ptr(), p.workspace.numel(), pi,
@@ -302,15 +358,58 @@ def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = Fal
 
 def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors, overwrite: bool = False) -> None:
     """g_* += gradients (reference contract: caller zero-fills), or g_* = gradients when `overwrite`."""
-    ptrs = [_chk(sigmas, "sigmas", (3,)), _chk(coords, "coords", (2,)), _chk(colors, "colors", (3,)),
-            _chk(grad_img, "grads", (p.dims.w, 3)), _chk(g_sigmas, "grads_sigmas", (3,)),
-            _chk(g_coords, "grads_coords", (2,)), _chk(g_colors, "grads_colors", (3,))]
-    if grad_img.shape[0] != p.dims.row1 - p.dims.row0:
+    d0 = p.dims
+    pg = _ptr3(grad_img, "grads", 3)
+    if grad_img.dim() != 3 or grad_img.shape[1] != d0.w:
+        raise RuntimeError(f"grads has shape {tuple(grad_img.shape)}, expected [rows, {d0.w}, 3]")
+    if grad_img.shape[0] != d0.row1 - d0.row0:
         raise RuntimeError("grads does not match the plan's row band")
     d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
     with _on(p.device):
-        check(lib().gsasr_splat_backward(*ptrs, ctypes.byref(d), p.workspace.data_ptr(),
+        check(lib().gsasr_splat_backward(_ptr3(sigmas, "sigmas", 3), _ptr3(coords, "coords", 2), _ptr3(colors, "colors", 3), pg,
+                                         _ptr3(g_sigmas, "grads_sigmas", 3), _ptr3(g_coords, "grads_coords", 2),
+                                         _ptr3(g_colors, "grads_colors", 3), ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
+
+
+def plan_forward(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, img: torch.Tensor,
+                 dmax: Optional[float]) -> Plan:
+    """`plan` + `forward` (accumulating into `img[H,W,3]`) as one host call: what `GSCUDA.forward` does, with one device /
+    stream lookup and one set of argument checks for both C calls"""
+    ps = _ptr3(sigmas, "sigmas", 3)
+    pc = _ptr3(coords, "coords", 2)
+    pk = _ptr3(colors, "colors", 3)
+    pi = _ptr3(img, "rendered_img", 3)
+    if img.dim() != 3:
+        raise RuntimeError("rendered_img must be [H,W,3]")
+    s, h, w = sigmas.shape[0], img.shape[0], img.shape[1]
+    dev = sigmas.device
+    if coords.shape[0] != s or colors.shape[0] != s:
+        raise RuntimeError("sigmas, coords, colors disagree on the number of Gaussians")
+    if img.device != dev:
+        raise RuntimeError("rendered_img does not match the plan (shape / device)")
+    variants, nbytes = _plan_dims(s, h, w, dmax, None, 0.0, 0)
+    L = lib()
+    with _on(dev):
+        stream = _stream(dev)
+        if torch.cuda.is_current_stream_capturing():
+            ws, parity, clean, pool_key = torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False, None
+        else:
+            pool_key = (dev.index, stream, nbytes, s, h, w, 0, 0, 0)
+            ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
+        d = variants[1 + parity] if clean else variants[0]
+        pw = ws.data_ptr()
+        check(L.gsasr_splat_plan(ps, pc, pk, ctypes.byref(d), pw, nbytes, stream), "gsasr_splat_plan")
+        check(L.gsasr_splat_forward(ctypes.byref(d), pw, nbytes, pi, stream), "gsasr_splat_forward")
+    return Plan(d, ws, dev, pool_key, parity)
+
+
+def backward_new(p: Plan, sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, grad_img: torch.Tensor):
+    """`backward` into three fresh gradient tensors (stored, not accumulated): what `GSCUDA.backward` returns"""
+    g_sigmas, g_coords, g_colors = torch.empty_like(sigmas), torch.empty_like(coords), torch.empty_like(colors)
+    backward(p, sigmas, coords, colors, grad_img if grad_img.is_contiguous() else grad_img.contiguous(), g_sigmas, g_coords,
+             g_colors, overwrite=True)
+    return g_sigmas, g_coords, g_colors
 
 
 # ---- packed [N,8] records (GSASR_FLAG_STRIDE8): the wire format of the multi-GPU exchange --------------
@@ -423,19 +522,48 @@ def prologue_backward(gs_parameters, step, h: int, w: int, g_sigmas, g_coords, g
 _STEP_DIMS = {}     # (n, h, w, dmax, flags) -> (Dims, workspace bytes) of the single-image step entry points
 
 
-def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float],
-                 extra_flags: int = 0):
+_MISMATCH = {}      # device index -> int32[2] device tensor: the sticky "scale_modify pair differs" word of the _sm entry points
+
+
+def mismatch_flag(dev: torch.device) -> torch.Tensor:
+    t = _MISMATCH.get(dev.index)
+    if t is None:
+        t = _MISMATCH[dev.index] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return t
+
+
+def _sm_ptr(sm: torch.Tensor, batch: int):
+    """pointer + element stride of `scale_modify` pairs: a float32 CUDA tensor `[2]` (or longer) for one image, `[B, >=2]`
+    rows for a batched canvas"""
+    if not (sm.__class__ is torch.Tensor and sm.is_cuda and sm.dtype is torch.float32):
+        raise RuntimeError("scale_modify must be a float32 CUDA tensor")
+    if batch <= 1:
+        if sm.dim() != 1 or sm.shape[0] < 2 or sm.stride(0) != 1:
+            raise RuntimeError("scale_modify must be a contiguous [2] tensor")
+        return sm.data_ptr(), 2
+    if sm.dim() != 2 or sm.shape[0] != batch or sm.shape[1] < 2 or sm.stride(1) != 1 or sm.stride(0) < 2:
+        raise RuntimeError(f"scale_modify must be [{batch}, 2] with unit inner stride")
+    return sm.data_ptr(), int(sm.stride(0))
+
+
+def step_forward(gs_parameters: torch.Tensor, step: Optional[torch.Tensor], h: int, w: int, dmax: Optional[float],
+                 extra_flags: int = 0, scale_modify: Optional[torch.Tensor] = None, default_step_size: float = 1.2):
     """prologue + plan + forward in ONE call: raw `gs_parameters[N,9]` -> planar image `[3,h,w]` (fresh).
-    `extra_flags`: FLAG_FORWARD_ONLY (no backward will follow), FLAG_BWD_TILE (plan for the tile-stationary backward)."""
-    pp = _chk(gs_parameters, "gs_parameters", (9,))
-    ps = _chk(step, "step_size")
-    if dmax is not None and not (float(dmax) >= 0.0):
-        raise RuntimeError("dmax must be >= 0")
+    `extra_flags`: FLAG_FORWARD_ONLY (no backward will follow), FLAG_BWD_TILE (plan for the tile-stationary backward).
+    The step size is `step` (a `[1]` device tensor), or with `scale_modify` (a `[2]` float32 CUDA tensor) the reference's
+    `default_step_size / scale_modify[0]` formed on the device, its `[0] == [1]` assert reported through `mismatch_flag`."""
+    pp = _ptr3(gs_parameters, "gs_parameters", 9)
     dev = gs_parameters.device
+    if scale_modify is None:
+        ps = _chk(step, "step_size")
+    else:
+        psm, stride = _sm_ptr(scale_modify, 1)
     L = lib()
     key = (gs_parameters.shape[0], int(h), int(w), dmax, int(extra_flags))
     hit = _STEP_DIMS.get(key)
     if hit is None:      # (dims structs + workspace size per shape: built once, not per call)
+        if dmax is not None and not (float(dmax) >= 0.0):
+            raise RuntimeError("dmax must be >= 0")
         base = FLAG_OVERWRITE_IMAGE | FLAG_CHW_IMAGE | int(extra_flags)
         variants = [make_dims(gs_parameters.shape[0], h, w, dmax, flags=base | f)
                     for f in (0, FLAG_COUNTERS_CLEAN, FLAG_COUNTERS_CLEAN | FLAG_PARITY)]   # fresh / pooled parity 0 / 1
@@ -452,20 +580,27 @@ def step_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int
             # a captured plan is replayed on the same workspace with the same parity: it must zero its own counters
             ws, parity, clean, pool_key = torch.empty(nbytes, dtype=torch.uint8, device=dev), 0, False, None
         else:
-            pool_key = _pool_key(variants[0], nbytes, dev)
+            d0 = variants[0]
+            pool_key = (dev.index, stream, nbytes, d0.s, d0.h, d0.w, 0, 0, d0.flags & _LAYOUT_FLAGS)
             ws, parity, clean = _POOL.take(pool_key, nbytes, dev)
         d = variants[1 + parity] if clean else variants[0]
         img = torch.empty(3, int(h), int(w), dtype=torch.float32, device=dev)
-        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
-              "gsasr_step_forward")
+        if scale_modify is None:
+            check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
+                  "gsasr_step_forward")
+        else:
+            check(L.gsasr_step_forward_sm(pp, psm, stride, float(default_step_size), mismatch_flag(dev).data_ptr(),
+                                          ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
+                  "gsasr_step_forward_sm")
     return img, Plan(d, ws, dev, pool_key, parity)
 
 
-def step_backward(p: Plan, gs_parameters: torch.Tensor, step: torch.Tensor, grad: torch.Tensor, chw: bool = False) -> torch.Tensor:
+def step_backward(p: Plan, gs_parameters: torch.Tensor, step: Optional[torch.Tensor], grad: torch.Tensor, chw: bool = False) -> torch.Tensor:
     """splat backward + prologue backward in ONE call; `grad` is `[h,w,3]`, or with `chw` the planar `[3,h,w]` autograd
-    hands back (tile-stationary backward, GSASR_FLAG_CHW_GRAD); returns d/d gs_parameters `[N,9]`."""
-    pp = _chk(gs_parameters, "gs_parameters", (9,))
-    ps = _chk(step, "step_size")
+    hands back (tile-stationary backward, GSASR_FLAG_CHW_GRAD); returns d/d gs_parameters `[N,9]`.  `step=None`: the step
+    size the forward's prologue used (kept in the workspace)."""
+    pp = _ptr3(gs_parameters, "gs_parameters", 9)
+    ps = None if step is None else _chk(step, "step_size")
     pg = _chk(grad, "grads", (3, p.dims.h, p.dims.w) if chw else (p.dims.h, p.dims.w, 3))
     d = _dims_with(p, FLAG_CHW_GRAD if chw else 0)
     with _on(p.device):
@@ -493,14 +628,20 @@ def make_batch_dims(n_per: int, sizes, w_max: int, h_max: int, dmax: Optional[fl
     return d
 
 
-def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax: Optional[float], extra_flags: int = 0):
+def batch_forward(gs_parameters: torch.Tensor, steps: Optional[torch.Tensor], sizes, dmax: Optional[float], extra_flags: int = 0,
+                  scale_modify: Optional[torch.Tensor] = None, default_step_size: float = 1.2):
     """prologue + plan + forward of a whole batch in ONE set of launches.
     `gs_parameters` [B,N,9], `steps` [B] (device), `sizes` [(h_b, w_b)] -> planar images `[B,3,slot,w_max]`
     (sample b in `[:, :, :h_b, :w_b]`, zero elsewhere) and the plan for `batch_backward`."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
-    ps = _chk(steps, "step_sizes")
-    if gs_parameters.dim() != 3 or steps.numel() != gs_parameters.shape[0] or len(sizes) != gs_parameters.shape[0]:
+    if gs_parameters.dim() != 3 or len(sizes) != gs_parameters.shape[0]:
         raise RuntimeError("gs_parameters must be [B,N,9] with one step size and one (h,w) per sample")
+    if scale_modify is None:
+        ps = _chk(steps, "step_sizes")
+        if steps.numel() != gs_parameters.shape[0]:
+            raise RuntimeError("gs_parameters must be [B,N,9] with one step size and one (h,w) per sample")
+    else:
+        psm, stride = _sm_ptr(scale_modify, gs_parameters.shape[0])
     if dmax is not None and not (float(dmax) >= 0.0):
         raise RuntimeError("dmax must be >= 0")
     B, n = gs_parameters.shape[0], gs_parameters.shape[1]
@@ -515,20 +656,29 @@ def batch_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax:
         stream = _stream(dev)
         ws, pool_key, parity = _pooled_workspace(d, nbytes, dev)
         img = torch.empty(B, 3, d.slot, w_max, dtype=torch.float32, device=dev)
-        check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
-              "gsasr_step_forward")
+        if scale_modify is None:
+            check(L.gsasr_step_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
+                  "gsasr_step_forward")
+        else:
+            check(L.gsasr_step_forward_sm(pp, psm, stride, float(default_step_size), mismatch_flag(dev).data_ptr(),
+                                          ctypes.byref(d), ws.data_ptr(), nbytes, img.data_ptr(), stream),
+                  "gsasr_step_forward_sm")
     return img, Plan(d, ws, dev, pool_key, parity)
 
 
-def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: torch.Tensor, grad: torch.Tensor, chw: bool = False) -> torch.Tensor:
+def batch_backward(p: Plan, gs_parameters: torch.Tensor, steps: Optional[torch.Tensor], grad: torch.Tensor, chw: bool = False) -> torch.Tensor:
     """`grad` is `[B, slot, w_max, 3]`, or with `chw` the planar `[B, 3, rows, w_max]` autograd hands back (any
-    `rows` >= every sample's height; tile-stationary backward); returns d/d gs_parameters `[B,N,9]`."""
+    `rows` >= every sample's height; tile-stationary backward); returns d/d gs_parameters `[B,N,9]`.  `steps=None`: the
+    step sizes the forward's prologue used."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
-    ps = _chk(steps, "step_sizes")
+    ps = None if steps is None else _chk(steps, "step_sizes")
     d = p.dims
     if chw:
         if grad.dim() != 4 or grad.shape[0] != d.batch or grad.shape[1] != 3 or grad.shape[3] != d.w:
             raise RuntimeError(f"grads has shape {tuple(grad.shape)}, expected [{d.batch}, 3, rows, {d.w}]")
+        hmax = max(d.sample_hw[2 * b] for b in range(d.batch))
+        if not (hmax <= grad.shape[2]):
+            raise RuntimeError(f"grads has {grad.shape[2]} rows per plane, a sample has {hmax}")
         pg = _chk(grad, "grads")
         d = Dims.from_buffer_copy(p.dims)
         d.flags |= FLAG_CHW_GRAD
@@ -589,16 +739,16 @@ def sample_backward(p: Plan, state, sigmas, coords, colors, grad_out, g_sigmas, 
                                                 _stream(p.device)), "gsasr_splat_sample_backward")
 
 
-def step_sample_forward(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float],
-                        points: torch.Tensor):
-    """prologue + plan + sampled forward in ONE call: raw `gs_parameters[N,9]` -> `[3,S]`."""
+def step_sample_forward(gs_parameters: torch.Tensor, step: Optional[torch.Tensor], h: int, w: int, dmax: Optional[float],
+                        points: torch.Tensor, scale_modify: Optional[torch.Tensor] = None, default_step_size: float = 1.2):
+    """prologue + plan + sampled forward in ONE call: raw `gs_parameters[N,9]` -> `[3,S]` (step size as in `step_forward`)."""
     pp = _chk(gs_parameters, "gs_parameters", (9,))
-    ps = _chk(step, "step_size")
+    ps = None if scale_modify is not None else _chk(step, "step_size")
     if dmax is not None and not (float(dmax) >= 0.0):
         raise RuntimeError("dmax must be >= 0")
     dev = gs_parameters.device
     d = make_dims(gs_parameters.shape[0], h, w, dmax)
-    return _step_sample_forward(d, pp, ps, points, dev)
+    return _step_sample_forward(d, pp, ps, points, dev, scale_modify, default_step_size)
 
 
 def batch_sample_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax: Optional[float],
@@ -615,9 +765,11 @@ def batch_sample_forward(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes
     return _step_sample_forward(d, pp, ps, points, gs_parameters.device)
 
 
-def _step_sample_forward(d: Dims, pp: int, ps: int, points: torch.Tensor, dev):
+def _step_sample_forward(d: Dims, pp: int, ps, points: torch.Tensor, dev, scale_modify=None, default_step_size: float = 1.2):
     L = lib()
     B = max(int(d.batch), 1)
+    if scale_modify is not None:
+        psm, stride = _sm_ptr(scale_modify, B)
     pts, n = _points(points, B, dev)
     nbytes = L.gsasr_step_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
@@ -626,9 +778,14 @@ def _step_sample_forward(d: Dims, pp: int, ps: int, points: torch.Tensor, dev):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         sws = _sample_ws(d, n, dev)
         out = torch.empty((B, 3, n) if B > 1 else (3, n), dtype=torch.float32, device=dev)
-        check(L.gsasr_step_sample_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, pts.data_ptr(), n,
-                                          out.data_ptr(), sws.data_ptr(), sws.numel(), _stream(dev)),
-              "gsasr_step_sample_forward")
+        if scale_modify is None:
+            check(L.gsasr_step_sample_forward(pp, ps, ctypes.byref(d), ws.data_ptr(), nbytes, pts.data_ptr(), n,
+                                              out.data_ptr(), sws.data_ptr(), sws.numel(), _stream(dev)),
+                  "gsasr_step_sample_forward")
+        else:
+            check(L.gsasr_step_sample_forward_sm(pp, psm, stride, float(default_step_size), mismatch_flag(dev).data_ptr(),
+                                                 ctypes.byref(d), ws.data_ptr(), nbytes, pts.data_ptr(), n, out.data_ptr(),
+                                                 sws.data_ptr(), sws.numel(), _stream(dev)), "gsasr_step_sample_forward_sm")
     return out, Plan(d, ws, dev), (pts, n, sws)
 
 
@@ -637,7 +794,7 @@ def step_sample_backward(p: Plan, state, gs_parameters: torch.Tensor, step: torc
     """sampled backward + prologue backward in ONE call; returns d/d gs_parameters (`[N,9]` or `[B,N,9]`)."""
     pts, n, sws = state
     pp = _chk(gs_parameters, "gs_parameters", (9,))
-    ps = _chk(step, "step_size")
+    ps = None if step is None else _chk(step, "step_size")      # None: the step sizes the forward's prologue used
     pg = _chk(grad_out, "grad_out", (3, n))
     if grad_out.numel() != max(int(p.dims.batch), 1) * 3 * n:
         raise RuntimeError("grad_out does not match the points")

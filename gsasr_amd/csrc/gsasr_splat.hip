@@ -54,6 +54,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "gsasr_splat.h"
 
@@ -237,7 +238,7 @@ int bwd_part_k(const gsasr_dims *d)
     return px_per_gaussian >= 32.0 ? 16 : 8;
 }
 
-Layout make_layout(const gsasr_dims *d)
+Layout make_layout(const gsasr_dims *d, int part_k = -1)
 {
     Layout L{};
     L.ncx = (d->w + CELL - 1) / CELL;
@@ -264,7 +265,7 @@ Layout make_layout(const gsasr_dims *d)
     L.off_done = o;   o += align_up(bw * 4, 256);
     L.off_bbox = o;   o += align_up(s * 32, 256);
     L.off_win = o;    o += align_up(s * 8, 256);
-    L.part_k = bwd_part_k(d);
+    L.part_k = part_k >= 0 ? part_k : bwd_part_k(d);
     L.off_part = o;   o += align_up(s * 32 * (size_t)L.part_k, 256);
     L.off_qspan = o;  o += L.part_k ? align_up(s * 16, 256) : 0;
     L.total = o;
@@ -341,6 +342,39 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.part_k = L.part_k;
     P.grad_rows = d->grad_rows > 0 ? d->grad_rows : P.slot;
     return P;
+}
+
+// Which plans carry slots.  The slot count of a workspace follows from the flags of the dims the PLAN was made with; a
+// backward (or the gather of a step call) that derives it from its OWN flags would, when the two disagree, read slots and
+// spans the plan never wrote.  The plan therefore leaves a note {workspace -> slots per Gaussian} here and every later
+// call on that workspace lays it out from the note (a small direct-mapped table: a lost note only means the old
+// behaviour, trusting the caller's flags).
+struct PlanNote {
+    const void *ws;
+    int part_k;
+};
+constexpr int NOTES = 1024;
+PlanNote g_notes[NOTES];
+std::mutex g_notes_mu;
+
+unsigned note_slot(const void *ws) { return (unsigned)(((uintptr_t)ws >> 8) * 2654435761u >> 22) & (NOTES - 1); }
+
+void note_plan(const void *ws, int part_k)
+{
+    std::lock_guard<std::mutex> lk(g_notes_mu);
+    g_notes[note_slot(ws)] = PlanNote{ws, part_k};
+}
+
+// layout of the plan in `ws`: from the note its plan left, else from these dims
+Layout plan_layout(const gsasr_dims *d, const void *ws)
+{
+    int part_k = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_notes_mu);
+        const PlanNote &n = g_notes[note_slot(ws)];
+        if (n.ws == ws && ws) part_k = n.part_k;
+    }
+    return make_layout(d, part_k);
 }
 
 thread_local char tl_err[256] = "";
@@ -452,10 +486,24 @@ __device__ __forceinline__ void prologue_one(const float *__restrict__ q, float 
 
 // PROLOGUE: the step entry points hand over the RAW decoder parameters; the kernel-frame tensors are formed here (and
 // stored for k_bin and the backward) instead of by a separate k_prologue_fwd launch in front of the plan.
+// Where the step size of the prologue comes from: a device array step[b] (the reference's 0-dim tensor
+// default_step_size / scale), or -- sm != nullptr -- the caller's scale_modify pairs themselves: the reference's
+// `assert scale_modify[0] == scale_modify[1]; step = default_step_size / scale_modify[0]`
+// (utils/gaussian_splatting.py:168-171) evaluated HERE, so that the host issues no division, comparison, copy or event
+// per call.  The step is left in `keep[b]` for the backward; a differing pair sets the caller's sticky word.
+struct StepSrc {
+    const float *step;    // [batch] or nullptr
+    const float *sm;      // scale_modify: sample b's pair at sm[b * stride + {0, 1}]
+    int stride;
+    float def_step;       // default_step_size
+    int *mismatch;        // device int[2] or nullptr: {1 + sample index, bits of scale_modify[0]} of a differing pair
+    float *keep;          // [GSASR_MAX_BATCH] in the step workspace: the step sizes used
+};
+
 template <bool PROLOGUE>
 __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restrict__ sigmas,
                                                   const float *__restrict__ coords, PlanView V,
-                                                  const float *__restrict__ raw, const float *__restrict__ step_ptr,
+                                                  const float *__restrict__ raw, StepSrc SS,
                                                   float *__restrict__ o_sig, float *__restrict__ o_xy, float *__restrict__ o_col)
 {
     __shared__ unsigned s_rx[4], s_ry[4];
@@ -477,7 +525,20 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
         float sx, sy, x, y;
         if (PROLOGUE) {
             float o[8];
-            prologue_one(raw + (size_t)i * 9, step_ptr[P.batch > 1 ? i / P.nper : 0], g.h, g.w, o);
+            const int smp = P.batch > 1 ? i / P.nper : 0;
+            float step;
+            if (SS.sm) {
+                const float s0 = SS.sm[(size_t)smp * SS.stride], s1 = SS.sm[(size_t)smp * SS.stride + 1];
+                step = SS.def_step / s0;
+                if (i == smp * P.nper) {
+                    SS.keep[smp] = step;
+                    if (!(s0 == s1) && SS.mismatch) { SS.mismatch[0] = 1 + smp; SS.mismatch[1] = (int)__float_as_uint(s0); }
+                }
+            } else {
+                step = SS.step[smp];
+                if (i == smp * P.nper) SS.keep[smp] = step;
+            }
+            prologue_one(raw + (size_t)i * 9, step, g.h, g.w, o);
             o_sig[i * 3 + 0] = o[0]; o_sig[i * 3 + 1] = o[1]; o_sig[i * 3 + 2] = o[2];
             o_xy[i * 2 + 0] = o[3]; o_xy[i * 2 + 1] = o[4];
             o_col[i * 3 + 0] = o[5]; o_col[i * 3 + 1] = o[6]; o_col[i * 3 + 2] = o[7];
@@ -1917,12 +1978,22 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
             const int qy0 = max(r0 - by0, 0) >> 3, qy1 = min(r1 - by0, BT_H - 1) >> 3;
             int xl[2] = {1, 1}, xh[2] = {0, 0};
             if (hit) {
+                // per-8-row spans (qspan) when the window has at most eight such bands; a taller window (x12 and up) still has
+                // the forward's per-16-row spans in its window words: both quadrant rows of this tile then share one band
                 uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);
-                if (V.qspan) qs = V.qspan[cj[k]];
-                const int t8 = ((by0 - P.row0) >> 3) - ((r0 - P.row0) >> 3), cu = (c0 >> 3) - (bx0 >> 3);
+                const int q0 = (r0 - P.row0) >> 3, b8 = (by0 - P.row0) >> 3;
+                const bool fine = ((r1 - P.row0) >> 3) - q0 < 8;
+                if (fine) {
+                    if (V.qspan) qs = V.qspan[cj[k]];
+                } else if (cw[k].y & 0x8000u) {
+                    const uint2 *sp = reinterpret_cast<const uint2 *>(V.bbox + 2 * (size_t)cj[k]);
+                    const uint2 s0 = sp[1], s1 = sp[2];
+                    qs = make_uint4(s0.x, s0.y, s1.x, s1.y);
+                }
+                const int cu = (c0 >> 3) - (bx0 >> 3);
 #pragma unroll
                 for (int qy = 0; qy < 2; ++qy) {
-                    const unsigned t = (unsigned)(t8 + qy) & 7u, sh = (t & 3u) * 8u;
+                    const unsigned t = (unsigned)(fine ? b8 - q0 + qy : (b8 >> 1) - (q0 >> 1)) & 7u, sh = (t & 3u) * 8u;
                     const int lo = (int)(((t < 4u ? qs.x : qs.z) >> sh) & 0xffu), hi = (int)(((t < 4u ? qs.y : qs.w) >> sh) & 0xffu);
                     if (qy >= qy0 && qy <= qy1) {
                         xl[qy] = max(qx0, cu + lo);
@@ -2629,10 +2700,18 @@ int launch_batch_geo(const gsasr_dims *dims, const PlanView &V, hipStream_t st)
     return GSASR_OK;
 }
 
-int check_ws(const gsasr_dims *dims, const void *ws, size_t ws_bytes, Layout &L)
+int check_ws(const gsasr_dims *dims, const void *ws, size_t ws_bytes, Layout &L, bool planning = false)
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims (need c==3, 2<=h,w<=32767, 0<=row0<=row1<=h)");
-    L = make_layout(dims);
+    if (dims->batch > 1 && dims->grad_rows != 0 && (dims->flags & GSASR_FLAG_CHW_GRAD)) {
+        // planar gradient of a batched canvas [B, 3, grad_rows, w]: every sample's rows must lie inside its planes
+        int hmax = 0;
+        for (int b = 0; b < dims->batch; ++b) hmax = dims->sample_hw[2 * b] > hmax ? dims->sample_hw[2 * b] : hmax;
+        if (dims->grad_rows < hmax) return fail(GSASR_ERR_ARG, "grad_rows is smaller than a sample's height");
+    } else if (dims->batch <= 1 && dims->grad_rows != 0 && dims->grad_rows != dims->row1 - dims->row0) {
+        return fail(GSASR_ERR_ARG, "grad_rows applies to a batched canvas only (leave it 0)");
+    }
+    L = planning ? make_layout(dims) : plan_layout(dims, ws);
     if (!ws || ((uintptr_t)ws & 255u)) return fail(GSASR_ERR_WORKSPACE, "workspace null or not 256-byte aligned");
     if (ws_bytes < L.total) return fail(GSASR_ERR_WORKSPACE, "workspace smaller than gsasr_splat_workspace_bytes()");
     return GSASR_OK;
@@ -2739,10 +2818,11 @@ namespace {
 // The plan: [memset of this parity's counters unless the caller vouches for them] -> classify (with the host prologue
 // fused in when `raw` is given: sigmas/coords/colors are then OUTPUTS) -> [scan] -> bin.
 int plan_impl(const float *sigmas, const float *coords, const float *colors, const gsasr_dims *dims, void *workspace,
-              size_t workspace_bytes, void *stream, const float *raw, const float *step_size)
+              size_t workspace_bytes, void *stream, const float *raw, const StepSrc &SS)
 {
     Layout L;
-    if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
+    if (int rc = check_ws(dims, workspace, workspace_bytes, L, true)) return rc;
+    note_plan(workspace, L.part_k);
     if (dims->s > 0 && (!sigmas || !coords || !colors)) return fail(GSASR_ERR_ARG, "null input pointer");
     hipStream_t st = (hipStream_t)stream;
     const Params P = make_params(dims, L);
@@ -2752,11 +2832,11 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
         if (int rc = launch_batch_geo(dims, V, st)) return rc;   // (a step call has published the geometry already)
     const int nblk = classify_blocks(dims);
     if (raw)
-        hipLaunchKernelGGL(k_classify<true>, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V, raw, step_size,
+        hipLaunchKernelGGL(k_classify<true>, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V, raw, SS,
                            const_cast<float *>(sigmas), const_cast<float *>(coords), const_cast<float *>(colors));
     else
         hipLaunchKernelGGL(k_classify<false>, dim3(nblk), dim3(256), 0, st, P, sigmas, coords, V, (const float *)nullptr,
-                           (const float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+                           SS, (float *)nullptr, (float *)nullptr, (float *)nullptr);
     const int ncls = L.ncells + 1 + NDEAD;
     const unsigned nbin = (unsigned)((dims->s + 255) / 256);
     if (ncls <= FUSED_CELLS && dims->s > 0) {
@@ -2785,7 +2865,7 @@ extern "C" {
 int gsasr_splat_plan(const float *sigmas, const float *coords, const float *colors, const gsasr_dims *dims,
                      void *workspace, size_t workspace_bytes, void *stream)
 {
-    return plan_impl(sigmas, coords, colors, dims, workspace, workspace_bytes, stream, nullptr, nullptr);
+    return plan_impl(sigmas, coords, colors, dims, workspace, workspace_bytes, stream, nullptr, StepSrc{});
 }
 
 int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, float *img,
@@ -2897,8 +2977,9 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
         // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
         const bool unroll = (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
-        // (experiment, off by default: two Gaussians per wave for small windows -- k_render_bwd_pair; its single buffer
-        // resource spans the slab, which must then be addressable with 31 bits)
+        // (Measured dead ends, git history: two Gaussians per wave one after the other, side by side in half waves, and --
+        // round 3 -- sharing every gradient load over the union of their windows: 44-50 us against 37 us at config 2.  The
+        // sweep is bound by instruction issue, not by its loads)
 #define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
         if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
         else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
@@ -2968,14 +3049,15 @@ int gsasr_prologue_backward(const float *gs_parameters, const float *step_size, 
 // ---- whole-step entry points ----------------------------------------------------------------------
 namespace {
 struct StepLayout {
-    size_t plan_bytes, off_sig, off_xy, off_col, off_gsig, off_gxy, off_gcol, off_ghwc, total;
+    size_t plan_bytes, off_step, off_sig, off_xy, off_col, off_gsig, off_gxy, off_gcol, off_ghwc, total;
 };
-StepLayout make_step_layout(const gsasr_dims *d)
+StepLayout make_step_layout(const gsasr_dims *d, const void *planned_ws = nullptr)
 {
     StepLayout S;
     const size_t n = (size_t)d->s;
-    S.plan_bytes = make_layout(d).total;
+    S.plan_bytes = (planned_ws ? plan_layout(d, planned_ws) : make_layout(d)).total;   // (the plan's own slot count: plan_layout)
     size_t o = S.plan_bytes;
+    S.off_step = o; o += align_up(GSASR_MAX_BATCH * 4, 256);   // the step size of every sample, as the prologue used it
     S.off_sig = o;  o += align_up(n * 12, 256);
     S.off_xy = o;   o += align_up(n * 8, 256);
     S.off_col = o;  o += align_up(n * 12, 256);
@@ -3003,8 +3085,8 @@ size_t gsasr_step_workspace_bytes(const gsasr_dims *dims)
 }
 
 namespace {
-// prologue (per-sample sizes and step sizes step_size[b] on a batched canvas) + plan of a whole-step call
-int step_prologue_plan(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
+// prologue (per-sample sizes and step sizes on a batched canvas) + plan of a whole-step call
+int step_prologue_plan(const float *gs_parameters, StepSrc SS, const gsasr_dims *dims, void *workspace,
                        size_t workspace_bytes, void *stream, StepLayout &S)
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
@@ -3014,13 +3096,15 @@ int step_prologue_plan(const float *gs_parameters, const float *step_size, const
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
     char *b = (char *)workspace;
     float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
-    if (dims->s > 0 && (!gs_parameters || !step_size)) return fail(GSASR_ERR_ARG, "null pointer");
+    if (dims->s > 0 && (!gs_parameters || (!SS.step && !SS.sm))) return fail(GSASR_ERR_ARG, "null pointer");
+    if (SS.sm && SS.stride < 2) return fail(GSASR_ERR_ARG, "scale_modify stride must be >= 2");
+    SS.keep = (float *)(b + S.off_step);
     if (dims->batch > 1 && dims->s > 0) {  // the per-sample geometry must be in place before the classify kernel reads it
         const PlanView V = make_view(make_layout(dims), workspace, dims->flags);
         if (int rc = launch_batch_geo(dims, V, (hipStream_t)stream)) return rc;
     }
     // (the prologue runs inside the plan's first kernel: k_classify<true>)
-    return plan_impl(sig, xy, col, dims, workspace, S.plan_bytes, stream, dims->s > 0 ? gs_parameters : nullptr, step_size);
+    return plan_impl(sig, xy, col, dims, workspace, S.plan_bytes, stream, dims->s > 0 ? gs_parameters : nullptr, SS);
 }
 }  // namespace
 
@@ -3028,7 +3112,21 @@ int gsasr_step_forward(const float *gs_parameters, const float *step_size, const
                        size_t workspace_bytes, float *img, void *stream)
 {
     StepLayout S;
-    if (int rc = step_prologue_plan(gs_parameters, step_size, dims, workspace, workspace_bytes, stream, S)) return rc;
+    StepSrc SS{};
+    SS.step = step_size;
+    if (int rc = step_prologue_plan(gs_parameters, SS, dims, workspace, workspace_bytes, stream, S)) return rc;
+    return gsasr_splat_forward(dims, workspace, S.plan_bytes, img, stream);
+}
+
+int gsasr_step_forward_sm(const float *gs_parameters, const float *scale_modify, int sm_stride, float default_step_size,
+                          int *mismatch, const gsasr_dims *dims, void *workspace, size_t workspace_bytes, float *img,
+                          void *stream)
+{
+    StepLayout S;
+    StepSrc SS{};
+    SS.sm = scale_modify; SS.stride = sm_stride; SS.def_step = default_step_size; SS.mismatch = mismatch;
+    if (!scale_modify && dims && dims->s > 0) return fail(GSASR_ERR_ARG, "null pointer");
+    if (int rc = step_prologue_plan(gs_parameters, SS, dims, workspace, workspace_bytes, stream, S)) return rc;
     return gsasr_splat_forward(dims, workspace, S.plan_bytes, img, stream);
 }
 
@@ -3038,12 +3136,13 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
     if (dims->flags & GSASR_FLAG_STRIDE8) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 does not apply to the step entry points");
-    const StepLayout S = make_step_layout(dims);
+    const StepLayout S = make_step_layout(dims, workspace);
     if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
     char *b = (char *)workspace;
     float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
     float *gs = (float *)(b + S.off_gsig), *gc = (float *)(b + S.off_gxy), *gk = (float *)(b + S.off_gcol);
+    if (!step_size) step_size = (const float *)(b + S.off_step);   // what the forward's prologue used (gsasr_step_forward_sm)
     gsasr_dims d = *dims;
     d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
     if ((d.flags & GSASR_FLAG_CHW_GRAD) && S.total > S.off_ghwc && dims->s > 0 && d.row1 > d.row0) {
@@ -3065,7 +3164,7 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
     if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
     const dim3 grid((unsigned)((dims->s + 255) / 256)), block(256);
     if (mode != 0) {   // tile-stationary: gather of the slots + chain rule in one kernel
-        const Layout L = make_layout(dims);
+        const Layout L = plan_layout(dims, workspace);
         const PlanView V = make_view(L, workspace);
         hipLaunchKernelGGL(k_prologue_bwd_gather, grid, block, 0, (hipStream_t)stream, make_params(&d, L), V, (int)(mode == 2 || d.row1 == d.row0),
                            gs_parameters, step_size, g_parameters);
@@ -3213,7 +3312,21 @@ int gsasr_step_sample_forward(const float *gs_parameters, const float *step_size
                               size_t sample_ws_bytes, void *stream)
 {
     StepLayout S;
-    if (int rc = step_prologue_plan(gs_parameters, step_size, dims, workspace, workspace_bytes, stream, S)) return rc;
+    StepSrc SS{};
+    SS.step = step_size;
+    if (int rc = step_prologue_plan(gs_parameters, SS, dims, workspace, workspace_bytes, stream, S)) return rc;
+    return gsasr_splat_sample_forward(dims, workspace, S.plan_bytes, points, n_points, out, sample_ws, sample_ws_bytes, stream);
+}
+
+int gsasr_step_sample_forward_sm(const float *gs_parameters, const float *scale_modify, int sm_stride, float default_step_size,
+                                 int *mismatch, const gsasr_dims *dims, void *workspace, size_t workspace_bytes, const int *points,
+                                 int n_points, float *out, void *sample_ws, size_t sample_ws_bytes, void *stream)
+{
+    StepLayout S;
+    StepSrc SS{};
+    SS.sm = scale_modify; SS.stride = sm_stride; SS.def_step = default_step_size; SS.mismatch = mismatch;
+    if (!scale_modify && dims && dims->s > 0) return fail(GSASR_ERR_ARG, "null pointer");
+    if (int rc = step_prologue_plan(gs_parameters, SS, dims, workspace, workspace_bytes, stream, S)) return rc;
     return gsasr_splat_sample_forward(dims, workspace, S.plan_bytes, points, n_points, out, sample_ws, sample_ws_bytes, stream);
 }
 
@@ -3223,12 +3336,13 @@ int gsasr_step_sample_backward(const float *gs_parameters, const float *step_siz
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
     if (dims->flags & GSASR_FLAG_STRIDE8) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 does not apply to the step entry points");
-    const StepLayout S = make_step_layout(dims);
+    const StepLayout S = make_step_layout(dims, workspace);
     if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");
     char *b = (char *)workspace;
     float *sig = (float *)(b + S.off_sig), *xy = (float *)(b + S.off_xy), *col = (float *)(b + S.off_col);
     float *gs = (float *)(b + S.off_gsig), *gc = (float *)(b + S.off_gxy), *gk = (float *)(b + S.off_gcol);
+    if (!step_size) step_size = (const float *)(b + S.off_step);   // what the forward's prologue used
     gsasr_dims d = *dims;
     d.flags |= GSASR_FLAG_OVERWRITE_GRADS;
     if (int rc = gsasr_splat_sample_backward(sig, xy, col, grad_out, gs, gc, gk, &d, workspace, S.plan_bytes, points, n_points,

@@ -17,6 +17,7 @@ is part of the API surface and is never used as a fallback for the HIP path.
 """
 from __future__ import annotations
 
+import atexit
 import math
 
 import torch
@@ -31,7 +32,11 @@ def _capturing() -> bool:
 
 
 def _hw(sr_size):
-    # sr_size arrives as list, CPU tensor or GPU int tensor (gsasr_model.py:148,202); make ints once
+    # sr_size arrives as list, CPU tensor or GPU int tensor (gsasr_model.py:148,202); make ints once -- a GPU tensor
+    # with ONE device-to-host copy (the reference's `int(sr_size[0])`, `int(sr_size[1])` are two synchronisations)
+    if torch.is_tensor(sr_size):
+        v = sr_size.tolist()
+        return int(v[0]), int(v[1])
     return int(sr_size[0]), int(sr_size[1])
 
 
@@ -90,23 +95,34 @@ def _tile_backward(n_pixels: int, n_gaussians: int) -> bool:
     return n_pixels >= 4 * n_gaussians and n_pixels >= 128 * 1024
 
 
+def _plan_flags(needs_grad: bool, tile: bool) -> int:
+    """flags of a fused step's plan: the backward kernel is chosen HERE, explicitly (the library's own default would
+    otherwise plan slots for large images that this module then never uses); planar gradient in, forward-only plans
+    for inference"""
+    from . import _cabi
+    if not needs_grad:
+        return _cabi.FLAG_FORWARD_ONLY
+    return _cabi.FLAG_CHW_GRAD | (_cabi.FLAG_BWD_TILE if tile else _cabi.FLAG_BWD_GAUSSIAN)
+
+
 class _FusedStep(torch.autograd.Function):
     """raw decoder output `gs_parameters[N,9]` -> `[3,H,W]` image with ONE prologue kernel (activations +
     kernel-frame conversion, reference :174-180 and :121-123) in front of the splat, the splat writing the
     planar layout directly (no `permute(2,0,1).contiguous()` pass, reference :129), and the matching chain
     rule behind the splat's backward.  Replaces ~15 elementwise launches in forward
-    and ~30 in backward; numerically the same expressions evaluated in fp32."""
+    and ~30 in backward; numerically the same expressions evaluated in fp32.  The step size is `step` (a `[1]`
+    device tensor), or -- `step is None` -- `default_step / scale_modify[0]` formed on the device from the caller's
+    `scale_modify` tensor (`_StepSource`)."""
 
     @staticmethod
     @fp32_boundary_fwd
-    def forward(ctx, gs_parameters, step, H, W, dmax):
+    def forward(ctx, gs_parameters, step, H, W, dmax, scale_modify=None, default_step=1.2):
         from . import _cabi
         # the planar gradient autograd hands back goes to the C call as it is (GSASR_FLAG_CHW_GRAD): the
         # tile-stationary backward stages the planes directly, the Gaussian-stationary one behind one interleaving
         # kernel inside the same call -- no torch permute / allocation on the host path either way
-        tile = _tile_backward(H * W, gs_parameters.shape[0])
-        flags = (_cabi.FLAG_CHW_GRAD | (_cabi.FLAG_BWD_TILE if tile else 0)) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
-        img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax, flags)   # one C call: prologue + plan + splat
+        flags = _plan_flags(ctx.needs_input_grad[0], _tile_backward(H * W, gs_parameters.shape[0]))
+        img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax, flags, scale_modify, default_step)   # one C call: prologue + plan + splat
         ctx.save_for_backward(gs_parameters, step)
         ctx.plan = plan
         return img
@@ -117,7 +133,8 @@ class _FusedStep(torch.autograd.Function):
     def backward(ctx, grad_output):
         from . import _cabi
         gs_parameters, step = ctx.saved_tensors
-        return _cabi.step_backward(ctx.plan, gs_parameters, step, grad_output.contiguous(), chw=True), None, None, None, None
+        g = _cabi.step_backward(ctx.plan, gs_parameters, step, grad_output.contiguous(), chw=True)
+        return g, None, None, None, None, None, None
 
 
 class _FusedStepSampled(torch.autograd.Function):
@@ -127,9 +144,9 @@ class _FusedStepSampled(torch.autograd.Function):
 
     @staticmethod
     @fp32_boundary_fwd
-    def forward(ctx, gs_parameters, step, H, W, dmax, points):
+    def forward(ctx, gs_parameters, step, H, W, dmax, points, scale_modify=None, default_step=1.2):
         from . import _cabi
-        out, plan, state = _cabi.step_sample_forward(gs_parameters, step, H, W, dmax, points)
+        out, plan, state = _cabi.step_sample_forward(gs_parameters, step, H, W, dmax, points, scale_modify, default_step)
         ctx.save_for_backward(gs_parameters, step)
         ctx.plan, ctx.state = plan, state
         return out
@@ -141,7 +158,7 @@ class _FusedStepSampled(torch.autograd.Function):
         from . import _cabi
         gs_parameters, step = ctx.saved_tensors
         return (_cabi.step_sample_backward(ctx.plan, ctx.state, gs_parameters, step, grad_output.contiguous()),
-                None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class _FusedBatchSampled(torch.autograd.Function):
@@ -196,7 +213,8 @@ _STEP_TENSORS = {}      # (value, device) -> [1] float32 device tensor of a pyth
 def _step_tensor(step_size, dev):
     if torch.is_tensor(step_size):
         return step_size.detach().to(device=dev, dtype=torch.float32).reshape(1)   # stays on the device: no sync
-    key = (float(step_size), dev)
+    # (keyed by the stream as well: the tensor is filled asynchronously on the stream that first asks for the value)
+    key = (float(step_size), dev, None if _capturing() else torch.cuda.current_stream(dev).cuda_stream)
     t = _STEP_TENSORS.get(key)
     if t is None or _capturing():
         t = torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
@@ -207,11 +225,24 @@ def _step_tensor(step_size, dev):
     return t
 
 
+class _StepSource:
+    """`default_step_size / scale_modify[0]`, not evaluated: the fused entry points hand the caller's `scale_modify`
+    tensor to the plan's first kernel, which forms the step size and checks `[0] == [1]` itself (gsasr_step_forward_sm)"""
+    __slots__ = ("scale_modify", "default_step")
+
+    def __init__(self, scale_modify, default_step):
+        self.scale_modify, self.default_step = scale_modify, default_step
+
+
 def _fused_render(gs_parameters, sr_size, step_size, dmax):
-    """[3,H,W] through the fused prologue; `step_size` may be a python number or a (GPU) tensor."""
+    """[3,H,W] through the fused prologue; `step_size` may be a python number, a (GPU) tensor or a `_StepSource`."""
     H, W = _hw(sr_size)
+    dm = None if dmax is None else float(dmax)
+    if step_size.__class__ is _StepSource:
+        deferred_asserts.watch(gs_parameters.device)
+        return _FusedStep.apply(gs_parameters.contiguous(), None, H, W, dm, step_size.scale_modify, step_size.default_step)
     step = _step_tensor(step_size, gs_parameters.device)
-    return _FusedStep.apply(gs_parameters.contiguous(), step, H, W, None if dmax is None else float(dmax))
+    return _FusedStep.apply(gs_parameters.contiguous(), step, H, W, dm)
 
 
 def rendering_cuda(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device):
@@ -295,55 +326,121 @@ def rendering_python(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size,
 
 class _DeferredAsserts:
     """The reference asserts `scale_modify[0] == scale_modify[1]` on every call (:169), which for a CUDA tensor is a
-    device-to-host synchronisation per call -- sixteen per training step in the reference's per-sample loop.  For
-    CUDA tensors the comparison is evaluated on the device, its result copied to pinned host memory without
-    blocking, and examined at a LATER call of the API (or by `flush()`), once the copy has landed: the same
-    AssertionError, at most a few calls late, and no pipeline drain.  Python numbers and CPU tensors are checked
-    on the spot, exactly as in the reference."""
+    device-to-host synchronisation per call -- sixteen per training step in the reference's per-sample loop.  Here:
+
+    * fused path (`_StepSource`): the plan's first kernel compares the pair and sets a sticky per-device word
+      (`_cabi.mismatch_flag`) when it differs.  `watch()` copies that word to pinned memory every `WATCH_EVERY` calls
+      (non-blocking) and examines the copy once it has landed -- no torch kernel, copy or event per call.
+    * other CUDA-tensor callers (`add()`): the comparison runs on the device, its result and the two values go to
+      pinned memory without blocking, and are examined at a LATER call of the API, once the copy has landed.
+
+    Either way: the same AssertionError (with the offending values), at most a few calls late, and no pipeline drain;
+    `flush()` -- also registered with `atexit` -- waits for everything outstanding.  Python numbers and CPU tensors are
+    checked on the spot, exactly as in the reference."""
 
     RING = 256          # pinned result slots, reused round robin (allocating pinned memory per call costs more than the check)
+    WATCH_EVERY = 64
 
     def __init__(self):
         self.pending = []
         self.ring = None
         self.next = 0
+        self.watched = {}       # device -> calls since the last look at its mismatch word
 
-    def add(self, ok: torch.Tensor, message: str) -> None:
+    def _slot(self):
         if self.ring is None:
-            self.ring = torch.empty(self.RING, dtype=torch.bool, pin_memory=True)
+            self.ring = torch.empty(self.RING, 3, dtype=torch.float32, pin_memory=True)
         if len(self.pending) >= self.RING:      # every slot in flight: wait for the oldest
             self.poll_one(wait=True)
-        host = self.ring[self.next: self.next + 1]
+        host = self.ring[self.next]
         self.next = (self.next + 1) % self.RING
-        host.copy_(ok.reshape(1), non_blocking=True)
+        return host
+
+    def add(self, pair: torch.Tensor, message: str) -> None:
+        """`pair` = the two values (device tensor); fails later with `message` + the values if they differ"""
+        host = self._slot()
+        a, b = pair[0], pair[1]
+        host.copy_(torch.stack([a, b, (a == b).to(a.dtype)]).to(torch.float32), non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ok.device))
-        self.pending.append((ev, host, message))
+        ev.record(torch.cuda.current_stream(pair.device))
+        self.pending.append((ev, host, message, None))
+        self.poll()
+
+    def watch(self, dev, force: bool = False) -> None:
+        """count a fused call on `dev`; every WATCH_EVERY-th one (or `force`) fetches the device's mismatch word"""
+        n = self.watched.get(dev, 0) + 1
+        if n < self.WATCH_EVERY and not force:
+            self.watched[dev] = n
+            return
+        self.watched[dev] = 0
+        if _capturing():
+            return
+        from . import _cabi
+        flag = _cabi.mismatch_flag(dev)
+        host = self._slot()
+        host[:2].view(torch.int32).copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.pending.append((ev, host, None, flag))
         self.poll()
 
     def poll_one(self, wait: bool) -> None:
-        ev, host, message = self.pending.pop(0)
+        ev, host, message, flag = self.pending.pop(0)
         if wait:
             ev.synchronize()
-        assert bool(host[0]), message
+        if flag is not None:        # the sticky word of the fused path: {1 + sample index, bits of scale_modify[0]}
+            word = host[:2].view(torch.int32)
+            if int(word[0]) != 0:
+                sample, first = int(word[0]) - 1, float(host[1])      # (word[1] holds the float's bits)
+                flag.zero_()
+                raise AssertionError(f"scale_modify is not the same (sample {sample} of a fused call: scale_modify[0] = {first})")
+            return
+        assert bool(host[2] != 0), f"{message}-[{float(host[0])}, {float(host[1])}]"
 
     def poll(self, wait: bool = False) -> None:
         while self.pending and (wait or self.pending[0][0].query()):
             self.poll_one(wait)
 
     def flush(self) -> None:
+        if torch.cuda.is_available():
+            for dev in list(self.watched):
+                if self.watched[dev]:
+                    self.watch(dev, force=True)
         self.poll(wait=True)
 
 
 deferred_asserts = _DeferredAsserts()
 
 
-def _step_size(scale, scale_modify, default_step_size, mode):
+def _flush_at_exit():
+    try:
+        deferred_asserts.flush()
+    except AssertionError as e:      # (an exception in an atexit hook is printed, not raised: say it plainly)
+        import sys
+        print(f"gsasr_amd: deferred check failed at exit: {e}", file=sys.stderr)
+    except Exception:
+        pass
+
+
+atexit.register(_flush_at_exit)
+
+
+def _sm_source_ok(scale_modify) -> bool:
+    """can the fused entry points read this `scale_modify` on the device themselves (a `[2]`-like float32 CUDA tensor)"""
+    return (scale_modify.__class__ is torch.Tensor and scale_modify.is_cuda and scale_modify.dtype is torch.float32
+            and scale_modify.dim() == 1 and scale_modify.shape[0] >= 2 and scale_modify.stride(0) == 1)
+
+
+def _step_size(scale, scale_modify, default_step_size, mode, fused=False):
+    """the reference's step size (:163-172).  `fused`: the caller is the fused path, which can take a `_StepSource`
+    (scale_modify left on the device, nothing evaluated here) instead of a value"""
     if mode == 'scale':
         final_scale = scale
     elif mode == 'scale_modify':
+        if fused and _sm_source_ok(scale_modify):
+            return _StepSource(scale_modify, float(default_step_size))
         if torch.is_tensor(scale_modify) and scale_modify.is_cuda and not _capturing():
-            deferred_asserts.add(scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify.shape}")
+            deferred_asserts.add(scale_modify, "scale_modify is not the same")
         elif not (torch.is_tensor(scale_modify) and scale_modify.is_cuda):
             assert scale_modify[0] == scale_modify[1], f"scale_modify is not the same-{scale_modify}"
         final_scale = scale_modify[0]
@@ -388,19 +485,24 @@ def _sample(final_image, sample_coords):
 def generate_2D_gaussian_splatting_step(sr_size, gs_parameters, scale, scale_modify, sample_coords=None,
                                         default_step_size=1.2, cuda_rendering=True, mode='scale_modify',
                                         if_dmax=True, dmax_mode='fix', dmax=25):
-    step_size = _step_size(scale, scale_modify, default_step_size, mode)
     if gs_parameters.dtype != torch.float32:
         # under bf16 autocast the decoder happens to emit fp32; make that explicit
         gs_parameters = gs_parameters.float()
-    if cuda_rendering and _fused_ok(gs_parameters):
+    fused = cuda_rendering and _fused_ok(gs_parameters)
+    step_size = _step_size(scale, scale_modify, default_step_size, mode, fused=fused)
+    if fused:
         # fused prologue + splat (same maths as the unfused branch below, one kernel instead of ~15)
-        dmax_eff = _resolve_dmax(dmax, dmax_mode, sr_size) if if_dmax else None
-        pts = _as_points(sample_coords) if sample_coords is not None else None
         H, W = _hw(sr_size)
+        dmax_eff = _resolve_dmax(dmax, dmax_mode, (H, W)) if if_dmax else None
+        pts = _as_points(sample_coords) if sample_coords is not None else None
         if pts is not None and 0 < pts.shape[0] <= SAMPLED_MAX_FRACTION * H * W:
-            return _FusedStepSampled.apply(gs_parameters.contiguous(), _step_tensor(step_size, gs_parameters.device), H, W,
-                                           None if dmax_eff is None else float(dmax_eff), pts)
-        return _sample(_fused_render(gs_parameters, sr_size, step_size, dmax_eff), sample_coords)
+            dm = None if dmax_eff is None else float(dmax_eff)
+            if step_size.__class__ is _StepSource:
+                deferred_asserts.watch(gs_parameters.device)
+                return _FusedStepSampled.apply(gs_parameters.contiguous(), None, H, W, dm, pts, step_size.scale_modify,
+                                               step_size.default_step)
+            return _FusedStepSampled.apply(gs_parameters.contiguous(), _step_tensor(step_size, gs_parameters.device), H, W, dm, pts)
+        return _sample(_fused_render(gs_parameters, (H, W), step_size, dmax_eff), sample_coords)
     sigma_x, sigma_y, rho, coords, colours_with_alpha = _activate(gs_parameters)
     dev = sigma_x.device
     if cuda_rendering:
@@ -426,11 +528,11 @@ class _FusedBatch(torch.autograd.Function):
 
     @staticmethod
     @fp32_boundary_fwd
-    def forward(ctx, gs_parameters, steps, sizes, dmax):
+    def forward(ctx, gs_parameters, steps, sizes, dmax, scale_modify=None, default_step=1.2):
         from . import _cabi
         tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1])
-        flags = (_cabi.FLAG_CHW_GRAD | (_cabi.FLAG_BWD_TILE if tile else 0)) if ctx.needs_input_grad[0] else _cabi.FLAG_FORWARD_ONLY
-        img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax, flags)
+        flags = _plan_flags(ctx.needs_input_grad[0], tile)
+        img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax, flags, scale_modify, default_step)
         ctx.save_for_backward(gs_parameters, steps)
         ctx.plan = plan
         ctx.h_max = max(h for h, _ in sizes)
@@ -443,7 +545,7 @@ class _FusedBatch(torch.autograd.Function):
         from . import _cabi
         gs_parameters, steps = ctx.saved_tensors
         # [B,3,Hmax,Wmax] read in place (rows per plane = Hmax <= slot): pixels outside a sample's own grid are never read
-        return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad_output.contiguous(), chw=True), None, None, None
+        return _cabi.batch_backward(ctx.plan, gs_parameters, steps, grad_output.contiguous(), chw=True), None, None, None, None, None
 
 
 def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
@@ -454,7 +556,7 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
         if all(torch.is_tensor(v) for v in vals):
             return torch.stack([v.reshape(()) for v in vals]).to(device=dev, dtype=torch.float32)
         # python numbers: one host-to-device copy per DISTINCT tuple of values, not per call
-        key = (tuple(float(v) for v in vals), dev)
+        key = (tuple(float(v) for v in vals), dev, None if _capturing() else torch.cuda.current_stream(dev).cuda_stream)
         t = _STEP_TENSORS.get(key)
         if t is None or _capturing():
             t = torch.tensor(key[0], dtype=torch.float32, device=dev)
@@ -470,7 +572,8 @@ def _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev):
             both = torch.stack([sm.reshape(-1)[:2] for sm in scale_modifies]).to(device=dev, dtype=torch.float32)   # [B,2], one kernel
             a, b = both[:, 0], both[:, 1]
             if not _capturing():      # the reference's assert, without draining the pipeline
-                deferred_asserts.add((a == b).all(), "scale_modify is not the same (batched step)")
+                bad = (a != b).to(torch.float32)
+                deferred_asserts.add(torch.stack([bad.sum(), bad.new_zeros(())]), "scale_modify is not the same (batched step): differing pairs, 0")
         else:
             a, b = col([sm[0] for sm in scale_modifies]), col([sm[1] for sm in scale_modifies])
             assert bool((a == b).all()), f"scale_modify is not the same-{scale_modifies}"
@@ -495,7 +598,10 @@ def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_
     `sample_coords` `[B,S,2]` (row, column on each sample's own grid; gsasr_model.py:196-197) it returns the
     `[B,3,S]` stack of the per-sample `[3,S]` results instead."""
     B = gs_parameters.shape[0]
-    sizes = [_hw(s) for s in sr_sizes]
+    if torch.is_tensor(sr_sizes) and sr_sizes.dim() == 2:      # e.g. the [B,2] GPU tensor of gsasr_model.py:147: ONE copy to the host
+        sizes = [(int(r[0]), int(r[1])) for r in sr_sizes.tolist()]
+    else:
+        sizes = [_hw(s) for s in sr_sizes]
     if not (len(sizes) == B == len(scales) == len(scale_modifies)):
         raise ValueError("one sr_size, scale and scale_modify per sample")
     if gs_parameters.dtype != torch.float32:
@@ -515,9 +621,20 @@ def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_
         return torch.cat(parts)
     if 1 < B <= cap and gs_parameters.is_cuda and gs_parameters.dim() == 3 and gs_parameters.shape[2] == 9 and uniform_dmax:
         dev = gs_parameters.device
-        steps = _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev)
-        dmax_eff = _resolve_dmax(dmax, dmax_mode, sr_sizes[0]) if if_dmax else None
+        dmax_eff = _resolve_dmax(dmax, dmax_mode, sizes[0]) if if_dmax else None
         dm = None if dmax_eff is None else float(dmax_eff)
+        if sample_coords is None and mode == 'scale_modify':
+            # scale_modify pairs that are already on the device go to the plan's first kernel as they are (one [B,2]
+            # tensor: no kernel at all; a list of [2] tensors: one torch.stack): no division, comparison or copy here
+            sm = None
+            if torch.is_tensor(scale_modifies) and scale_modifies.dim() == 2 and _sm_source_ok(scale_modifies[0]):
+                sm = scale_modifies
+            elif not torch.is_tensor(scale_modifies) and all(_sm_source_ok(v) for v in scale_modifies):
+                sm = torch.stack([v[:2] for v in scale_modifies])
+            if sm is not None:
+                deferred_asserts.watch(dev)
+                return _FusedBatch.apply(gs_parameters.contiguous(), None, tuple(sizes), dm, sm, float(default_step_size))
+        steps = _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev)
         if sample_coords is None:
             return _FusedBatch.apply(gs_parameters.contiguous(), steps, tuple(sizes), dm)
         pts = sample_coords if torch.is_tensor(sample_coords) else torch.as_tensor(sample_coords)

@@ -23,12 +23,9 @@ class GSCUDA(Function):
     @fp32_boundary_fwd
     def forward(ctx, sigmas, coords, colors, rendered_img):
         ctx.save_for_backward(sigmas, coords, colors)
-        h, w, c = rendered_img.shape
-        if c != 3:
+        if rendered_img.dim() != 3 or rendered_img.shape[2] != 3:
             raise RuntimeError("rendered_img must be [H,W,3]")
-        plan = _cabi.plan(sigmas, coords, colors, h, w, None)
-        _cabi.forward(plan, rendered_img)
-        ctx.plan = plan
+        ctx.plan = _cabi.plan_forward(sigmas, coords, colors, rendered_img, None)   # plan + splat, one host call
         return rendered_img
 
     @staticmethod
@@ -38,12 +35,7 @@ class GSCUDA(Function):
         sigmas, coords, colors = ctx.saved_tensors
         # (the reference zero-fills three tensors and lets the kernel add into them; the backward
         # stores instead, which saves three memsets per step)
-        grads_sigmas = torch.empty_like(sigmas)
-        grads_coords = torch.empty_like(coords)
-        grads_colors = torch.empty_like(colors)
-        _cabi.backward(ctx.plan, sigmas, coords, colors, grad_output.contiguous(), grads_sigmas, grads_coords,
-                       grads_colors, overwrite=True)
-        return (grads_sigmas, grads_coords, grads_colors, None)
+        return (*_cabi.backward_new(ctx.plan, sigmas, coords, colors, grad_output), None)
 
 
 def gaussiansplatting_render(sigmas, coords, colors, image_size):

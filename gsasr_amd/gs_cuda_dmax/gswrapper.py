@@ -20,12 +20,9 @@ class GSCUDA(Function):
     def forward(ctx, sigmas, coords, colors, rendered_img, dmax):
         ctx.save_for_backward(sigmas, coords, colors)
         ctx.dmax = dmax
-        h, w, c = rendered_img.shape
-        if c != 3:
+        if rendered_img.dim() != 3 or rendered_img.shape[2] != 3:
             raise RuntimeError("rendered_img must be [H,W,3]")
-        plan = _cabi.plan(sigmas, coords, colors, h, w, float(dmax))
-        _cabi.forward(plan, rendered_img)
-        ctx.plan = plan
+        ctx.plan = _cabi.plan_forward(sigmas, coords, colors, rendered_img, float(dmax))   # plan + splat, one host call
         return rendered_img
 
     @staticmethod
@@ -35,12 +32,7 @@ class GSCUDA(Function):
         sigmas, coords, colors = ctx.saved_tensors
         # (the reference zero-fills three tensors and lets the kernel add into them; the backward
         # stores instead, which saves three memsets per step)
-        grads_sigmas = torch.empty_like(sigmas)
-        grads_coords = torch.empty_like(coords)
-        grads_colors = torch.empty_like(colors)
-        _cabi.backward(ctx.plan, sigmas, coords, colors, grad_output.contiguous(), grads_sigmas, grads_coords,
-                       grads_colors, overwrite=True)
-        return (grads_sigmas, grads_coords, grads_colors, None, None)
+        return (*_cabi.backward_new(ctx.plan, sigmas, coords, colors, grad_output), None, None)
 
 
 def gaussiansplatting_render(sigmas, coords, colors, image_size, dmax=100):

@@ -44,7 +44,7 @@ extern "C" {
 #define GSASR_API
 #endif
 
-#define GSASR_SPLAT_ABI_VERSION 3 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags */
+#define GSASR_SPLAT_ABI_VERSION 4 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags; 4: the _sm step entry points, step_size = NULL in the step backwards */
 
 enum gsasr_status {
     GSASR_OK = 0,
@@ -76,8 +76,11 @@ enum gsasr_status {
 #define GSASR_FLAG_BWD_TILE 256u      /* ... or tile-stationary (one workgroup per 32x16-px tile, grad_img staged once
                                          in LDS, deterministic partial-gradient slots + gather).  Set it on the dims the
                                          PLAN is made with: the workspace then carries the slots (32 * 8 or 16 bytes per
-                                         Gaussian) and the per-quadrant ellipse spans; a backward asked for this kernel
-                                         on a plan without slots accumulates with fp32 atomics instead (slower) */
+                                         Gaussian) and the per-quadrant ellipse spans.  Whether a workspace carries slots
+                                         is the PLAN's decision (the library remembers it per workspace): a backward that
+                                         asks for this kernel on a plan without slots runs the Gaussian-stationary kernel
+                                         instead (with GSASR_FLAG_CHW_GRAD: the atomic variant below) -- never reads slots
+                                         that were not written */
 #define GSASR_FLAG_BWD_ATOMIC 512u    /* tile-stationary with ONE fp32 atomic set per (tile, Gaussian) instead of the
                                          slots (the measured alternative of DESIGN.md 3c; order-dependent rounding)  */
 #define GSASR_FLAG_COUNTERS_CLEAN 1024u /* plan: the caller keeps this workspace between plans and promises that the
@@ -170,10 +173,21 @@ GSASR_API int gsasr_prologue_backward(const float *gs_parameters, const float *s
  * prologue + plan + forward, and splat-backward + prologue-backward.  The workspace additionally holds the
  * kernel-frame tensors and their gradients (gsasr_step_workspace_bytes >= gsasr_splat_workspace_bytes).
  * Forward honours dims.flags (OVERWRITE_IMAGE, CHW_IMAGE); backward always stores g_parameters[n,9] and
- * expects grad_img as [row1-row0, w, 3]. */
+ * reads grad_img as [row1-row0, w, 3], or with GSASR_FLAG_CHW_GRAD as planar [3, row1-row0, w] (batched canvas:
+ * [B, 3, grad_rows, w], grad_rows >= every sample's height).  step_size = NULL in the backward: the step sizes the
+ * forward's prologue used (kept in the workspace) -- the counterpart of the _sm forward below.
+ *
+ * gsasr_step_forward_sm: the reference's `scale_modify` calling convention (utils/gaussian_splatting.py:166-171:
+ * `assert scale_modify[0] == scale_modify[1]`, step = default_step_size / scale_modify[0]) evaluated on the DEVICE by the
+ * plan's first kernel.  scale_modify = device floats, sample b's pair at scale_modify[b * sm_stride + {0, 1}]
+ * (sm_stride >= 2; one image: b = 0).  mismatch = device int[2] or NULL: set to {1 + b, bits of scale_modify[b][0]} when
+ * a pair differs and never cleared here -- the caller reads it when convenient (no host synchronisation per call). */
 GSASR_API size_t gsasr_step_workspace_bytes(const gsasr_dims *dims);
 GSASR_API int gsasr_step_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
                        size_t workspace_bytes, float *img, void *stream);
+GSASR_API int gsasr_step_forward_sm(const float *gs_parameters, const float *scale_modify, int sm_stride, float default_step_size,
+                          int *mismatch, const gsasr_dims *dims, void *workspace, size_t workspace_bytes, float *img,
+                          void *stream);
 GSASR_API int gsasr_step_backward(const float *gs_parameters, const float *step_size, const float *grad_img,
                         float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
                         void *stream);
@@ -206,6 +220,10 @@ GSASR_API int gsasr_splat_sample_backward(const float *sigmas, const float *coor
 GSASR_API int gsasr_step_sample_forward(const float *gs_parameters, const float *step_size, const gsasr_dims *dims, void *workspace,
                               size_t workspace_bytes, const int *points, int n_points, float *out, void *sample_ws,
                               size_t sample_ws_bytes, void *stream);
+GSASR_API int gsasr_step_sample_forward_sm(const float *gs_parameters, const float *scale_modify, int sm_stride,
+                                 float default_step_size, int *mismatch, const gsasr_dims *dims, void *workspace,
+                                 size_t workspace_bytes, const int *points, int n_points, float *out, void *sample_ws,
+                                 size_t sample_ws_bytes, void *stream);
 GSASR_API int gsasr_step_sample_backward(const float *gs_parameters, const float *step_size, const float *grad_out,
                                float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
                                const int *points, int n_points, void *sample_ws, size_t sample_ws_bytes, void *stream);
