@@ -19,12 +19,17 @@ import types
 
 
 def _parent(name: str):
-    """the real package `name` if importable, else an empty stand-in (registered in sys.modules)"""
+    """the real package `name` if it exists, else an empty stand-in (registered in sys.modules).  Only "there is no such
+    package" makes a stand-in: any other failure while importing a package that DOES exist (a missing dependency such
+    as cv2 inside basicsr.utils, a syntax error, ...) is the user's real problem and is raised as it is."""
     if name in sys.modules:
         return sys.modules[name]
     try:
         return importlib.import_module(name)
-    except ImportError:
+    except ModuleNotFoundError as e:
+        # e.name is the module that could not be found: the package itself (or one of its parents) => stand-in
+        if e.name is None or not (name == e.name or name.startswith(e.name + ".")):
+            raise
         m = types.ModuleType(name)
         m.__path__ = []            # a package with nothing in it besides what install() attaches
         m.__gsasr_amd_stub__ = True
@@ -40,16 +45,24 @@ def install(also_gaussian_splatting: bool = False) -> None:
     from .gs_cuda_dmax import gswrapper as bounded
 
     sys.modules["gscuda"] = gscuda
+    # 1. The LEAF names first, before any parent package is imported: importing the real `basicsr` runs
+    #    `from .models import *`, which imports gsasr_model.py, which does `from basicsr.utils.gaussian_splatting import
+    #    generate_2D_gaussian_splatting_step` -- the import machinery imports the parents and then finds the leaf already
+    #    registered here, so the model classes bind THIS package's functions (registered afterwards, they would have bound
+    #    the reference's unfused host path for good).
+    leaves = {}
     for root in ("utils", "basicsr.utils"):
-        parts = root.split(".")
-        for k in range(1, len(parts) + 1):
-            _parent(".".join(parts[:k]))
-        for sub, mod in (("gs_cuda", unbounded), ("gs_cuda_dmax", bounded)):
-            pkg = _parent(f"{root}.{sub}")
-            sys.modules[f"{root}.{sub}.gswrapper"] = mod      # the leaf: never the reference's JIT-compiling CUDA wrapper
-            setattr(pkg, "gswrapper", mod)
+        leaves[f"{root}.gs_cuda.gswrapper"] = unbounded      # never the reference's JIT-compiling CUDA wrappers
+        leaves[f"{root}.gs_cuda_dmax.gswrapper"] = bounded
         if also_gaussian_splatting:   # the host API and the tiled-inference driver built on it
             from . import gaussian_splatting, split_and_joint_image
-            for name, mod in (("gaussian_splatting", gaussian_splatting), ("split_and_joint_image", split_and_joint_image)):
-                sys.modules[f"{root}.{name}"] = mod
-                setattr(sys.modules[root], name, mod)
+            leaves[f"{root}.gaussian_splatting"] = gaussian_splatting
+            leaves[f"{root}.split_and_joint_image"] = split_and_joint_image
+    sys.modules.update(leaves)
+    # 2. The parents: the real packages where they exist, and the leaves attached to them as attributes
+    for name, mod in leaves.items():
+        parts = name.split(".")
+        for k in range(1, len(parts)):
+            _parent(".".join(parts[:k]))
+        setattr(sys.modules[".".join(parts[:-1])], parts[-1], mod)
+        sys.modules[name] = mod       # (a parent's own __init__ may have imported and re-registered its leaf meanwhile)

@@ -185,3 +185,43 @@ def test_compat_install_keeps_real_packages_importable(tmp_path):
         "print('ok')\n" % (ROOT, str(tmp_path)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr
+
+
+def test_compat_install_rebinds_models_that_import_at_package_import(tmp_path):
+    """the real `basicsr/__init__.py` does `from .models import *`, which imports gsasr_model.py, which binds
+    `from basicsr.utils.gaussian_splatting import generate_2D_gaussian_splatting_step` at import time.  install() must have
+    the leaf registered BEFORE it imports the parent packages, or the model keeps the reference's function.  A tree of
+    that shape (TrainTestGSASR/basicsr/__init__.py, models/__init__.py, models/gsasr_model.py:10), and a package whose
+    import fails for another reason (missing dependency), which must surface instead of being replaced by a stub."""
+    import subprocess
+    import sys
+    b = tmp_path / "basicsr"
+    (b / "models").mkdir(parents=True)
+    (b / "utils").mkdir()
+    (b / "__init__.py").write_text("from .models import *\n")
+    (b / "models" / "__init__.py").write_text("from .gsasr_model import GSASRModel\n__all__ = ['GSASRModel']\n")
+    (b / "models" / "gsasr_model.py").write_text(
+        "from basicsr.utils.gaussian_splatting import generate_2D_gaussian_splatting_step\n"
+        "from basicsr.utils.split_and_joint_image import split_and_joint_image\n"
+        "class GSASRModel:\n    step = staticmethod(generate_2D_gaussian_splatting_step)\n")
+    (b / "utils" / "__init__.py").write_text("")
+    (b / "utils" / "gaussian_splatting.py").write_text("def generate_2D_gaussian_splatting_step(*a, **k):\n    raise RuntimeError('reference host path')\n")
+    (b / "utils" / "split_and_joint_image.py").write_text("def split_and_joint_image(*a, **k):\n    raise RuntimeError('reference tiled driver')\n")
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from gsasr_amd import compat, gaussian_splatting as gsp; compat.install(also_gaussian_splatting=True)\n"
+        "import basicsr.models.gsasr_model as m\n"
+        "assert m.generate_2D_gaussian_splatting_step is gsp.generate_2D_gaussian_splatting_step, m.generate_2D_gaussian_splatting_step\n"
+        "assert m.GSASRModel.step is gsp.generate_2D_gaussian_splatting_step\n"
+        "import basicsr.utils as u; assert u.gaussian_splatting is gsp\n"
+        "print('ok')\n" % (ROOT, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr
+    # a parent package that exists but cannot be imported: the real error, not a silent empty stand-in
+    (b / "utils" / "__init__.py").write_text("import a_dependency_that_is_not_installed\n")
+    code2 = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "from gsasr_amd import compat\n"
+             "try:\n    compat.install()\nexcept ModuleNotFoundError as e:\n    assert e.name == 'a_dependency_that_is_not_installed', e.name\n    print('ok')\n"
+             % (ROOT, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
