@@ -63,9 +63,9 @@ class HipBackend:
 
     # ---- packed [N,8] records (BandExchange) ----
     @staticmethod
-    def forward_packed(records, h, w, dmax, rows, cutoff=0.0):
+    def forward_packed(records, h, w, dmax, rows, cutoff=0.0, flags=0):
         from . import _cabi
-        plan = _cabi.plan_packed(records, h, w, dmax, rows=rows, cutoff=cutoff)
+        plan = _cabi.plan_packed(records, h, w, dmax, rows=rows, cutoff=cutoff, flags=flags)
         slab = torch.empty(rows[1] - rows[0], w, 3, device=records.device, dtype=torch.float32)
         _cabi.forward(plan, slab, overwrite=True)
         return slab, plan
@@ -175,6 +175,92 @@ def splat_band(sigmas, coords, colors, h: int, w: int, dmax: Optional[float] = N
         grad_reduce = "none"
     return _BandSplat.apply(sigmas, coords, colors, int(h), int(w), dmax, tuple(rows), group, grad_reduce,
                             backend or HipBackend)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The same pattern on ONE packed [N,8] buffer (BASELINE config 4 as stated: "Gaussians broadcast once, per-Gaussian
+# grads reduce-scatter"): the broadcast's receive buffer IS what the plan reads (GSASR_FLAG_STRIDE8) and the packed
+# gradient the backward writes IS the collective's buffer -- no cat / slice copies around either collective.
+# ---------------------------------------------------------------------------------------------------
+def broadcast_packed(packed: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """ONE broadcast of the `[N,8]` records {sx,sy,rho,x,y,r,g,b} from `src`, in place (non-src ranks pass a buffer of
+    the right shape)."""
+    if packed.dim() != 2 or packed.shape[1] != 8 or not packed.is_contiguous():
+        raise RuntimeError("packed must be a contiguous [N,8] tensor")
+    dist.broadcast(packed, src=src, group=group)
+    return packed
+
+
+def reduce_packed_grads_(g: torch.Tensor, n: int, mode: str = "reduce_scatter", group=None) -> torch.Tensor:
+    """Sum the ranks' partial gradients held in `g[per*world, 8]` (rows [n:] zero) IN PLACE and return `g[:n]`.
+    "reduce_scatter": `reduce_scatter_tensor` with this rank's chunk of `g` itself as the output (the in-place form
+    RCCL supports: output = input + rank * count), after which the rows of the other ranks' slices are zeroed --
+    32 N / G bytes leave with the reduced values instead of 32 N; "all_reduce": every rank gets everything."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if mode == "none" or world == 1:
+        return g[:n]
+    if mode == "all_reduce":
+        dist.all_reduce(g[:n], op=dist.ReduceOp.SUM, group=group)
+        return g[:n]
+    if mode != "reduce_scatter":
+        raise ValueError(f"unknown grad reduction mode {mode!r}")
+    rank = dist.get_rank(group)
+    per = g.shape[0] // world
+    if per * world != g.shape[0] or per * world < n:
+        raise RuntimeError("g must hold ceil(n / world) * world rows")
+    dist.reduce_scatter_tensor(g[rank * per: (rank + 1) * per], g, op=dist.ReduceOp.SUM, group=group)
+    a, b = gaussian_slice(n, rank, world)
+    if a > 0:
+        g[:a].zero_()
+    if b < n:
+        g[b:n].zero_()
+    return g[:n]
+
+
+class _BandSplatPacked(Function):
+    @staticmethod
+    def forward(ctx, packed, h, w, dmax, rows, group, grad_reduce, backend, cutoff):
+        band = rows[1] - rows[0] < h
+        flags = 0
+        if band and backend is HipBackend:      # (proper bands of a replicated set: the tile-stationary backward, see HipBackend.forward)
+            from . import _cabi
+            flags = _cabi.FLAG_BWD_TILE
+        slab, state = backend.forward_packed(packed, h, w, dmax, rows, cutoff, flags) if flags else \
+            backend.forward_packed(packed, h, w, dmax, rows, cutoff)
+        ctx.save_for_backward(packed)
+        ctx.state, ctx.group, ctx.grad_reduce, ctx.backend = state, group, grad_reduce, backend
+        return slab
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_slab):
+        (packed,) = ctx.saved_tensors
+        n = packed.shape[0]
+        world = dist.get_world_size(ctx.group) if (dist.is_available() and dist.is_initialized()) else 1
+        per = (n + world - 1) // world
+        g = torch.empty(per * world, 8, device=packed.device, dtype=packed.dtype)   # the ONE allocation of this backward
+        if per * world > n:
+            g[n:].zero_()
+        ctx.backend.backward_packed(ctx.state, packed, grad_slab, g[:n])
+        return reduce_packed_grads_(g, n, ctx.grad_reduce, ctx.group), None, None, None, None, None, None, None, None
+
+
+def splat_band_packed(packed: torch.Tensor, h: int, w: int, dmax: Optional[float] = None, group=None,
+                      grad_reduce: str = "all_reduce", rows: Optional[Tuple[int, int]] = None, backend=None,
+                      cutoff: float = 0.0) -> torch.Tensor:
+    """`splat_band` for Gaussians held as ONE `[N,8]` tensor (what `broadcast_packed` filled): the plan reads the
+    records where they are, the backward writes one `[N,8]` gradient and the collective runs on that buffer in place.
+    Same `grad_reduce` modes and the same result as `splat_band(*unpack(packed), ...)`, without its five `[N,8]`-sized
+    copies per step."""
+    if rows is None:
+        if dist.is_available() and dist.is_initialized():
+            rows = row_band(h, dist.get_rank(group), dist.get_world_size(group))
+        else:
+            rows, grad_reduce = (0, h), "none"
+    if not (dist.is_available() and dist.is_initialized()):
+        grad_reduce = "none"
+    return _BandSplatPacked.apply(packed, int(h), int(w), dmax, tuple(rows), group, grad_reduce, backend or HipBackend,
+                                  float(cutoff))
 
 
 def gather_image(slab: torch.Tensor, h: int, group=None) -> torch.Tensor:

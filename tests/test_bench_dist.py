@@ -26,3 +26,9 @@ def test_bench_two_ranks_functional(extra):
     assert d["config"]["rccl"]["ranks"] == 2 and d["config"]["rccl"]["bytes_sent_per_rank_per_step"] > 0
     assert d["scaling"] == ("strong" if "c4" in extra else "weak")
     assert set(("roofline", "kernels", "metric", "unit", "ms_per_step", "dtype", "data")) <= set(d)
+    # every multi-rank line carries BASELINE config 4's own pattern: strong-scaled 8192^2, packed broadcast + reduce-scatter
+    leg = d["c4_strong"]
+    assert "error" not in leg, leg
+    assert leg["scaling"] == "strong" and leg["n_gpus"] == 2 and leg["value"] > 0 and leg["rows_per_rank"] == 4096
+    assert leg["rccl"]["ranks"] == 2 and leg["rccl"]["bytes_sent_per_rank_per_step"] == 64 * 1048576
+    assert "reduce_scatter" in leg["rccl"]["pattern"] and "broadcast" in leg["rccl"]["pattern"]

@@ -95,6 +95,59 @@ def test_row_band_shard_matches_single_process(world, mode):
                 assert np.abs(got[:a]).max(initial=0) == 0 and np.abs(got[b:]).max(initial=0) == 0
 
 
+def _packed_worker(rank, world, port, mode, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sig, xy, col, H, W = synthetic.kernel_inputs(11, 10, 3.0, seed=5)   # 110 Gaussians: padded chunks at world 3
+        n = sig.shape[0]
+        # ONE [N,8] buffer per rank: the broadcast lands in it and the plan reads it where it is
+        packed = shard.pack(sig, xy, col) if rank == 0 else torch.full((n, 8), float("nan"))
+        shard.broadcast_packed(packed, src=0)
+        p = packed.clone().requires_grad_(True)
+        slab = shard.splat_band_packed(p, H, W, dmax=0.4, grad_reduce=mode, backend=OraclePackedBackend)
+        r0, r1 = shard.row_band(H, rank, world)
+        assert slab.shape == (r1 - r0, W, 3)
+        wgt = synthetic.grad_image(H, W, 6)
+        (slab * wgt[r0:r1]).sum().backward()
+        out[rank] = dict(slab=slab.detach().numpy(), rows=(r0, r1), g=p.grad.numpy(), sl=shard.gaussian_slice(n, rank, world))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "all_reduce"), (3, "all_reduce"), (2, "reduce_scatter"), (3, "reduce_scatter")])
+def test_packed_row_band_shard_matches_single_process(world, mode):
+    """the north star's pattern on one packed buffer: broadcast_packed + splat_band_packed, gradients
+    reduced in place on the [N,8] buffer the backward wrote"""
+    from oracle import gs_oracle
+    mgr = mp.Manager()
+    out = mgr.dict()
+    try:
+        mp.spawn(_packed_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
+    except Exception as e:  # gloo builds without reduce_scatter: the NCCL/RCCL path has it; skip here
+        if mode == "reduce_scatter" and "reduce_scatter" in str(e).lower():
+            pytest.skip(f"gloo lacks reduce_scatter_tensor in this build: {e}")
+        raise
+    sig, xy, col, H, W = synthetic.kernel_inputs(11, 10, 3.0, seed=5)   # 110 Gaussians: padded chunks at world 3
+    wgt = synthetic.grad_image(H, W, 6)
+    ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, 0.4)
+    gref = shard.pack(*(torch.from_numpy(a) for a in
+                        gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), 0.4))).numpy()
+    for r in range(world):
+        o = out[r]
+        r0, r1 = o["rows"]
+        np.testing.assert_allclose(o["slab"], ref[r0:r1], rtol=0, atol=1e-5)
+        for cols in (slice(0, 3), slice(3, 5), slice(5, 8)):
+            want, got, scale = gref[:, cols], o["g"][:, cols], np.abs(gref[:, cols]).max()
+            if mode == "all_reduce":
+                assert np.abs(got - want).max() <= 1e-5 * scale
+            else:   # rank r holds the reduced gradients of its Gaussian slice, zeros elsewhere
+                a, b = o["sl"]
+                assert np.abs(got[a:b] - want[a:b]).max() <= 1e-5 * scale
+                assert np.abs(got[:a]).max(initial=0) == 0 and np.abs(got[b:]).max(initial=0) == 0
+
+
 def test_band_and_slice_partitions():
     for h, world in ((1024, 8), (1000, 3), (7, 8), (8192, 8)):
         bands = [shard.row_band(h, r, world) for r in range(world)]
