@@ -120,9 +120,12 @@ typedef struct gsasr_dims {
 #define GSASR_MAX_BATCH 64
 
 /* Default tau is ADAPTIVE: tau = ln(s / GSASR_SPLAT_DEFAULT_EPS), clamped to [16, 104].  Every skipped
- * term is < exp(-tau) times its colour (<= 1 after the host prologue's sigmoid * alpha), and at most s terms
- * can be skipped on one pixel, so the image error is < s * exp(-tau) = 1e-5 absolute per pixel for ANY input
- * -- an order below the 1e-4 parity tolerance and at the level of fp32 summation noise; in practice the
+ * term is < exp(-tau) times its colour, and at most s terms can be skipped on one pixel, so the image error is
+ * < s * exp(-tau) * max|colour| = 1e-5 * max|colour| per pixel for ANY input: a bound RELATIVE to the colour scale.
+ * After the host prologue (sigmoid * alpha) colours are <= 1 and the bound is 1e-5 absolute -- an order below the
+ * 1e-4 parity tolerance and at the level of fp32 summation noise; the raw op accepts any float as a colour, and
+ * there the bound scales with it exactly as the fp32 rounding of the sum itself does
+ * (tests/test_hip_parity.py::test_raw_op_colours_far_above_one).  In practice the
  * skipped mass is ~1e-9 because terms decay further outside the ellipse.  Gradients lose the same tail:
  * relative error ~ tau * exp(-tau) < 1e-8.  (s = 65 536 -> tau = 22.6; s = 2^20 -> tau = 25.4.)
  * A fixed tau can be set per call (dims.cutoff) or per process (gsasr_set_default_cutoff / environment

@@ -263,3 +263,36 @@ def test_large_scale_forward_tall_tiles_against_oracle(dev):
         for rows in ((0, 16), (56, 72), (1784, 1824)):
             ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax, rows=rows)
             assert np.abs(img[rows[0]:rows[1]].cpu().numpy() - ref).max() <= IMG_ATOL * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("dmax", [0.1, 0.5])
+def test_real_density_inference_size_band_against_oracle(dmax, dev):
+    """GSASR's real Gaussian density at inference size (Fea2GS emits 16 Gaussians per LR pixel,
+    utils/fea2gs.py:546-551): 256x256 LR -> x4 = 1024^2, 1 048 576 Gaussians, inference box 0.1 and training box 0.5.
+    A 16-row band of the whole-image forward, and the gradient of that band through both backward kernels, against the
+    oracle with every Gaussian (image sums of ~500 terms: tolerance relative to the band's peak, as at x32)."""
+    from gsasr_amd import _cabi, synthetic
+    from oracle import gs_oracle
+    from test_bwd_tile import per_gaussian_ok
+    sig, xy, col, H, W = synthetic.kernel_inputs(256, 256, 4.0, seed=0, gpp=16)
+    assert (H, W, sig.shape[0]) == (1024, 1024, 1048576)
+    s, c, k = sig.numpy(), xy.numpy(), col.numpy()
+    a, b, d = sig.to(dev), xy.to(dev), col.to(dev)
+    rows = (504, 520)
+    ref = gs_oracle.forward_f64(s, c, k, H, W, dmax, rows=rows)
+    plan = _cabi.plan(a, b, d, H, W, dmax, flags=_cabi.FLAG_FORWARD_ONLY)
+    img = torch.empty(H, W, 3, device=dev)
+    _cabi.forward(plan, img, overwrite=True)
+    atol = IMG_ATOL * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(img[rows[0]:rows[1]].cpu().numpy() - ref).max() <= atol
+    wgt = synthetic.grad_image(rows[1] - rows[0], W, 3)
+    want = gs_oracle.backward_f64(s, c, k, wgt.numpy(), dmax, h=H, rows=rows)
+    for flag in (_cabi.FLAG_BWD_GAUSSIAN, _cabi.FLAG_BWD_TILE):
+        band = _cabi.plan(a, b, d, H, W, dmax, rows=rows, flags=flag)
+        slab = torch.empty(rows[1] - rows[0], W, 3, device=dev)
+        _cabi.forward(band, slab, overwrite=True)
+        assert np.abs(slab.cpu().numpy() - ref).max() <= atol
+        g = [torch.empty_like(t) for t in (a, b, d)]
+        _cabi.backward(band, a, b, d, wgt.to(dev), *g, overwrite=True)
+        for got, w_, name in zip(g, want, ("sigmas", "coords", "colors")):
+            per_gaussian_ok(got.cpu().numpy(), w_, name, rho=s[:, 2])
