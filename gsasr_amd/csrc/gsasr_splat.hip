@@ -529,7 +529,9 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
             float step;
             if (SS.sm) {
                 const float s0 = SS.sm[(size_t)smp * SS.stride], s1 = SS.sm[(size_t)smp * SS.stride + 1];
-                step = SS.def_step / s0;
+                // (`default_step_size / scale_modify[0]` with a tensor on the right is torch's __rtruediv__: reciprocal, then
+                // the product -- two roundings, reproduced here so that the step is the reference's float bit for bit)
+                step = (1.0f / s0) * SS.def_step;
                 if (i == smp * P.nper) {
                     SS.keep[smp] = step;
                     if (!(s0 == s1) && SS.mismatch) { SS.mismatch[0] = 1 + smp; SS.mismatch[1] = (int)__float_as_uint(s0); }

@@ -108,3 +108,141 @@ def test_pooled_workspaces_are_not_shared_between_layouts(dev):
                 ref[(H, W)] = out.clone()
             assert float((out - ref[(H, W)]).abs().max()) <= 1e-5
             assert float((img.permute(2, 0, 1) - ref[(H, W)]).abs().max()) <= 1e-5
+
+
+def _host_prologue_reference(p, H, W, scale_modify, dmax, wgt):
+    """the unfused torch path of this package (activations + kernel frame as torch ops, reference :174-180, :121-123)
+    with the reference's own step expression on a CUDA tensor"""
+    from gsasr_amd import gaussian_splatting as gsp
+    pa = p.detach().clone().requires_grad_(True)
+    a5 = gsp._activate(pa)
+    out = gsp.rendering_cuda_dmax(*a5, (H, W), 1.2 / scale_modify[0], p.device, dmax=dmax)
+    out.backward(wgt)
+    return out.detach(), pa.grad
+
+
+@pytest.mark.parametrize("kernel", ["gaussian", "tile"])
+def test_scale_modify_read_on_the_device_single_and_batched(kernel, dev):
+    """a float32 CUDA `scale_modify` goes to the plan's first kernel as a pointer
+    (gsasr_step_forward_sm): step = default_step_size / scale_modify[0] is formed there (torch's reciprocal-then-multiply,
+    bit for bit) and kept in the workspace for the backward.  Equal (to summation-order noise) to the same fused kernels fed the step as a
+    torch tensor, and within rounding of the unfused torch prologue -- for one image (a row view of a [B,2] tensor,
+    gsasr_model.py:202) and for the batched canvas ([B,2] tensor and list of rows)."""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    old = gsp.BACKWARD_KERNEL
+    gsp.BACKWARD_KERNEL = kernel
+    try:
+        H, W = 96, 80
+        p = synthetic.gs_parameters(24, 20, seed=2).to(dev)
+        wgt = synthetic.grad_image(H, W, 3).permute(2, 0, 1).contiguous().to(dev)
+        sms = torch.tensor([[3.0, 3.0], [4.0, 4.0], [2.7, 2.7]], device=dev)
+        for b in range(3):
+            pa = p.clone().requires_grad_(True)
+            out = gsp.generate_2D_gaussian_splatting_step((H, W), pa, 4.0, sms[b], dmax=0.3, default_step_size=1.2)
+            out.backward(wgt)
+            pt = p.clone().requires_grad_(True)      # the same kernels, the step evaluated by torch
+            ref = gsp._FusedStep.apply(pt, (1.2 / sms[b][0]).reshape(1), H, W, 0.3)
+            ref.backward(wgt)
+            # (not bit-identical run to run: the order of a cell's Gaussians comes from atomics; summation-order noise only)
+            assert float((out - ref).abs().max()) <= 2e-6 and float((pa.grad - pt.grad).abs().max()) <= 2e-6 * float(pt.grad.abs().max())
+            want, gwant = _host_prologue_reference(p, H, W, sms[b], 0.3, wgt)
+            assert float((out - want).abs().max()) <= 1e-5
+            assert float((pa.grad - gwant).abs().max()) <= 1e-4 * float(gwant.abs().max())
+        # batched canvas: the [B,2] tensor itself, and a list of its rows
+        B = 3
+        pb = torch.stack([synthetic.gs_parameters(24, 20, seed=2 + i) for i in range(B)]).to(dev)
+        for sm_arg in (sms, [sms[i] for i in range(B)]):
+            pa = pb.clone().requires_grad_(True)
+            out = gsp.generate_2D_gaussian_splatting_batch([(H, W)] * B, pa, [4.0] * B, sm_arg, dmax=0.3)
+            out.backward(wgt.expand(B, -1, -1, -1).contiguous())
+            for i in range(B):
+                want, gwant = _host_prologue_reference(pb[i], H, W, sms[i], 0.3, wgt)
+                assert float((out[i] - want).abs().max()) <= 1e-5
+                assert float((pa.grad[i] - gwant).abs().max()) <= 1e-4 * float(gwant.abs().max())
+        gsp.deferred_asserts.flush()
+    finally:
+        gsp.BACKWARD_KERNEL = old
+
+
+def test_scale_modify_mismatch_on_the_device_is_reported(dev):
+    """the reference's `assert scale_modify[0] == scale_modify[1]` (:169) for the on-device path: the kernel sets a
+    sticky word, the host reads it every few calls / at flush() and raises with the sample and the value"""
+    from gsasr_amd import _cabi, gaussian_splatting as gsp, synthetic
+    p = synthetic.gs_parameters(8, 8, seed=1).to(dev)
+    gsp.deferred_asserts.flush()
+    assert int(_cabi.mismatch_flag(dev)[0]) == 0
+    pb = torch.stack([p, p, p])
+    sms = torch.tensor([[4.0, 4.0], [4.0, 4.0], [4.0, 3.5]], device=dev)
+    gsp.generate_2D_gaussian_splatting_batch([(32, 32)] * 3, pb, [4.0] * 3, sms, dmax=0.3)
+    with pytest.raises(AssertionError, match=r"scale_modify is not the same \(sample 2 .*4\.0"):
+        gsp.deferred_asserts.flush()
+    gsp.deferred_asserts.flush()                       # the word was re-armed: nothing pending, nothing raised
+    assert int(_cabi.mismatch_flag(dev)[0]) == 0
+    # it is polled without anyone calling flush(): WATCH_EVERY calls later the error surfaces at a call site
+    gsp.generate_2D_gaussian_splatting_step((32, 32), p, 4.0, torch.tensor([2.0, 3.0], device=dev), dmax=0.3)
+    ok = torch.tensor([4.0, 4.0], device=dev)
+    with pytest.raises(AssertionError, match="scale_modify is not the same"):
+        for _ in range(3 * gsp.deferred_asserts.WATCH_EVERY):
+            gsp.generate_2D_gaussian_splatting_step((32, 32), p, 4.0, ok, dmax=0.3)
+            torch.cuda.synchronize()
+    gsp.deferred_asserts.flush()
+
+
+def test_backward_kernel_flag_that_disagrees_with_the_plan(dev):
+    """whether a workspace carries slots is the PLAN's decision.  A backward that asks for the tile-stationary
+    kernel on a plan made without slots -- in a workspace large enough for a plan WITH slots, so that no size check can
+    catch it -- must not read slots and spans nobody wrote: it runs another kernel and returns the right gradient; and
+    the other way round (slots planned, Gaussian-stationary asked)."""
+    import ctypes
+    from gsasr_amd import _cabi, synthetic
+    from oracle import gs_oracle
+    sig, xy, col, H, W = synthetic.kernel_inputs(20, 20, 4.0, seed=4)
+    wgt = synthetic.grad_image(H, W, 5)
+    want = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), 0.3)
+    a, b, c, wg = (t.to(dev) for t in (sig, xy, col, wgt))
+    L = _cabi.lib()
+    big = _cabi.make_dims(sig.shape[0], H, W, 0.3, flags=_cabi.FLAG_BWD_TILE)
+    ws = torch.full((L.gsasr_splat_workspace_bytes(ctypes.byref(big)) + 4096,), 0xFF, dtype=torch.uint8, device=dev)   # garbage, not zeros
+    for plan_flags, bwd_flags in ((_cabi.FLAG_BWD_GAUSSIAN, _cabi.FLAG_BWD_TILE), (0, _cabi.FLAG_BWD_TILE),
+                                  (_cabi.FLAG_BWD_TILE, _cabi.FLAG_BWD_GAUSSIAN), (_cabi.FLAG_BWD_TILE, 0)):
+        ws.fill_(0xFF)
+        dp = _cabi.make_dims(sig.shape[0], H, W, 0.3, flags=plan_flags)
+        _cabi.check(L.gsasr_splat_plan(a.data_ptr(), b.data_ptr(), c.data_ptr(), ctypes.byref(dp), ws.data_ptr(), ws.numel(),
+                                       _cabi._stream(dev)), "plan")
+        db = _cabi.make_dims(sig.shape[0], H, W, 0.3, flags=bwd_flags | _cabi.FLAG_OVERWRITE_GRADS)
+        g = [torch.full_like(t, float("nan")) for t in (a, b, c)]
+        _cabi.check(L.gsasr_splat_backward(a.data_ptr(), b.data_ptr(), c.data_ptr(), wg.data_ptr(), g[0].data_ptr(), g[1].data_ptr(),
+                                           g[2].data_ptr(), ctypes.byref(db), ws.data_ptr(), ws.numel(), _cabi._stream(dev)), "backward")
+        for got, w_ in zip(g, want):
+            got = got.cpu().numpy()
+            assert np.isfinite(got).all() and np.abs(got - w_).max() <= 2e-4 * np.abs(w_).max(), (plan_flags, bwd_flags)
+
+
+def test_grad_rows_is_validated(dev):
+    """ADVICE r2: a planar batched gradient whose planes are shorter than a sample is an error, not an out-of-bounds read;
+    grad_rows on a single image is rejected"""
+    import ctypes
+    from gsasr_amd import _cabi, synthetic
+    B, H, W = 2, 48, 40
+    p = torch.stack([synthetic.gs_parameters(12, 10, seed=i) for i in range(B)]).to(dev)
+    steps = torch.full((B,), 0.3, device=dev)
+    img, plan = _cabi.batch_forward(p, steps, [(H, W), (H - 8, W)], 0.3, _cabi.FLAG_CHW_GRAD | _cabi.FLAG_BWD_TILE)
+    good = torch.rand(B, 3, H, W, device=dev)
+    assert _cabi.batch_backward(plan, p, steps, good, chw=True).shape == p.shape
+    with pytest.raises(RuntimeError, match="rows per plane"):
+        _cabi.batch_backward(plan, p, steps, torch.rand(B, 3, H - 4, W, device=dev), chw=True)
+    d = _cabi.Dims.from_buffer_copy(plan.dims)
+    d._keepalive = plan.dims._keepalive
+    d.flags |= _cabi.FLAG_CHW_GRAD
+    d.grad_rows = H - 4
+    gp = torch.empty_like(p)
+    rc = _cabi.lib().gsasr_step_backward(p.data_ptr(), steps.data_ptr(), good.data_ptr(), gp.data_ptr(), ctypes.byref(d),
+                                         plan.workspace.data_ptr(), plan.workspace.numel(), _cabi._stream(dev))
+    assert rc == -1 and b"grad_rows" in _cabi.lib().gsasr_last_error()
+    one = _cabi.make_dims(10, 32, 32, 0.3)
+    one.grad_rows = 7
+    assert _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(one)) > 0     # (sizes do not depend on it)
+    ws = torch.empty(_cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(one)), dtype=torch.uint8, device=dev)
+    z = torch.zeros(10, 3, device=dev)
+    rc = _cabi.lib().gsasr_splat_plan(z.data_ptr(), z.data_ptr(), z.data_ptr(), ctypes.byref(one), ws.data_ptr(), ws.numel(), _cabi._stream(dev))
+    assert rc == -1
