@@ -806,13 +806,18 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 const float eps = (float)WINDOW_EPS;
                 const int tx0 = b.c0 >> SUBX_SHIFT;
                 // eight bands of (1 << shift) rows starting at band `first` (counted from row0)
+                // (the loop runs as far as the tallest window of the WAVE reaches -- two or three bands at GSASR's x4, not
+                // eight: the plan runs one wave per SIMD, every predicated iteration is on its critical path)
                 auto spans = [&](int shift, int first, int nb, unsigned (&lo4)[2], unsigned (&hi4)[2]) {
-                    for (int t = 0; t < 8; ++t) {
+                    lo4[0] = lo4[1] = 0x01010101u;   // every band empty (lo = 1 > hi = 0) until computed
+                    hi4[0] = hi4[1] = 0u;
+                    for (int t = 0; t < 8 && __ballot(t < nb) != 0ull; ++t) {
+                        if (t >= nb) continue;
                         unsigned lo = 1u, hi = 0u;  // empty
                         // the band's pixel rows Ya..Ya+2^shift-1, relative to the centre
                         const float v0 = (float)((double)(P.row0 + ((first + t) << shift)) - cyp) - eps,
                                     v1 = v0 + (float)((1 << shift) - 1) + 2.f * eps;
-                        if (t < nb && v1 >= -vmax && v0 <= vmax) {
+                        if (v1 >= -vmax && v0 <= vmax) {
                             const float a0 = fmaxf(v0, -vmax), a1 = fminf(v1, vmax);
                             const float vr = fminf(fmaxf(vstar, a0), a1), vl = fminf(fmaxf(-vstar, a0), a1);
                             const float dr_ = disc0 - disc2 * vr * vr;
@@ -826,16 +831,17 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                                 hi = (unsigned)min(255, (xh >> SUBX_SHIFT) - tx0);
                             }
                         }
-                        lo4[t >> 2] |= lo << (8 * (t & 3));
-                        hi4[t >> 2] |= hi << (8 * (t & 3));
+                        const unsigned sh = 8u * (unsigned)(t & 3), keep = ~(0xffu << sh);
+                        if (t < 4) { lo4[0] = (lo4[0] & keep) | (lo << sh); hi4[0] = (hi4[0] & keep) | (hi << sh); }
+                        else { lo4[1] = (lo4[1] & keep) | (lo << sh); hi4[1] = (hi4[1] & keep) | (hi << sh); }
                     }
                 };
-                unsigned lo4[2] = {0u, 0u}, hi4[2] = {0u, 0u};
+                unsigned lo4[2], hi4[2];
                 spans(SUBY_SHIFT, ty0, ty1 - ty0 + 1, lo4, hi4);
                 // the same per band of 8 rows, for the 8x8-px quadrants of the tile-stationary backward
                 const int q0 = (b.r0 - P.row0) >> 3, q1 = (b.r1 - P.row0) >> 3;
                 if (V.qspan && q1 - q0 < 8) {   // (plans with slots only: the others never run the tile-stationary backward)
-                    unsigned l8[2] = {0u, 0u}, h8[2] = {0u, 0u};
+                    unsigned l8[2], h8[2];
                     spans(3, q0, q1 - q0 + 1, l8, h8);
                     qs = make_uint4(l8[0], h8[0], l8[1], h8[1]);
                 }
