@@ -50,7 +50,10 @@ python $R/tools/rocpd_summary.py /tmp/kt3_$TAG/kt_results.db --skip 1 > $OUT/ker
 rocprofv3 --kernel-trace --stats -d /tmp/kt5_$TAG -o kt -- $BENCH --config c5 > /dev/null 2> $OUT/kt5.err
 python $R/tools/rocpd_summary.py /tmp/kt5_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c5.txt
 fi
-# 4. the plain bench line (with exact / dropin / cpu_baseline)
+# 3c. GSASR's real Gaussian density at inference size (16 per LR pixel)
+rocprofv3 --kernel-trace --stats -d /tmp/kt216_$TAG -o kt -- $BENCH --config c2x16 --steps 10 --warmup 3 > /dev/null 2> $OUT/kt216.err
+python $R/tools/rocpd_summary.py /tmp/kt216_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c2x16.txt
+# 4. the plain bench line (with exact / dropin / cpu_baseline / the x12, x8 and 16-per-LR-pixel legs)
 cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/kernel_stats.txt $OUT/pmc_fetch.txt $OUT/pmc_write.txt
 tail -c 3000 $OUT/bench.json
@@ -78,3 +81,9 @@ tail -c 600 $OUT/bench_c5s.json; cat $OUT/sample_time.txt | tail -7
 # 7. multi-rank code path self-test at world size 1 (RCCL init, band exchange with itself)
 python bench.py --no-cpu-baseline --force-dist --steps 10 --warmup 3 > $OUT/bench_force_dist.json 2>> $OUT/bench.err
 tail -c 700 $OUT/bench_force_dist.json
+# 8. host path: the reference's calling convention and PyTorch's own floor under it; gradient error vs conditioning
+python tools/dropin_profile.py > $OUT/dropin_profile.txt 2>&1
+python tools/autograd_floor.py > $OUT/autograd_floor.txt 2>&1
+python tools/rho_conditioning.py > $OUT/rho_conditioning.txt 2>&1
+python bench.py --no-cpu-baseline --config c2x16 > $OUT/bench_c2x16.json 2>> $OUT/bench.err
+cat $OUT/dropin_profile.txt $OUT/autograd_floor.txt | grep -v amdgpu.ids
