@@ -5,6 +5,7 @@
 """
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,7 +47,7 @@ def main():
             busy = grab_any(sq, name, "SQ_BUSY_CYCLES")
             insts = grab_any(sq, name, "SQ_INSTS_VALU")
             d[k].update(valu_busy=round(4.0 * act / (32.0 * busy), 4), valu_insts=int(insts * 32))
-    d["_source"] = d["_source"].replace("r01_", tag + "_")
+    d["_source"] = re.sub(r"r\d\d_", tag + "_", d["_source"])
     d["_valu_method"] = ("valu_busy = 4 * SQ_ACTIVE_INST_VALU / (32 * SQ_BUSY_CYCLES), both per shader-engine averages from "
                          f"profiles/{tag}_pmc_sq.txt (quad-cycle units; 32 SIMDs per SE); valu_insts = wave-level VALU "
                          "instructions per launch (SQ_INSTS_VALU x 32 SE instances)")
