@@ -226,7 +226,7 @@ def main():
                        "H": step.H, "W": step.W, "gaussians": step.n, "dmax": step.dmax if step.dmax is not None else -1,
                        "cutoff_tau": round(step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 3),
                        "cutoff_note": "terms with exponent < -tau are skipped; default tau = ln(N/1e-5) bounds the image error by "
-                                      "1e-5 per pixel for any input (parity tolerance 1e-4, all parity tests run at this default); "
+                                      "1e-5 x max|colour| per pixel for any input (colours are <= 1 after the host prologue; parity tolerance 1e-4, all parity tests run at this default); "
                                       "--cutoff 104 sums the reference's exact set of non-zero fp32 terms, --cutoff -1 every in-box term",
                        "launch": launch,
                        "parallelism": (f"data-parallel x{world} (one batch per rank, no exchange)" if step.batched and world > 1
