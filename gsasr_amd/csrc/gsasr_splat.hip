@@ -1884,7 +1884,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
     __shared__ unsigned s_list[BT_LIST];            // survivor: index in cell order | needs the dmax test << 31
     __shared__ unsigned char s_slot[BT_LIST];       // its slot in part[] for this tile, or BT_WIDE
     __shared__ unsigned short s_items[BT_LIST * 8]; // item: survivor (9 bits) | quadrant << 9 | last of its survivor << 12
-    __shared__ unsigned s_cnt[2];                   // survivors, items of the round
+    __shared__ unsigned s_cnt[3];                   // survivors, items of the round; head of the item queue (level 2)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned tt = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1923,7 +1923,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
         }
         if (tid < BT_W) s_px[tid] = V.px[g.pxo + min(bx0 + tid, P.w - 1)];
         else if (tid < BT_W + BT_H) s_py[tid - BT_W] = V.py[min(by0 + tid - BT_W, P.h - 1)];
-        if (tid < 2) s_cnt[tid] = 0u;
+        if (tid < 3) s_cnt[tid] = 0u;
     }
 
     // ---- segment table of the tile (every wave builds the same one; cf. fwd_block) ------------------------
@@ -2041,24 +2041,25 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
         const unsigned nsurv = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[0]);
         const unsigned nitems = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[1]);
         (void)nsurv;
-        // ---- level 2: this wave's run of items, cut where a Gaussian's items end ---------------------------
-        // run boundaries: nitems * w / 4 moved up to the next item that starts a Gaussian
-        unsigned run[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            unsigned b = nitems * (unsigned)(wv + e) / (unsigned)BT_WAVES;
-            if (b > 0u && b < nitems) {
-                const unsigned i = b - 1u + (unsigned)lane;
-                const unsigned long long tails = __ballot(i < nitems && (s_items[i < nitems ? i : 0u] & 0x1000u));
-                b = tails ? b + (unsigned)__builtin_ctzll(tails) : nitems;
+        // ---- level 2: chunks of <= 64 items, cut where a Gaussian's items end, CLAIMED by the waves from one queue ----
+        // (a static split of the item list between the waves leaves every wave a ragged last chunk: with ~150 items per wave
+        // that is 3-3.5 chunk iterations for 2.4 chunks of work, the largest single loss of this kernel.  A chunk's end
+        // depends on its items, so a wave reads the queue head, finds its cut and claims [head, cut] with a compare-and-swap.)
+        for (;;) {
+            unsigned p0, it = 0u;
+            int tlast = 0;
+            for (;;) {
+                p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned *)&s_cnt[2]);
+                if (p0 >= nitems) break;
+                const unsigned idx = p0 + (unsigned)lane;
+                it = idx < nitems ? s_items[idx] : 0u;
+                const unsigned long long tails = __ballot(idx < nitems && (it & 0x1000u));
+                tlast = 63 - __builtin_clzll(tails);                  // (the list ends on a marked item: tails != 0)
+                unsigned got = 0u;
+                if (lane == 0) got = atomicCAS(&s_cnt[2], p0, p0 + (unsigned)tlast + 1u);
+                if ((unsigned)__builtin_amdgcn_readfirstlane((int)got) == p0) break;
             }
-            run[e] = b;
-        }
-        for (unsigned p0 = run[0]; p0 < run[1];) {
-            const unsigned idx = p0 + (unsigned)lane;
-            const unsigned it = idx < run[1] ? s_items[idx] : 0u;
-            const unsigned long long tails = __ballot(idx < run[1] && (it & 0x1000u));
-            const int tlast = 63 - __builtin_clzll(tails);            // (a run ends on a marked item: tails != 0)
+            if (p0 >= nitems) break;
             const bool valid = lane <= tlast;
             const unsigned lidx = it & 0x1ffu, q = (it >> 9) & 7u;
             float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -2100,10 +2101,9 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
                     for (int k = 0; k < 8; ++k) atomicAdd(V.sums + 8 * (size_t)j + k, a[k]);
                 }
             }
-            p0 += (unsigned)tlast + 1u;
         }
         __syncthreads();
-        if (tid < 2) s_cnt[tid] = 0u;
+        if (tid < 3) s_cnt[tid] = 0u;
         __syncthreads();
     }
 }
