@@ -2004,8 +2004,10 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5
                     const unsigned t = (unsigned)(fine ? b8 - q0 + qy : (b8 >> 1) - (q0 >> 1)) & 7u, sh = (t & 3u) * 8u;
                     const int lo = (int)(((t < 4u ? qs.x : qs.z) >> sh) & 0xffu), hi = (int)(((t < 4u ? qs.y : qs.w) >> sh) & 0xffu);
                     if (qy >= qy0 && qy <= qy1) {
+                        // (hi = 255 is "as far as the window goes": the default of a window k_bin computed no spans for --
+                        // one wider than 255 columns of 8 px among them, whose far tiles would otherwise lose their quadrants)
                         xl[qy] = max(qx0, cu + lo);
-                        xh[qy] = min(qx1, cu + hi);
+                        xh[qy] = hi == 255 ? qx1 : min(qx1, cu + hi);
                     }
                 }
             }

@@ -290,6 +290,32 @@ def test_fuzz_extreme_parameters_tile_backward(seed, dev):
                                sig[np.argwhere(bad)[0][0]].tolist())
 
 
+@pytest.mark.parametrize("shape", [(24, 2600), (2600, 24), (300, 2500)], ids=["wide", "tall", "both"])
+@pytest.mark.parametrize("kernel", ["tile", "atomic", "gaussian"])
+def test_windows_wider_than_2048_px(kernel, shape, dev):
+    """Gaussians whose window spans more than 255 columns of 8 px (or as many rows): k_bin computes no ellipse spans for
+    them, and the tile kernel's "every column" default (hi = 255) must not end at column 255 -- found by
+    tools/fuzz_sample.py case 82 (a 1108 x 2394 image with sigma_x ~ 0.3: the far tiles of such windows lost their
+    quadrants, 10-40% gradient error; the small images of the other fuzzers never have a window that wide)."""
+    from oracle import gs_oracle
+    h, w = shape
+    rng = np.random.default_rng(82)
+    s = 40
+    sig = np.stack([10 ** rng.uniform(-2.2, 0.3, s), 10 ** rng.uniform(-2.2, 0.3, s), rng.uniform(-0.9, 0.9, s)], 1).astype(np.float32)
+    sig[:10, 0] = rng.uniform(0.25, 0.6, 10)      # ~ 0.3 * w/2 * 6 px: wider than 2048 px on the wide images
+    sig[10:20, 1] = rng.uniform(0.25, 0.6, 10)    # (kernel frame: sigmas[:,1] scales x... both axes get their share)
+    xy = rng.uniform(-1.1, 1.1, (s, 2)).astype(np.float32)
+    col = rng.uniform(0, 1, (s, 3)).astype(np.float32)
+    wgt = np.zeros((h, w, 3), np.float32)          # sparse upstream gradient: a lost tile shows, a dense one averages it away
+    idx = rng.integers(0, h * w, 400)
+    wgt.reshape(-1, 3)[idx] = rng.normal(0, 1, (400, 3)).astype(np.float32)
+    for dmax in (None, 0.9):
+        got = _backward(sig, xy, col, wgt, h, w, dmax, dev, _flags()[kernel])
+        want = gs_oracle.backward_f64(sig, xy, col, wgt, dmax)
+        for g, r, name in zip(got, want, ("sigmas", "coords", "colors")):
+            per_gaussian_ok(g, r, name, rho=sig[:, 2])
+
+
 def test_packed_records_tile_backward(dev):
     """GSASR_FLAG_STRIDE8 (the wire format of the multi-GPU exchange) through the tile-stationary backward: inputs and
     gradients as columns of one [N,8] array, row band, dead (NaN) padding records"""
