@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Randomised cross-check of the kernels against each other and against the oracle at sizes the small fuzzers never
+reach (GPU, development aid):   python tools/fuzz_cross.py [cases] [seed]
+
+Per case: a random image (up to ~5000 px a side, sometimes very thin), a random row band, Gaussians from hairlines to
+several image widths, dmax or none, default / exact / no cutoff.  Checked:
+  forward    band render  ==  oracle (f64) on a few rows of the band
+  backward   Gaussian-stationary, tile-stationary (slots), tile-stationary (atomics): each against the oracle's
+             gradient of the same band (upstream gradient dense or sparse)
+The sampled-pixel fuzzer found the one bug of round 3 this way (a window wider than 2048 px in the tile backward)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gsasr_amd import _cabi  # noqa: E402
+from oracle import gs_oracle  # noqa: E402
+
+dev = torch.device("cuda:0")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+FLAGS = {"gaussian": _cabi.FLAG_BWD_GAUSSIAN, "tile": _cabi.FLAG_BWD_TILE, "atomic": _cabi.FLAG_BWD_TILE | _cabi.FLAG_BWD_ATOMIC}
+worst = {"img": 0.0, "gaussian": 0.0, "tile": 0.0, "atomic": 0.0}
+t0 = time.time()
+for case in range(cases):
+    shape = rng.integers(0, 4)
+    big = [int(rng.integers(600, 5000)), int(rng.integers(600, 5000))]
+    if shape == 0:
+        H, W = int(rng.integers(2, 64)), big[1]
+    elif shape == 1:
+        H, W = big[0], int(rng.integers(2, 64))
+    elif shape == 2:
+        H, W = int(rng.integers(100, 1200)), int(rng.integers(100, 1200))
+    else:
+        H, W = big
+    n = int(rng.integers(1, 1500))
+    nb = int(min(H, rng.integers(1, 40)))             # rows of the band (the oracle's cost)
+    r0 = int(rng.integers(0, H - nb + 1))
+    rows = (r0, r0 + nb)
+    lo = float(rng.choice([-4.0, -3.0, -2.0]))
+    sig = np.stack([10 ** rng.uniform(lo, 0.5, n), 10 ** rng.uniform(lo, 0.5, n), np.clip(rng.normal(0, 0.6, n), -0.999, 0.999)], 1).astype(np.float32)
+    xy = rng.uniform(-1.3, 1.3, (n, 2)).astype(np.float32)
+    # most centres near the band, so that the band sees work
+    yc = (2.0 * (r0 + nb / 2) / max(H - 1, 1) - 1.0)
+    near = rng.random(n) < 0.7
+    xy[near, 1] = np.clip(yc + rng.normal(0, 3.0 * nb / H + 0.02, int(near.sum())), -1.3, 1.3).astype(np.float32)
+    col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    dmax = [None, float(10 ** rng.uniform(-2.5, 0.5))][int(rng.integers(0, 2))]
+    cutoff = [0.0, 104.0, -1.0][int(rng.integers(0, 3))]
+    wgt = rng.normal(0, 1, (nb, W, 3)).astype(np.float32)
+    sparse = rng.random() < 0.5
+    if sparse and cutoff != 0.0:                       # sparse upstream gradient: only where no term is culled -- under the
+        wgt *= (rng.random((nb, W, 1)) < 0.01)         # default cutoff a gradient made of tail terms alone is legitimately dropped
+    what = (case, H, W, rows, n, dmax, cutoff)
+    a, b, c = (torch.from_numpy(x).to(dev) for x in (sig, xy, col))
+    gw = torch.from_numpy(wgt).to(dev)
+    ref_img = gs_oracle.forward_f64(sig, xy, col, H, W, dmax, rows=rows)
+    want = gs_oracle.backward_f64(sig, xy, col, wgt, dmax, h=H, rows=rows)
+    scale = max(1.0, float(np.abs(ref_img).max()))
+    if cutoff == 0.0 and float(np.abs(ref_img).max()) < 1e-3:
+        continue                                       # nothing of these Gaussians is visible in the band: tails only
+    for name, flag in FLAGS.items():
+        plan = _cabi.plan(a, b, c, H, W, dmax, rows=rows, cutoff=cutoff, flags=flag)
+        if name == "gaussian":
+            img = torch.empty(nb, W, 3, device=dev)
+            _cabi.forward(plan, img, overwrite=True)
+            ei = float(np.abs(img.cpu().numpy() - ref_img).max()) / scale
+            worst["img"] = max(worst["img"], ei)
+            assert np.isfinite(ei) and ei <= 1e-4, (what, "forward", ei)
+        g = [torch.full_like(t, float("nan")) for t in (a, b, c)]
+        _cabi.backward(plan, a, b, c, gw, *g, overwrite=True)
+        for got, w_, tn in zip(g, want, ("sigmas", "coords", "colors")):
+            got = got.cpu().numpy()
+            assert np.isfinite(got).all(), (what, name, tn, "non-finite")
+            e = float(np.abs(got - w_).max()) / max(1e-30, float(np.abs(w_).max()))
+            worst[name] = max(worst[name], e)
+            assert e <= 2e-4, (what, name, tn, e)
+    if case % 10 == 9:
+        print(f"{case + 1} cases, {time.time() - t0:.0f} s, worst {worst}", flush=True)
+print(f"{cases} cases ok: worst relative errors {worst}")
