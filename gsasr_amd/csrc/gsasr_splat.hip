@@ -14,8 +14,8 @@
 //            k_scan      exclusive scan of the cell histogram + max-extent reduction (one workgroup;
 //                        k_scan_local + k_scan_fix for grids above 8192 cells).
 //            k_bin       counting-sort placement (cell start + rank) fused with packing: 32-byte records
-//                        {x, y, A, B, C, r, g, b} (A,B,C = exponent coefficients with log2(e) folded,
-//                        computed in double), backward-epilogue constants, 16-byte windows with the
+//                        {x, y, IX, NR, IY, r, g, b} (the coefficients of the completed-square exponent
+//                        -(IX dx)^2 - (IY dy + NR IX dx)^2 in log2 units, computed in double), backward-epilogue constants, 16-byte windows with the
 //                        per-tile-band column spans of the ellipse {exponent >= -tau}, and the first 8 bytes of the
 //                        windows once more as a dense array for the coarse tests.
 //   forward  k_render_fwd2 PIXEL-stationary: one wave64 = one 8x16 pixel sub-tile (2 px per lane, packed
@@ -761,13 +761,21 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         const double dr = rho, dsx = sx, dsy = sy;
         const double w1 = -0.5 / (1.0 - dr * dr);
         const double w2 = 1.0 / (dsx * dsx), w3 = 1.0 / (dsx * dsy), w4 = 1.0 / (dsy * dsy);
-        const float A = (float)(w1 * LOG2E * w2);
-        const float B = (float)(-2.0 * dr * w1 * LOG2E * w3);
-        const float C = (float)(w1 * LOG2E * w4);
-        // record layout {x, y, A, B | C, r, g, b}: after the two 16-byte LDS reads of the forward every value it
-        // broadcasts into a packed-fp32 operand (y, C, r, g, b) is the low or high half of an aligned register pair
-        recA = make_float4(x, y, A, B);
-        recB = make_float4(C, colors[i3 + 0], colors[i3 + 1], colors[i3 + 2]);
+        // The forward evaluates the completed square (like the backward, bwd_trip): with u0 = dx/sx, v0 = dy/sy,
+        //   dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2 = (1-rho^2) u0^2 + (v0 - rho u0)^2,
+        // so log2(e) * exponent = -U^2 - Bq^2,  U = sqrt(h) dx/sx,  Bq = sqrt(h c) dy/sy - rho sqrt(c) U,  h = log2(e)/2,
+        // c = 1/(1-rho^2).  Same seven instructions per record and lane as the monomial form A dx^2 + B dx dy + C dy^2, but
+        // nothing cancels as |rho| -> 1: there the monomial form (the reference's own, gs.cu:33-56) subtracts terms of size
+        // u0^2 c from each other in fp32 -- at rho = 0.999999 an image value was off by 0.3% of itself (tools/fuzz_step.py).
+        const double cinv_d = -2.0 * w1, hl = 0.5 * LOG2E;
+        const float IX = (float)(sqrt(hl) / dsx);
+        const float IY = (float)(sqrt(hl * cinv_d) / dsy);
+        const float NR = (float)(-dr * sqrt(cinv_d));
+        (void)w2; (void)w3; (void)w4;
+        // record layout {x, y, IX, NR | IY, r, g, b}: after the two 16-byte LDS reads of the forward every value it
+        // broadcasts into a packed-fp32 operand (y, IY, r, g, b) is the low or high half of an aligned register pair
+        recA = make_float4(x, y, IX, NR);
+        recB = make_float4(IY, colors[i3 + 0], colors[i3 + 1], colors[i3 + 2]);
         // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
         // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
         finA = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
@@ -950,13 +958,13 @@ template <bool TEST>
 __device__ __forceinline__ void fwd_eval_one(const float4 a, const float4 b, float px, v2f py, float dmax, v2f &ar,
                                              v2f &ag, v2f &ab)
 {
-    // a = {x, y, A, B}, b = {C, r, g, b}
+    // a = {x, y, IX, NR}, b = {IY, r, g, b}:  exponent (log2) = -U^2 - Bq^2,  U = IX dx,  Bq = IY dy + NR U   (k_bin)
     const float dx = px - a.x;
     const v2f dy = py - a.y;
-    const float adx = a.z * dx, bdx = a.w * dx;
-    const float adx2 = adx * dx;
-    const v2f t = b.x * dy + bdx;
-    const v2f pw = dy * t + adx2;
+    const float u = a.z * dx;
+    const float k0 = -u * u, ru = a.w * u;
+    const v2f bq = b.x * dy + ru;
+    const v2f pw = k0 - bq * bq;
     v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
     if (TEST) {
         const bool inx = fabsf(dx) <= dmax;
@@ -1622,7 +1630,7 @@ typedef unsigned u8v __attribute__((ext_vector_type(8)));
 // wave's life.  The plan was written by an earlier kernel, so the scalar cache is coherent for it.
 struct BwdRec {
     u8v bb;    // both bbox words: {c0|test|c1, r0|r1, spans.. | spans.., padded rows r0|r1 of the sweep, -}
-    u8v rec;   // {x, y, A, B | C, r, g, b}
+    u8v rec;   // {x, y, IX, NR | IY, r, g, b}
     u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, px-table offset, sample, index}
 };
 
@@ -2314,9 +2322,9 @@ __device__ __forceinline__ void sample_eval(const float4 *s_pt, int npb, const f
         if (2 * k >= npb) continue;   // (uniform; an odd last point pairs with a stale entry that is never written out)
         const float4 p0 = s_pt[2 * k], p1 = s_pt[2 * k + 1];
         const v2f dx = (v2f){p0.x, p1.x} - a.x, dy = (v2f){p0.y, p1.y} - a.y;
-        const v2f adx = a.z * dx, bdx = a.w * dx;
-        const v2f t = b.x * dy + bdx;
-        const v2f pw = dy * t + adx * dx;
+        const v2f u = a.z * dx;
+        const v2f bq = b.x * dy + a.w * u;
+        const v2f pw = -(u * u) - bq * bq;
         v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
         if (TEST) {   // (dmax = +inf for the lanes whose Gaussian needs no test)
             v.x = fmaxf(fabsf(dx.x), fabsf(dy.x)) <= dmax ? v.x : 0.f;
@@ -2450,7 +2458,7 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
             // window means), so adding them is as exact as skipping them; only the dmax box must be honoured.
             // (the next survivor's record is in flight while the current one is evaluated)
             unsigned q = (unsigned)wv * 64u;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;   // {x, y, A, B}, {C, r, g, b}; dead lanes add 0 * v
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;   // {x, y, IX, NR}, {IY, r, g, b}; dead lanes add 0 * v
             bool test = false;
             if (q + (unsigned)lane < n) {
                 const unsigned e = s_list[q + lane], j = e & 0x7fffffffu;

@@ -910,6 +910,36 @@ def test_saturated_rho_per_gaussian_gradients(kernel, dev):
         assert not bad.any(), (name, int(np.argwhere(bad)[0][0]), float(np.abs(got - ref)[bad].max()))
 
 
+@pytest.mark.parametrize("shape", [(96, 96), (46, 2845)], ids=["square", "wide"])
+def test_saturated_rho_forward_image(shape, dev):
+    """|rho| up to the prologue's 0.999999 in the FORWARD: the image stays within 1e-4 of the f64 truth.  The kernel
+    evaluates the completed square -U^2 - Bq^2 (k_bin); the monomial form A dx^2 + B dx dy + C dy^2 -- the reference's
+    own, utils/gs_cuda_dmax/gs.cu:33-56 -- cancels terms of size u^2/(1-rho^2) in fp32 and was off by up to 2.4e-3
+    here (found by tools/fuzz_step.py on a 46 x 2845 image).  Also held: the reference's fp32 arithmetic, restated by
+    the oracle, is itself further from the truth than this kernel on these inputs."""
+    from gsasr_amd import _cabi
+    from oracle import gs_oracle
+    H, W = shape
+    rng = np.random.default_rng(12)
+    n = 600
+    # elongated, strongly correlated Gaussians a few pixels wide (kernel frame: sigma in units of the half image)
+    sig = np.stack([rng.uniform(1.0, 8.0, n) * 2 / (W - 1), rng.uniform(1.0, 8.0, n) * 2 / (H - 1),
+                    np.sign(rng.standard_normal(n)) * np.sqrt(1.0 - 10.0 ** rng.uniform(-6, -2, n))], 1).astype(np.float32)
+    sig[:, 2] = np.clip(sig[:, 2], -0.999999, 0.999999)
+    xy = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    for dmax in (None, 0.5):
+        a, b, c = (torch.from_numpy(t).to(dev) for t in (sig, xy, col))
+        plan = _cabi.plan(a, b, c, H, W, dmax, flags=_cabi.FLAG_FORWARD_ONLY)
+        img = torch.empty(H, W, 3, device=dev)
+        _cabi.forward(plan, img, overwrite=True)
+        ref = gs_oracle.forward_f64(sig, xy, col, H, W, dmax)
+        err = float(np.abs(img.cpu().numpy() - ref).max())
+        assert err <= IMG_ATOL * max(1.0, float(np.abs(ref).max())), err
+        ref32 = gs_oracle.forward_f32(sig, xy, col, H, W, dmax, use_fma=True)
+        assert err <= float(np.abs(ref32 - ref).max()) + 1e-6
+
+
 @pytest.mark.parametrize("dmax", [None, 0.3], ids=["unbounded", "dmax0.3"])
 def test_raw_op_colours_far_above_one(dmax, dev):
     """The raw op takes any float as a colour (the reference's own __main__ feeds randn, utils/gs_cuda_dmax/gswrapper.py:
