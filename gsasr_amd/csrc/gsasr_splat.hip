@@ -3408,7 +3408,7 @@ int gsasr_band_select(const float *packed, const gsasr_dims *dims, int rows_abov
 int gsasr_band_merge(float *g_packed, int s, const float *g_up, const float *g_down, const int *up_index,
                      const int *down_index, const int *counts, int cap, void *stream)
 {
-    if (s < 0 || cap < 0 || !counts || (cap > 0 && (!g_packed || !g_up || !g_down || !up_index || !down_index)))
+    if (s < 0 || cap < 0 || !counts || (cap > 0 && ((s > 0 && !g_packed) || !g_up || !g_down || !up_index || !down_index)))   // (a rank may own no Gaussian)
         return fail(GSASR_ERR_ARG, "gsasr_band_merge: null pointer or negative size");
     if (cap == 0 || s == 0) return GSASR_OK;
     hipLaunchKernelGGL(k_band_merge, dim3((2 * cap * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, s, cap,

@@ -12,13 +12,14 @@ from gsasr_amd import gaussian_splatting as gsp  # noqa: E402
 
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+BIG = int(sys.argv[2]) if len(sys.argv) > 2 else 300      # largest sample side of the "big" cases
 rng = np.random.default_rng(7)
 worst_img = worst_g = 0.0
 for case in range(cases):
     B = int(rng.integers(2, 12))
     n = int(rng.integers(1, 600))
     big = rng.random() < 0.3
-    sizes = [(int(rng.integers(2, 300 if big else 90)), int(rng.integers(2, 300 if big else 90))) for _ in range(B)]
+    sizes = [(int(rng.integers(2, BIG if big else 90)), int(rng.integers(2, BIG if big else 90))) for _ in range(B)]
     g = torch.Generator().manual_seed(case)
     p = (torch.randn(B, n, 9, generator=g) * float(rng.choice([0.5, 1.5, 3.0]))).to(dev)
     p[:, :, 7:9] = torch.rand(B, n, 2, generator=g).to(dev) * 1.4 - 0.2
