@@ -27,7 +27,7 @@ FLAGS = {"gaussian": _cabi.FLAG_BWD_GAUSSIAN, "tile": _cabi.FLAG_BWD_TILE, "atom
 worst = {"img": 0.0, "gaussian": 0.0, "tile": 0.0, "atomic": 0.0}
 t0 = time.time()
 for case in range(cases):
-    shape = rng.integers(0, 4)
+    shape = rng.integers(0, 5)
     big = [int(rng.integers(600, 5000)), int(rng.integers(600, 5000))]
     if shape == 0:
         H, W = int(rng.integers(2, 64)), big[1]
@@ -35,8 +35,12 @@ for case in range(cases):
         H, W = big[0], int(rng.integers(2, 64))
     elif shape == 2:
         H, W = int(rng.integers(100, 1200)), int(rng.integers(100, 1200))
-    else:
+    elif shape == 3:
         H, W = big
+    else:                                              # up to the largest side the ABI takes (32767), the other side thin
+        H, W = int(rng.integers(20000, 32768)), int(rng.integers(2, 40))
+        if rng.random() < 0.5:
+            H, W = W, H
     n = int(rng.integers(1, 1500))
     nb = int(min(H, rng.integers(1, 40)))             # rows of the band (the oracle's cost)
     r0 = int(rng.integers(0, H - nb + 1))
