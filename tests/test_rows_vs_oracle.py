@@ -309,3 +309,15 @@ def test_cross_fuzz_large_and_thin_images(dev):
                        timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "60 cases ok" in r.stdout
+
+
+def test_sixteen_million_gaussians_properties(dev):
+    """tools/big_n_check.py at 1024^2 LR x 16 Gaussians per LR pixel x4 (16 777 216 Gaussians on 4096^2): per-Gaussian
+    gradients independent of the other Gaussians (both backward kernels), forward additive over a split"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "big_n_check.py"), "1024", "16", "4"], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "forward additivity over two halves" in r.stdout
