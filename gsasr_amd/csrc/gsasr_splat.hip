@@ -469,16 +469,22 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // frame): q = raw decoder output [sigma_x, sigma_y, rho, alpha, r, g, b, mu_x, mu_y] -> o = {sx, sy, rho | x, y | r, g, b}
 __device__ __forceinline__ void prologue_one(const float *__restrict__ q, float step, int h, int w, float (&o)[8])
 {
+#pragma clang fp contract(off)   // torch rounds after every operation: no fused multiply-adds in here
     const float sx = 0.99999f * sigmoidf_(q[0]) + 1e-6f;  // the network's sigma_x is the ROW std
     const float sy = 0.99999f * sigmoidf_(q[1]) + 1e-6f;
     const float alpha = sigmoidf_(q[3]);
     const float W = (float)w, H = (float)h;
-    o[0] = sy / step * 2.f / (W - 1.f);     // kernel's first sigma pairs with WIDTH (:121)
-    o[1] = sx / step * 2.f / (H - 1.f);
+    // Rounded exactly as torch rounds the reference's expressions on the GPU: a tensor divided by a Python number is
+    // multiplied by the number's fp32 reciprocal (BinaryDivTrueKernel), a tensor divided by the 0-dim step tensor is a true
+    // division.  An ulp of a centre is 2e-4 px on a 3000-px image, which a sub-pixel Gaussian (sigma ~ 0.07 px: randn x 1.5
+    // parameters at x8) turns into 1e-3 of its value -- the fused and the unfused host paths must not differ by that.
+    const float iw1 = 1.f / (W - 1.f), ih1 = 1.f / (H - 1.f);
+    o[0] = sy / step * 2.f * iw1;     // kernel's first sigma pairs with WIDTH (:121)
+    o[1] = sx / step * 2.f * ih1;
     o[2] = 0.999999f * tanhf(q[2]);
     const float c0 = q[7] * 2.f - 1.f, c1 = q[8] * 2.f - 1.f;
-    o[3] = (c0 + 1.f - 1.f / W) * W / (W - 1.f) - 1.f;   // align_corners=False -> True (:122-123)
-    o[4] = (c1 + 1.f - 1.f / H) * H / (H - 1.f) - 1.f;
+    o[3] = (c0 + 1.f - (float)(1.0 / (double)w)) * W * iw1 - 1.f;   // align_corners=False -> True (:122-123)
+    o[4] = (c1 + 1.f - (float)(1.0 / (double)h)) * H * ih1 - 1.f;
     o[5] = sigmoidf_(q[4]) * alpha;
     o[6] = sigmoidf_(q[5]) * alpha;
     o[7] = sigmoidf_(q[6]) * alpha;

@@ -78,6 +78,49 @@ class _Splat(torch.autograd.Function):
         return (*g, None, None, None)
 
 
+class _SplatInto(torch.autograd.Function):
+    """One chunk of a chunked render: `img += splat(chunk)` into the image this module owns, with the support cutoff of
+    the WHOLE set (`cutoff`): the adaptive default is tau = ln(N/1e-5), and chunks planned on their own would each cull
+    with their own smaller tau -- the skipped mass would grow with the number of chunks (tools/fuzz_host.py: 1e-4 of an
+    image rendered in 1 700 chunks) instead of staying below 1e-5.  Unlike a chain of the reference-shaped
+    `GSCUDA.apply` calls (whose backward returns None for `rendered_img`, so only the LAST chunk would see a gradient --
+    the reference's chain has the same gap, utils/gaussian_splatting.py:146-151), the image's gradient is passed on: every
+    chunk is differentiated."""
+
+    @staticmethod
+    @fp32_boundary_fwd
+    def forward(ctx, sigmas, coords, colors, img, dmax, cutoff):
+        from . import _cabi
+        sigmas, coords, colors = sigmas.contiguous(), coords.contiguous(), colors.contiguous()
+        plan = _cabi.plan(sigmas, coords, colors, img.shape[0], img.shape[1], dmax, cutoff=cutoff)
+        _cabi.forward(plan, img, overwrite=False)
+        ctx.mark_dirty(img)
+        ctx.save_for_backward(sigmas, coords, colors)
+        ctx.plan = plan
+        return img
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    @fp32_boundary_bwd
+    def backward(ctx, grad_output):
+        from . import _cabi
+        sigmas, coords, colors = ctx.saved_tensors
+        g = (torch.empty_like(sigmas), torch.empty_like(coords), torch.empty_like(colors))
+        _cabi.backward(ctx.plan, sigmas, coords, colors, grad_output.contiguous(), *g, overwrite=True)
+        return (*g, grad_output, None, None)
+
+
+def _render_chunked(sigmas, xy, col, H, W, dmax, device, buffer_size):
+    from . import _cabi
+    final_image = torch.zeros(H, W, 3, device=device, dtype=torch.float32)
+    tau = _cabi.resolve_cutoff(0.0, max(1, sigmas.shape[0]))
+    for a, b in _chunks(sigmas.shape[0], buffer_size):
+        if sigmas[a:b].shape[0] == 0:
+            continue
+        final_image = _SplatInto.apply(sigmas[a:b], xy[a:b], col[a:b], final_image, dmax, tau)   # kernels accumulate (+=)
+    return final_image.permute(2, 0, 1).contiguous()
+
+
 # Which backward kernel the fused entry points plan for: "gaussian" (one wave per Gaussian; needs the upstream gradient
 # permuted to [H,W,3]), "tile" (one workgroup per 32x16-px tile; reads the planar gradient in place; deterministic), or
 # "auto" (DESIGN.md 3c: the measured choice per shape).
@@ -265,26 +308,14 @@ def _chunks(n, buffer_size):
 
 def rendering_cuda_buffer(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device,
                           buffer_size=1000000):
-    from .gs_cuda.gswrapper import GSCUDA
     sigmas, xy, col, H, W = _to_kernel_frame(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size)
-    final_image = torch.zeros(H, W, 3, device=device, dtype=torch.float32)
-    for a, b in _chunks(len(sigma_x), buffer_size):
-        if sigmas[a:b].shape[0] == 0:
-            continue
-        final_image = GSCUDA.apply(sigmas[a:b], xy[a:b], col[a:b], final_image)  # kernels accumulate (+=)
-    return final_image.permute(2, 0, 1).contiguous()
+    return _render_chunked(sigmas, xy, col, H, W, None, device, buffer_size)
 
 
 def rendering_cuda_dmax_buffer(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device,
                                dmax=1, buffer_size=1000000):
-    from .gs_cuda_dmax.gswrapper import GSCUDA
     sigmas, xy, col, H, W = _to_kernel_frame(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size)
-    final_image = torch.zeros(H, W, 3, device=device, dtype=torch.float32)
-    for a, b in _chunks(len(sigma_x), buffer_size):
-        if sigmas[a:b].shape[0] == 0:
-            continue
-        final_image = GSCUDA.apply(sigmas[a:b], xy[a:b], col[a:b], final_image, dmax)
-    return final_image.permute(2, 0, 1).contiguous()
+    return _render_chunked(sigmas, xy, col, H, W, float(dmax), device, buffer_size)
 
 
 def rendering_python(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device):

@@ -58,8 +58,8 @@ for case in range(cases):
     # rasterizer is held to the oracle on ITS inputs, the prologue to the reference expression on its own.
     sig, xy, col = (t.cpu() for t in _cabi.prologue_forward(pg.detach(), torch.tensor([1.2 / s], device=dev), H, W))
     for a_, b_, tn in ((sig, sig_r, "sigmas"), (xy, xy_r, "coords"), (col, col_r, "colors")):
-        ep = float(((a_ - b_).abs() / (b_.abs() + 1e-3)).max())
-        assert ep <= 4e-6, (what, "prologue", tn, ep)
+        ep = float(((a_ - b_).abs() / b_.abs().clamp_min(1.0)).max())     # (CPU torch divides truly, the GPU multiplies by reciprocals: an ulp)
+        assert ep <= 5e-7, (what, "prologue", tn, ep)
     rows = (r0, r0 + nb)
     ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax, rows=rows)
     ei = float(np.abs(out.detach()[:, r0:r0 + nb].permute(1, 2, 0).cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
