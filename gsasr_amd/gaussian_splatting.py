@@ -324,7 +324,11 @@ def rendering_python(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size,
     resampled onto the HR grid centred at its mean.  An approximation of the kernels, kept for API
     completeness (BASELINE.json config 1); plain torch ops on `device`."""
     H, W = _hw(sr_size)
-    step = float(step_size)
+    # `step_size` is used as it comes: in the reference's default mode it is the 0-dim fp32 tensor
+    # `default_step_size / scale_modify[0]`, so `10 * 2 / step_size` and `i * step_size` are fp32 operations -- at scale 3.3
+    # the grid has int(55.0) = 55 steps where the same expression on the Python float gives int(54.9999...) = 54
+    # (tests/golden/tiled_frac_s3p3_30x16.npz)
+    step = step_size
     n = sigma_x.shape[0]
     cxy = rho * sigma_x * sigma_y
     if ((sigma_x ** 2) * (sigma_y ** 2) - cxy ** 2 < 0).any():

@@ -53,7 +53,7 @@ def rendering_python(gs_parameters: torch.Tensor, sr_size: Sequence[int], scale_
                      default_step_size: float = 1.2, max_buffer: int = 2000) -> torch.Tensor:
     """Restatement of the `cuda_rendering=False` branch (utils/gaussian_splatting.py:11-84)."""
     H, W = int(sr_size[0]), int(sr_size[1])
-    step = float(default_step_size / scale_modify[0])
+    step = default_step_size / scale_modify[0]          # :171 (a 0-dim fp32 tensor for tensor scale_modify: fp32 arithmetic below, as in the reference)
     sx, sy, rho, coords, col = activations(gs_parameters)
     n = sx.shape[0]
     # inverse covariance of [[sx^2, r sx sy],[r sx sy, sy^2]] and sqrt(det)                 (:15-29)

@@ -75,8 +75,44 @@ def raster_case(tv_fn, name, sigmas, coords, colors, hw, dmax=None, wseed=1):
     print(name, "img.sum", float(out["img_f32"].sum()), "gs.sum", float(out["g_sigmas_f32"].sum()))
 
 
+def tiled_section():
+    """the tiled-inference goldens only (`python make_golden.py --tiled`)"""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for modname in ("utils.gs_cuda.gswrapper", "utils.gs_cuda_dmax.gswrapper"):   # (never called with cuda_rendering=False)
+        if modname not in sys.modules:
+            m = types.ModuleType(modname)
+            m.GSCUDA = None
+            sys.modules[modname] = m
+    # ---- tiled inference driver (utils/split_and_joint_image.py) -----------------------------------------
+    import utils.split_and_joint_image as reftile  # noqa: E402  (the reference, unmodified)
+    sys.path.insert(0, os.path.dirname(OUT))
+    import tiled_models  # noqa: E402
+    # (round 3: six more shapes -- other tile grids incl. a single row / column of tiles, crop 0, scales whose ceil()
+    # rounding of the SR tile and overlap sizes differs; `--tiled` regenerates this section only)
+    for name, (hl, wl), sc, split, overlap, crop in (("int_s2_20x26", (20, 26), 2.0, 8, 2, 2),
+                                                     ("frac_s2p5_18x22", (18, 22), 2.5, 8, 3, 1),
+                                                     ("int_s3_17x31", (17, 31), 3.0, 7, 2, 1),
+                                                     ("frac_s1p7_25x19", (25, 19), 1.7, 9, 3, 2),
+                                                     ("frac_s3p3_30x16", (30, 16), 3.3, 10, 3, 0),
+                                                     ("int_s4_12x40_onerow", (12, 40), 4.0, 11, 2, 3),
+                                                     ("frac_s2p25_40x13_onecol", (40, 13), 2.25, 12, 5, 1),
+                                                     ("frac_s1p2_33x35", (33, 35), 1.2, 6, 1, 0)):
+        torch.manual_seed(21)
+        lq = torch.rand(1, 3, hl, wl)
+        out = reftile.split_and_joint_image(lq, sc, split, overlap, tiled_models.model_g, tiled_models.model_fea2gs,
+                                            torch.tensor([sc, sc]), crop_size=crop, cuda_rendering=False)
+        np.savez_compressed(os.path.join(OUT, f"tiled_{name}.npz"), lq=lq.numpy(), scale=np.float64(sc),
+                            split_size=split, overlap_size=overlap, crop_size=crop, out=out.numpy())
+        print("tiled", name, tuple(out.shape), float(out.mean()))
+
+
 def main():
     _stub_modules()
+    if "--tiled" in sys.argv:
+        return tiled_section()
+    only_python = "--python" in sys.argv
+    case = (lambda *a, **k: None) if only_python else raster_case
     chk0 = _load(os.path.join(REF, "utils/gs_cuda/check.py"), "ref_check_unbounded")
     chk1 = _load(os.path.join(REF, "utils/gs_cuda_dmax/check.py"), "ref_check_dmax")
 
@@ -89,14 +125,14 @@ def main():
         return sigmas, coords, colors
 
     # the reference's own check.py sizes (SURVEY.md 8c known answers)
-    raster_case(chk0.torch_version, "unbounded_s40_49x49", *rnd(40), (49, 49))
+    case(chk0.torch_version, "unbounded_s40_49x49", *rnd(40), (49, 49))
     s, c, k = rnd(4, sig_scale=5.0)
-    raster_case(chk1.torch_version, "dmax0p5_s4_10x10_sig5", s, c, k, (10, 10), dmax=0.5)
-    raster_case(chk1.torch_version, "dmax0p5_s40_49x49", *rnd(40), (49, 49), dmax=0.5)
+    case(chk1.torch_version, "dmax0p5_s4_10x10_sig5", s, c, k, (10, 10), dmax=0.5)
+    case(chk1.torch_version, "dmax0p5_s40_49x49", *rnd(40), (49, 49), dmax=0.5)
     # box edges active: small dmax, non-square image
-    raster_case(chk1.torch_version, "dmax0p1_s40_49x49", *rnd(40, seed=2), (49, 49), dmax=0.1)
-    raster_case(chk1.torch_version, "dmax0p25_s24_31x47", *rnd(24, seed=3, sig_scale=0.3), (31, 47), dmax=0.25)
-    raster_case(chk0.torch_version, "unbounded_s24_31x47", *rnd(24, seed=3, sig_scale=0.3), (31, 47))
+    case(chk1.torch_version, "dmax0p1_s40_49x49", *rnd(40, seed=2), (49, 49), dmax=0.1)
+    case(chk1.torch_version, "dmax0p25_s24_31x47", *rnd(24, seed=3, sig_scale=0.3), (31, 47), dmax=0.25)
+    case(chk0.torch_version, "unbounded_s24_31x47", *rnd(24, seed=3, sig_scale=0.3), (31, 47))
     # degenerate / edge inputs: a Gaussian outside the image, |rho| near the activation limit, tiny sigma,
     # a Gaussian exactly on a pixel, one exactly dmax away from a pixel column
     s, c, k = rnd(12, seed=4, sig_scale=0.2)
@@ -107,8 +143,8 @@ def main():
     s[4, :2] = torch.tensor([1e-3, 2e-3])           # very narrow
     s[5, :2] = torch.tensor([0.9, 0.02])            # very anisotropic
     c[6] = torch.tensor([2 * 10 / 32 - 1.0 + 0.25, 0.0])   # column 10 of a 33-wide grid is exactly dmax away
-    raster_case(chk1.torch_version, "dmax0p25_edge_s12_29x33", s, c, k, (29, 33), dmax=0.25)
-    raster_case(chk0.torch_version, "unbounded_edge_s12_29x33", s, c, k, (29, 33))
+    case(chk1.torch_version, "dmax0p25_edge_s12_29x33", s, c, k, (29, 33), dmax=0.25)
+    case(chk0.torch_version, "unbounded_edge_s12_29x33", s, c, k, (29, 33))
 
     # ---- L2 prologue captures -------------------------------------------------------------------------
     sys.path.insert(0, REF)
@@ -134,7 +170,7 @@ def main():
              ("s2p5_40x52_dyn", (40, 52), 2.5, True, "dynamic", 25),
              ("s4_40x52_unbounded", (40, 52), 4.0, False, "fix", 25),
              ("s3_33x33_fix", [33, 33], 3.0, True, "fix", 0.5)]
-    for name, sr, sc, if_dmax, mode, dmax in cases:
+    for name, sr, sc, if_dmax, mode, dmax in ([] if only_python else cases):
         rec.clear()
         out = refgs.generate_2D_gaussian_splatting_step(sr, gsp.clone(), sc, torch.tensor([sc, sc]),
                                                         cuda_rendering=True, if_dmax=if_dmax,
@@ -148,7 +184,10 @@ def main():
         print("prologue", name, rec["shape"], rec["dmax"], tuple(out.shape))
 
     # ---- rendering_python (cuda_rendering=False) --------------------------------------------------------
-    for name, sr, sc, n in (("n64_40x40_s4", (40, 40), 4.0, 64), ("n48_36x44_s3", (36, 44), 3.0, 48)):
+    # (round 3: scales 2.7 and 6.6, where `int(10 * 2 / step_size)` on the fp32 step TENSOR -- 45 and 110 -- differs from
+    # the same expression on a Python float -- 44 and 109; `--python` regenerates this section only)
+    for name, sr, sc, n in (("n64_40x40_s4", (40, 40), 4.0, 64), ("n48_36x44_s3", (36, 44), 3.0, 48),
+                            ("n24_27x33_s2p7", (27, 33), 2.7, 24), ("n20_33x40_s6p6", (33, 40), 6.6, 20)):
         torch.manual_seed(11)
         g = torch.randn(n, 9)
         g[:, 7:9] = torch.rand(n, 2)
@@ -158,19 +197,9 @@ def main():
                             sr_size=np.array(sr), scale=np.float64(sc), out=out.numpy())
         print("rendering_python", name, float(out.mean()), float(out.max()))
 
-    # ---- tiled inference driver (utils/split_and_joint_image.py) -----------------------------------------
-    import utils.split_and_joint_image as reftile  # noqa: E402  (the reference, unmodified)
-    sys.path.insert(0, os.path.dirname(OUT))
-    import tiled_models  # noqa: E402
-    for name, (hl, wl), sc, split, overlap, crop in (("int_s2_20x26", (20, 26), 2.0, 8, 2, 2),
-                                                     ("frac_s2p5_18x22", (18, 22), 2.5, 8, 3, 1)):
-        torch.manual_seed(21)
-        lq = torch.rand(1, 3, hl, wl)
-        out = reftile.split_and_joint_image(lq, sc, split, overlap, tiled_models.model_g, tiled_models.model_fea2gs,
-                                            torch.tensor([sc, sc]), crop_size=crop, cuda_rendering=False)
-        np.savez_compressed(os.path.join(OUT, f"tiled_{name}.npz"), lq=lq.numpy(), scale=np.float64(sc),
-                            split_size=split, overlap_size=overlap, crop_size=crop, out=out.numpy())
-        print("tiled", name, tuple(out.shape), float(out.mean()))
+    if only_python:
+        return
+    tiled_section()
 
     # BASELINE.json config 1 known answer: statistics only (the tensor is 768 KB)
     torch.manual_seed(0)

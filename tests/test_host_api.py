@@ -55,7 +55,7 @@ def test_rendering_python_branch_matches_reference(path):
 
 
 def test_sample_coords_gather():
-    z = np.load(RP[0])
+    z = np.load(os.path.join(GOLDEN, "rendering_python_n48_36x44_s3.npz"))
     sc = float(z["scale"])
     pts = [(0, 0), (3, 7), (35, 43)]
     out = gsp.generate_2D_gaussian_splatting_step(z["sr_size"].tolist(), torch.from_numpy(z["gs_parameters"]), sc,

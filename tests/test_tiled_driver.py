@@ -27,7 +27,7 @@ def test_tiled_driver_matches_reference_cpu(path):
 
 
 def test_paste_rule_and_argument_checks():
-    assert len(GOLDEN) == 2
+    assert len(GOLDEN) == 8
     assert _paste_rule(0, 0, 3, 4, 2, True) == (0, 0) and _paste_rule(0, 2, 3, 4, 2, False) == (0, 2)
     assert _paste_rule(1, 1, 3, 4, 2, True) == (2, 2) and _paste_rule(2, 3, 3, 4, 2, True) == (2, 2)
     # the reference's irregularity (fractional scale only): last column / last row, interior otherwise
