@@ -169,14 +169,19 @@ def main():
     cases = [("s4_40x52_fix", (40, 52), 4.0, True, "fix", 0.1),
              ("s2p5_40x52_dyn", (40, 52), 2.5, True, "dynamic", 25),
              ("s4_40x52_unbounded", (40, 52), 4.0, False, "fix", 25),
-             ("s3_33x33_fix", [33, 33], 3.0, True, "fix", 0.5)]
+             ("s3_33x33_fix", [33, 33], 3.0, True, "fix", 0.5),
+             # round 3: a wide and a tall image (the align-corners shift of the centres at other magnitudes), a fractional
+             # scale whose step is not exactly representable, sr_size as the tensor the tiled driver passes
+             ("s3p3_37x1500_fix", (37, 1500), 3.3, True, "fix", 0.05),
+             ("s6p6_2000x24_dyn", torch.tensor([2000, 24]), 6.6, True, "dynamic", 40),
+             ("s1p2_64x64_unbounded", (64, 64), 1.2, False, "fix", 25)]
     for name, sr, sc, if_dmax, mode, dmax in ([] if only_python else cases):
         rec.clear()
         out = refgs.generate_2D_gaussian_splatting_step(sr, gsp.clone(), sc, torch.tensor([sc, sc]),
                                                         cuda_rendering=True, if_dmax=if_dmax,
                                                         dmax_mode=mode, dmax=dmax)
         np.savez_compressed(os.path.join(OUT, f"prologue_{name}.npz"), gs_parameters=gsp.numpy(),
-                            sr_size=np.array(sr), scale=np.float64(sc), if_dmax=if_dmax, dmax_mode=mode,
+                            sr_size=np.array([int(v) for v in sr]), scale=np.float64(sc), if_dmax=if_dmax, dmax_mode=mode,
                             dmax_in=np.float64(dmax), sigmas=rec["sigmas"].numpy(), coords=rec["coords"].numpy(),
                             colors=rec["colors"].numpy(), img_shape=np.array(rec["shape"]),
                             dmax_out=np.float64(-1.0 if rec["dmax"] is None else float(rec["dmax"])),
