@@ -145,6 +145,20 @@ def main():
     c[6] = torch.tensor([2 * 10 / 32 - 1.0 + 0.25, 0.0])   # column 10 of a 33-wide grid is exactly dmax away
     case(chk1.torch_version, "dmax0p25_edge_s12_29x33", s, c, k, (29, 33), dmax=0.25)
     case(chk0.torch_version, "unbounded_edge_s12_29x33", s, c, k, (29, 33))
+    # (sizes below 50: check.py:9 logs through an undefined `logger` from 50 px up)
+    # round 3: a thin wide image, a thin tall one, strongly correlated Gaussians, a sub-pixel dmax box, negative sigmas
+    # (only sigma^2 and 1/(sx sy) enter the reference's formulas)
+    case(chk1.torch_version, "dmax0p3_thin_s30_5x49", *rnd(30, seed=5, sig_scale=0.15), (5, 49), dmax=0.3)
+    case(chk0.torch_version, "unbounded_tall_s30_49x4", *rnd(30, seed=6, sig_scale=0.2), (49, 4))
+    s, c, k = rnd(24, seed=7, sig_scale=0.25)
+    s[:, 2] = torch.tensor([0.9999, -0.9999, 0.999, -0.999, 0.99, -0.99] * 4)
+    case(chk1.torch_version, "dmax0p4_rho_s24_33x37", s, c, k, (33, 37), dmax=0.4)
+    case(chk0.torch_version, "unbounded_rho_s24_33x37", s, c, k, (33, 37))
+    case(chk1.torch_version, "dmax0p02_s40_41x43", *rnd(40, seed=8, sig_scale=0.5), (41, 43), dmax=0.02)
+    s, c, k = rnd(16, seed=9, sig_scale=0.3)
+    s[::2, 0] *= -1.0
+    s[::3, 1] *= -1.0
+    case(chk1.torch_version, "dmax0p5_negsigma_s16_31x29", s, c, k, (31, 29), dmax=0.5)
 
     # ---- L2 prologue captures -------------------------------------------------------------------------
     sys.path.insert(0, REF)

@@ -35,8 +35,11 @@ def test_forward_f32_matches_reference_torch_version(path):
     # both are fp32 evaluations with different association; agreement is at fp32 rounding level
     # relative to the exponent's conditioning (|rho| -> 1 cases amplify it), checked vs fp64 too
     tol = 2e-3 if "edge" in path else 2e-5
-    assert np.abs(img - z["img_f32"]).max() <= tol * max(1.0, np.abs(z["img_f32"]).max())
-    assert np.abs(img - z["img_f64"]).max() <= tol * max(1.0, np.abs(z["img_f64"]).max())
+    # (the `_rho_` cases, |rho| up to 0.9999: never tighter than twice what the reference's own fp32 run achieves against
+    # its fp64 run -- 4e-5 and 1e-4 of the image there)
+    own = 2.0 * float(np.abs(z["img_f32"] - z["img_f64"]).max()) if "_rho_" in path else 0.0
+    assert np.abs(img - z["img_f32"]).max() <= max(own, tol * max(1.0, np.abs(z["img_f32"]).max()))
+    assert np.abs(img - z["img_f64"]).max() <= max(own, tol * max(1.0, np.abs(z["img_f64"]).max()))
 
 
 @pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[7:-4] for p in RASTER])
@@ -45,7 +48,9 @@ def test_forward_f64_matches_reference_fp64(path):
     h, w = int(z["h"]), int(z["w"])
     img = gs_oracle.forward_f64(z["sigmas"], z["coords"], z["colors"], h, w, dmax)
     # reference fp64 run stores into an fp32 image buffer (check.py:11)
-    assert np.abs(img - z["img_f64"]).max() <= 1e-6 * max(1.0, np.abs(img).max())
+    # (pixel coordinates: double in the reference's fp64 run, rounded to float here as in the kernels -- |rho| = 0.9999
+    # amplifies that difference to 2e-6)
+    assert np.abs(img - z["img_f64"]).max() <= (5e-6 if "_rho_" in path else 1e-6) * max(1.0, np.abs(img).max())
 
 
 @pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[7:-4] for p in RASTER])
@@ -61,6 +66,8 @@ def test_backward_matches_reference_autograd(path):
         # (check.py:15-16) while the kernels -- and this oracle -- round them to float (gs.cu:27-28)
         assert _relmax(got64, ref64) <= 2e-5, key
         tol = 5e-3 if "edge" in path else 2e-4
+        if "_rho_" in path:   # never tighter than twice the reference's own fp32-vs-fp64 distance (7e-4 for the centres)
+            tol = max(tol, 2.0 * _relmax(ref32, ref64))
         assert _relmax(got32, ref64) <= tol, key
         assert _relmax(got32, ref32) <= tol, key
 
