@@ -14,6 +14,7 @@ from gsasr_amd import _cabi, gaussian_splatting as gsp  # noqa: E402
 
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+BIG = int(sys.argv[2]) if len(sys.argv) > 2 else 400      # largest sample side of the "big" batched cases
 rng = np.random.default_rng(11)
 worst_img = worst_g = 0.0
 
@@ -29,7 +30,7 @@ for case in range(cases):
         B = int(rng.integers(2, 9))
         n = int(rng.integers(1, 500))
         big = rng.random() < 0.3
-        sizes = [(int(rng.integers(2, 400 if big else 90)), int(rng.integers(2, 400 if big else 90))) for _ in range(B)]
+        sizes = [(int(rng.integers(2, BIG if big else 90)), int(rng.integers(2, BIG if big else 90))) for _ in range(B)]
         S = int(rng.integers(1, 400))
         p = (torch.randn(B, n, 9, generator=g) * float(rng.choice([0.5, 1.5, 3.0]))).to(dev)
         p[:, :, 7:9] = torch.rand(B, n, 2, generator=g).to(dev) * 1.4 - 0.2
