@@ -5,6 +5,7 @@ config-2 checks for dmax 0.5 and the unbounded op, and raw-op inputs the host AP
 References: utils/gaussian_splatting.py:100-117,133-155,219-265; utils/gs_cuda/gswrapper.py:41-48;
 utils/gs_cuda_dmax/gswrapper.py:46-53; utils/split_and_joint_image.py:160-225.
 """
+import glob
 import math
 import os
 import sys
@@ -94,6 +95,45 @@ def test_gaussiansplatting_render_helpers_against_oracle(dev):
     (render_dmax(ag, b, d, (H, W), 0.2) * wgt.to(dev)).sum().backward()
     want = gs_oracle.backward_f64(s, c, k, wgt.numpy(), 0.2)[0]
     assert np.abs(ag.grad.cpu().numpy() - want).max() <= 2e-4 * np.abs(want).max()
+
+
+_TILED = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiled_*.npz")))
+
+
+@pytest.mark.parametrize("path", _TILED, ids=[os.path.basename(p)[6:-4] for p in _TILED])
+def test_tiled_driver_on_gpu_golden_shapes_against_oracle_canvas(path, dev):
+    """f3 on the GPU at the eight shapes of the reference-captured goldens (tile grids incl. one row / one column, crop 0,
+    scales 1.2 ... 4): batched canvases of tiles against a canvas of ORACLE tiles pasted with the restated case tree.
+    (The goldens' own `out` is the reference's CPU approximation `rendering_python`; here the kernels' exact maths.)"""
+    from gsasr_amd.split_and_joint_image import split_and_joint_image
+    z = np.load(path)
+    lq = torch.from_numpy(z["lq"])
+    scale, split, overlap, crop = float(z["scale"]), int(z["split_size"]), int(z["overlap_size"]), int(z["crop_size"])
+    hl, wl = lq.shape[-2:]
+    sm = torch.tensor([scale, scale])
+    out = split_and_joint_image(lq.to(dev), scale, split, overlap, tiled_models.model_g, tiled_models.model_fea2gs, sm.to(dev),
+                                crop_size=crop, if_dmax=True, dmax_mode="fix", dmax=0.4)
+    stride = split - overlap
+    nh, nw = math.ceil((hl - overlap) / stride), math.ceil((wl - overlap) / stride)
+    lq_pad = torch.nn.functional.pad(lq, (0, nw * stride + overlap - wl, 0, nh * stride + overlap - hl), mode="reflect")
+    size_sr, overlap_sr = math.ceil(split * scale), math.ceil(overlap * scale)
+    st = size_sr - overlap_sr
+    want = np.zeros((1, 3, (nh - 1) * st + size_sr, (nw - 1) * st + size_sr), np.float64)
+    frac = scale != int(scale)
+    for i in range(nh):
+        for j in range(nw):
+            tile = lq_pad[:, :, i * stride: i * stride + split, j * stride: j * stride + split]
+            p = tiled_models.model_fea2gs(tiled_models.model_g(tile), sm[0].unsqueeze(0))[0]
+            t = _oracle_image(p, size_sr, size_sr, sm, 0.4)
+            top = 0 if i == 0 else crop
+            left = 0 if j == 0 else crop
+            if frac and i > 0 and j > 0 and j == nw - 1 and i != nh - 1:
+                top = 0
+            if frac and i > 0 and j > 0 and i == nh - 1 and j != nw - 1:
+                left = 0
+            want[0, :, i * st + top: i * st + size_sr, j * st + left: j * st + size_sr] = t[:, top:, left:]
+    assert out.shape == want.shape
+    assert np.abs(out.cpu().numpy() - want).max() <= IMG_ATOL
 
 
 @pytest.mark.parametrize("scale", [2.0, 2.5])
