@@ -613,13 +613,23 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
     in_box, swept, vfrac = pair_rates(st, kern, a.cutoff)
     h_lr, w_lr, scale, desc = CONFIGS[config]
+    traffic = None
+    try:   # HBM bytes per launch of the dominant stage's kernels, replayed from the committed counter passes of this config
+        import json
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")))
+        traffic = pmc.get("configs", {}).get(config, {}).get(dom)
+    except (OSError, ValueError):
+        traffic = None
     out = {"workload": desc, "H": st.H, "W": st.W, "gaussians": st.n, "dmax": st.dmax if st.dmax is not None else -1,
            "cutoff_tau": round(st.cabi.resolve_cutoff(a.cutoff, st.plan.dims.s), 3), "what": "fwd only" if st.fwd_only else "fwd+bwd",
            "steps": n, "ms_per_step": ms, "value": st.H * st.W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
            "kernels": kern,
            "roofline": {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
                         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
-                        "traffic": None, "valu_frac": vfrac, "pairs_in_swept_window": swept, "pairs_in_dmax_box": in_box}}
+                        "traffic": traffic,
+                        "traffic_source": ("profiles/pmc_latest.json (REPLAYED from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                           "this config, all kernels of the stage; not counted in this run)" if traffic is not None else None),
+                        "valu_frac": vfrac, "pairs_in_swept_window": swept, "pairs_in_dmax_box": in_box}}
     del st
     torch.cuda.empty_cache()
     return out

@@ -53,6 +53,11 @@ fi
 # 3c. GSASR's real Gaussian density at inference size (16 per LR pixel)
 rocprofv3 --kernel-trace --stats -d /tmp/kt216_$TAG -o kt -- $BENCH --config c2x16 --steps 10 --warmup 3 > /dev/null 2> $OUT/kt216.err
 python $R/tools/rocpd_summary.py /tmp/kt216_$TAG/kt_results.db --skip 1 > $OUT/kernel_stats_c2x16.txt
+# 3d. HBM counter passes of the x12, x8 and dense legs (forward / backward / gather bytes per launch -> pmc_latest.json "configs")
+for cfg in c3 c4 c2x16; do
+  pass pmc_fetch_$cfg "FETCH_SIZE" $BENCH --config $cfg --steps 5 --warmup 2
+  pass pmc_write_$cfg "WRITE_SIZE" $BENCH --config $cfg --steps 5 --warmup 2
+done
 # 4. the plain bench line (with exact / dropin / cpu_baseline / the x12, x8 and 16-per-LR-pixel legs)
 cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/kernel_stats.txt $OUT/pmc_fetch.txt $OUT/pmc_write.txt

@@ -47,6 +47,37 @@ def main():
             busy = grab_any(sq, name, "SQ_BUSY_CYCLES")
             insts = grab_any(sq, name, "SQ_INSTS_VALU")
             d[k].update(valu_busy=round(4.0 * act / (32.0 * busy), 4), valu_insts=int(insts * 32))
+    # the x12, x8 and 16-per-LR-pixel legs of the bench line (same passes at those configs, when collected): HBM bytes per
+    # launch of every kernel of the stage, {forward: .., backward: ..}; the tile-stationary backward counts its gather
+    legs = {}
+    for cfg in ("c3", "c4", "c2x16"):
+        ff = os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_{cfg}.txt")
+        fw = os.path.join(ROOT, "profiles", f"{tag}_pmc_write_{cfg}.txt")
+        if not (os.path.exists(ff) and os.path.exists(fw)):
+            continue
+
+        def kernels(fn, ctr):
+            out, name = {}, None
+            for line in open(fn):
+                t = line.split()
+                if line.startswith("  ") and not line.startswith("      "):
+                    name = line.strip()
+                elif t and t[0] == ctr and name:
+                    out[name] = float(t[1])
+            return out
+        fe, wr = kernels(ff, "FETCH_SIZE"), kernels(fw, "WRITE_SIZE")
+        leg = {}
+        for stage, keys in (("forward", ("k_render_fwd",)), ("backward", ("k_render_bwd", "k_bwd_gather"))):
+            tot = 0.0
+            for k in fe:
+                if any(q in k for q in keys):
+                    tot += (2 * fe[k] + wr.get(k, 0.0)) * 1024
+            if tot:
+                leg[stage] = int(tot)
+        legs[cfg] = leg
+    if legs:
+        d["configs"] = legs
+        d["_configs_source"] = f"profiles/{tag}_pmc_fetch_<config>.txt + {tag}_pmc_write_<config>.txt, same method; backward = render kernel + gather"
     d["_source"] = re.sub(r"r\d\d_", tag + "_", d["_source"])
     d["_valu_method"] = ("valu_busy = 4 * SQ_ACTIVE_INST_VALU / (32 * SQ_BUSY_CYCLES), both per shader-engine averages from "
                          f"profiles/{tag}_pmc_sq.txt (quad-cycle units; 32 SIMDs per SE); valu_insts = wave-level VALU "
