@@ -1538,7 +1538,36 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 bwd_trip<TEST, false>(R, g0, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
                 bwd_trip<TEST, false>(R, g1, n1, w1, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
             }
-            for (; t > 0; --t, soff += 2 * halfb, sp += 2 * RPI) {
+            if (!UNROLL && t > 0) {
+                // The plain loop runs ONE TRIP AHEAD: the two loads of trip k+1 are in flight while trip k is summed (two
+                // register sets used alternately: no copies).  Left to the compiler every trip was a dependent round trip
+                // -- issue, wait, sum -- and a wave's life at x4 is six of them: -5% at config 2, -4% on the config-5 crops,
+                // at 71 VGPRs (seven waves per SIMD kept).  Two trips ahead spills (72-VGPR budget): +8%; the same rotation
+                // in the unrolled instantiation: no gain (profiles/r03_bwd_experiments.txt).
+#define GSASR_TRIP(G) { const v2f n0 = {sp[0], sp[RPI]}; const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0; \
+                        bwd_trip<TEST, false>(R, G, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax); sp += 2 * RPI; }
+                Grad6 ga = bwd_load(rsrc, voff, voff_b, soff);
+                soff += 2 * halfb;
+                for (; t >= 3; t -= 2) {
+                    const Grad6 gb = bwd_load(rsrc, voff, voff_b, soff);
+                    soff += 2 * halfb;
+                    GSASR_TRIP(ga)
+                    ga = bwd_load(rsrc, voff, voff_b, soff);
+                    soff += 2 * halfb;
+                    GSASR_TRIP(gb)
+                }
+                if (t == 2) {
+                    const Grad6 gb = bwd_load(rsrc, voff, voff_b, soff);
+                    soff += 2 * halfb;
+                    GSASR_TRIP(ga)
+                    GSASR_TRIP(gb)
+                } else {
+                    GSASR_TRIP(ga)
+                }
+#undef GSASR_TRIP
+                t = 0;
+            }
+            for (; t > 0; --t, soff += 2 * halfb, sp += 2 * RPI) {   // (odd trip of the unrolled instantiation)
                 const v2f n0 = {sp[0], sp[RPI]};
                 const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0;
                 bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr,
