@@ -1831,8 +1831,10 @@ constexpr int BT_W = 32, BT_H = 16;                 // tile
 #define BT_WAVES_N 2
 #endif
 constexpr int BT_WAVES = BT_WAVES_N;                // waves per workgroup (= per tile)
-constexpr int BT_CHUNKS = 8 / BT_WAVES;             // candidate chunks per wave and round (level 1)
-constexpr int BT_LIST = BT_WAVES * BT_CHUNKS * 64;  // survivors per round at most (512)
+// candidate chunks per wave and round (level 1) = a template parameter of the kernel: 8 / BT_WAVES (rounds of 512 candidates,
+// 19 KB of LDS per tile = four waves per SIMD), or half of that for plans at 32 HR pixels per Gaussian and more -- a tile
+// then sees ~300 candidates, rounds of 256 cost it nothing, and 15 KB of LDS + 96 VGPRs put FIVE waves on a SIMD: -8% at
+// config 4 (at x4 the smaller rounds cost +5%, at 16 Gaussians per LR pixel +8%: they keep the large ones)
 constexpr int BT_THREADS = 64 * BT_WAVES;
 constexpr int BT_QSTRIDE = 32 * 8 + 8;              // floats per quadrant block: 32 entries of 8 floats, +8 so that the
                                                     // blocks of the eight quadrants start 8 banks apart
@@ -1918,10 +1920,11 @@ __device__ __forceinline__ void bt_eval(const PlanView &V, unsigned j, float dm,
     a[7] = Cb.x + Cb.y;
 }
 
-template <bool BOUNDED>
-__global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_render_bwd_tile(
+template <bool BOUNDED, int BT_CHUNKS>
+__global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_CHUNKS * BT_WAVES <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
     Params P, PlanView V, const float *__restrict__ grad, int tiles_x, int use_atomics)
 {
+    constexpr int BT_LIST = BT_WAVES * BT_CHUNKS * 64;  // survivors per round at most (512 / 256)
     __shared__ __attribute__((aligned(16))) float s_g[8 * BT_QSTRIDE];
     __shared__ float s_px[BT_W], s_py[BT_H];
     __shared__ unsigned s_list[BT_LIST];            // survivor: index in cell order | needs the dmax test << 31
@@ -3047,8 +3050,12 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
     if (rows > 0) {
         const int tiles_x = (dims->w + BT_W - 1) / BT_W, tiles_y = (rows + BT_H - 1) / BT_H;
         const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(BT_THREADS);
-        if (P.bounded) hipLaunchKernelGGL(k_render_bwd_tile<true>, grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2);
-        else hipLaunchKernelGGL(k_render_bwd_tile<false>, grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2);
+        // small rounds + five waves per SIMD from 32 HR pixels per Gaussian up (where this kernel is the default)
+        const bool sparse = (double)rows * (double)dims->w >= 32.0 * (double)dims->s;
+#define GSASR_BT(B, C) hipLaunchKernelGGL((k_render_bwd_tile<B, C>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2)
+        if (P.bounded) { if (sparse) GSASR_BT(true, 4 / BT_WAVES); else GSASR_BT(true, 8 / BT_WAVES); }
+        else { if (sparse) GSASR_BT(false, 4 / BT_WAVES); else GSASR_BT(false, 8 / BT_WAVES); }
+#undef GSASR_BT
         HIP_TRY(hipGetLastError());
     }
     if (gather) {
