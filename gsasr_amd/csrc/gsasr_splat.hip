@@ -1430,9 +1430,9 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 
 // Two 12-byte pixels through a raw buffer resource: address = base(SGPR x4) + per-lane byte offset (one VGPR per
 // row of the pair, constant over the sweep) + ONE running row offset (SGPR), so a trip spends no VALU instruction and
-// a single scalar add on addressing, and reads past the end of the slab return 0 instead of faulting.  (This kernel
-// is bound by instruction issue of ANY kind: a scalar instruction per trip costs what a vector one does, 0.35 us at
-// config 2 -- DESIGN.md 3c.)
+// a single scalar add on addressing, and reads past the end of the slab return 0 instead of faulting.  (An instruction
+// added to a trip of ANY kind, scalar or vector, costs 0.35 us at config 2: the trips are the wave's dependent chain, and
+// that chain at seven waves per SIMD is the run time -- DESIGN.md 3c (c), (d).)
 __device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int voff_b, int soff_a)
 {
     const int soff_b = soff_a;
@@ -3034,8 +3034,9 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
         const bool unroll = (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
         // (Measured dead ends, git history: two Gaussians per wave one after the other, side by side in half waves, and --
-        // round 3 -- sharing every gradient load over the union of their windows: 44-50 us against 37 us at config 2.  The
-        // sweep is bound by instruction issue, not by its loads)
+        // round 3 -- sharing every gradient load over the union of their windows: 44-50 us against 37 us at config 2; rows
+        // or a cell's window staged in LDS; a planar-gradient sweep.  A wave's life is its chain of dependent round trips:
+        // what helped was running the sweep one trip ahead)
 #define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
         if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
         else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
