@@ -56,8 +56,33 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: re-execute this very command line under
+    torch.distributed.run, one rank per GPU on this node (rendezvous on 127.0.0.1, a free port).  The ranks inherit
+    stdout, so rank 0's JSON line is the last line of this process's output as well; the exit status is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        print(f"[bench] --gpus {args.gpus} over RCCL needs {args.gpus} GPUs, this node shows {torch.cuda.device_count()} "
+              "(--backend gloo runs the same code path functionally with ranks sharing devices)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {args.gpus} without a launcher: spawning {args.gpus} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

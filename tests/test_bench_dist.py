@@ -12,14 +12,24 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LAUNCHER = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", "29541"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--exchange", "halo"], ["--exchange", "broadcast"], ["--config", "c4"]],
-                         ids=["weak-halo", "weak-broadcast", "strong-c4"])
-def test_bench_two_ranks_functional(extra):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+@pytest.mark.parametrize("launcher,extra", [([sys.executable], ["--exchange", "halo"]),
+                                            ([sys.executable], ["--exchange", "broadcast"]),
+                                            ([sys.executable], ["--config", "c4"]),
+                                            (LAUNCHER, ["--exchange", "halo"])],
+                         ids=["self-weak-halo", "self-weak-broadcast", "self-strong-c4", "torchrun-weak-halo"])
+def test_bench_two_ranks_functional(launcher, extra):
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment spawns its own ranks (the form
+    the driver uses at N = 1); under `python -m torch.distributed.run ... bench.py --gpus 2` (the driver's N > 1 form)
+    it must not spawn again."""
+    cmd = [*launcher, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--backend", "gloo", "--no-cpu-baseline", *extra]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
