@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, copy_bandwidth, cpu_baseline, dropin_run, emit,  # noqa: E402
+from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
                       exact_runs, flush_c_stdio, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
 
 
@@ -202,7 +202,7 @@ def main():
             roofline["hbm_copy_GBps_measured"] = None
             print(f"[bench] copy bandwidth probe failed: {e!r}", file=sys.stderr)
         if not step.halo and not step.batched:
-            tau = step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s)
+            tau, _ = effective_tau(step, args.cutoff)
             in_box, swept = window_pairs(step.sig, step.xy, step.H, step.W, step.dmax, tau, step.rows)
             valu = {"pairs_in_dmax_box": in_box, "pairs_in_swept_window": swept,
                     "Gpairs_per_s": {k: round(swept / (kern[k]["avg_ms"] * 1e-3) / 1e9, 1) for k in kern if k != "plan"},
@@ -239,6 +239,8 @@ def main():
         dist.barrier()
     if rank == 0:
         h_lr, w_lr, scale, desc = CONFIGS[args.config]
+        tau_eff, k_box = (effective_tau(step, args.cutoff) if not step.batched
+                          else (step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 0))
         out = {
             "metric": ("HR Mpixels/sec fwd+bwd (x4, 1 Gaussian/LR px); achieved HBM GB/s vs roofline" if args.config == "c2"
                        else "sampled HR Mpixels/sec prologue+fwd+bwd (x4, 16 Gaussians/LR px, batch 16, sample_coords)" if getattr(step, "sampled", False)
@@ -249,9 +251,12 @@ def main():
             "config": {"workload": desc + (f"; weak-scaled to {step.H}x{step.W} HR / {step.n} Gaussians over {world} row bands"
                                            if world > 1 and not step.strong and not step.batched else ""),
                        "H": step.H, "W": step.W, "gaussians": step.n, "dmax": step.dmax if step.dmax is not None else -1,
-                       "cutoff_tau": round(step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 3),
-                       "cutoff_note": "terms with exponent < -tau are skipped; default tau = ln(N/1e-5) bounds the image error by "
-                                      "1e-5 x max|colour| per pixel for any input (colours are <= 1 after the host prologue; parity tolerance 1e-4, all parity tests run at this default); "
+                       "cutoff_tau": round(tau_eff, 3), "cutoff_k_box": k_box,
+                       "cutoff_tau_conservative": round(step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 3),
+                       "cutoff_note": "terms with exponent < -tau are skipped; default tau = ln(K/1e-5) with K = the plan's own bound on how many "
+                                      "Gaussians' dmax boxes cover one pixel (only those contribute, gs_cuda_dmax/gs.cu:41-50; K <= N, unbounded op: K = N) "
+                                      "bounds the image error by 1e-5 x max|colour| per pixel for any input (colours are <= 1 after the host prologue; "
+                                      "parity tolerance 1e-4, all parity tests run at this default); "
                                       "--cutoff 104 sums the reference's exact set of non-zero fp32 terms, --cutoff -1 every in-box term",
                        "launch": launch,
                        "parallelism": (f"data-parallel x{world} (one batch per rank, no exchange)" if step.batched and world > 1

@@ -26,7 +26,7 @@ EXPORTS = (
     "gsasr_band_select", "gsasr_band_merge", "gsasr_resolve_cutoff",
     "gsasr_sample_workspace_bytes", "gsasr_splat_sample_forward", "gsasr_splat_sample_backward",
     "gsasr_step_sample_forward", "gsasr_step_sample_backward",
-    "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm",
+    "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm", "gsasr_plan_cutoff",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -118,6 +118,8 @@ def lib():
         L.gsasr_get_default_cutoff.restype = f
         L.gsasr_resolve_cutoff.restype = f
         L.gsasr_resolve_cutoff.argtypes = [f, i]
+        L.gsasr_plan_cutoff.restype = i
+        L.gsasr_plan_cutoff.argtypes = [dp, vp, sz, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]
         if L.gsasr_abi_version() != 4:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
@@ -813,6 +815,17 @@ def set_default_cutoff(tau: float) -> None:
 
 def get_default_cutoff() -> float:
     return float(lib().gsasr_get_default_cutoff())
+
+
+def plan_cutoff(p: Plan) -> Tuple[float, int]:
+    """(tau, K) the windows of plan `p` were built with: for the bounded op under the adaptive default tau is data-derived,
+    ln(K / 1e-5) with K = the plan's own bound on how many dmax boxes cover one pixel (include/gsasr_splat.h); K = 0
+    otherwise.  Synchronises the stream: for reports and tests."""
+    tau, k = ctypes.c_float(0.0), ctypes.c_uint(0)
+    with _on(p.device):
+        check(lib().gsasr_plan_cutoff(ctypes.byref(p.dims), p.workspace.data_ptr(), p.workspace.numel(), _stream(p.device),
+                                      ctypes.byref(tau), ctypes.byref(k)), "gsasr_plan_cutoff")
+    return float(tau.value), int(k.value)
 
 
 def resolve_cutoff(cutoff: float, s: int) -> float:

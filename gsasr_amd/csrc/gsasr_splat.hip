@@ -87,14 +87,17 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #endif
 constexpr int BWD_WAVES = BWD_WAVES_N;  // waves (= consecutive cell-ordered Gaussians) per backward workgroup
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
-constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y
+constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y, [2]=largest cell count,
+                                //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut)
 constexpr double LOG2E = 1.4426950408889634074;
 
 struct Params {
     int s, h, w, row0, row1;
     int bounded;     // 1: gs_cuda_dmax box test, 0: gs_cuda (no test)
     float dmax;      // box half-size (normalised units); +inf when !bounded
-    float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled
+    float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled (the CONSERVATIVE tau: classes, dead set)
+    float adapt_cells;  // > 0: the windows are built with the data-derived cutoff tau' = ln(K / eps) <= tau, K = the most Gaussians
+                     // whose dmax box can cover one pixel <= (largest cell count) * adapt_cells + (large class); 0: kcut everywhere
     int ncx, ncy, ncells;
     unsigned flags;  // GSASR_FLAG_*
     int batch;       // 1: one image.  B > 1: B samples stacked in a canvas of B slots (h = B*slot rows, w columns)
@@ -315,6 +318,19 @@ float default_cutoff()
     return v;
 }
 
+// development switch: GSASR_SPLAT_ADAPT=0 keeps the conservative tau = ln(s / eps) in the windows (A/B of adapt_kcut)
+bool adapt_env()
+{
+    static std::atomic<int> cached{-1};
+    int v = cached.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("GSASR_SPLAT_ADAPT");
+        v = !e ? 1 : atoi(e) != 0;
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
 // tau used for `s` Gaussians: explicit, process-fixed, or adaptive ln(s/eps) in [16, 104] (see the header)
 float resolve_cutoff(float cutoff, int s)
 {
@@ -332,6 +348,16 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.dmax = P.bounded ? d->dmax : INFINITY;
     const float tau = resolve_cutoff(d->cutoff, d->s);
     P.kcut = tau > 0.f ? (float)(std::sqrt(2.0 * (double)tau) * (1.0 + 1e-6)) : 0.f;
+    // data-derived cutoff (adapt_kcut): the bounded op under the adaptive default only -- an explicit tau (per call, per
+    // process, environment) is used as given, and the unbounded op has no box to count in
+    P.adapt_cells = 0.f;
+    if (P.bounded && d->cutoff == 0.f && default_cutoff() == 0.f && P.kcut > 0.f && adapt_env()) {
+        const int B = batch_of(d);
+        const double dpx = (double)d->dmax * 0.5 * (double)(d->w - 1), dpy = (double)d->dmax * 0.5 * (double)((B > 1 ? d->slot : d->h) - 1);
+        const double cx = std::ceil(2.0 * std::floor(dpx + 1.02) / (double)CELL) + 1.0, cy = std::ceil(2.0 * std::floor(dpy + 1.02) / (double)CELL) + 1.0;
+        const double cells = std::fmin(cx, (double)L.ncx) * std::fmin(cy, (double)L.ncy);
+        P.adapt_cells = (float)std::fmin(cells, 1.0e9) * (1.f + 1e-6f);
+    }
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
     P.flags = d->flags;
     if (!(P.flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)))   // (development A/B switch)
@@ -402,15 +428,15 @@ struct Box {
 
 constexpr double WINDOW_EPS = 0.02;  // px; covers every rounding between these windows and the kernels' float tests
 
-__device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y, const Params &P, const Geo &g)
+__device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y, const Params &P, const Geo &g, float kcut)
 {
     Box b;
     float ext_x = P.dmax, ext_y = P.dmax;
-    if (P.kcut > 0.f) {  // marginal bound of the ellipse {exponent >= -tau}: |dx| <= sx*sqrt(2 tau), any rho
+    if (kcut > 0.f) {  // marginal bound of the ellipse {exponent >= -tau}: |dx| <= sx*sqrt(2 tau), any rho
         // (|sigma|: the reference's formulas only see sigma^2 and 1/(sx sy), gs.cu:33-56, so a negative sigma -- the
         // raw op accepts any float, check.py feeds randn -- is a Gaussian like any other, with the sign of rho flipped)
-        ext_x = fminf(ext_x, P.kcut * fabsf(sx));
-        ext_y = fminf(ext_y, P.kcut * fabsf(sy));
+        ext_x = fminf(ext_x, kcut * fabsf(sx));
+        ext_y = fminf(ext_y, kcut * fabsf(sy));
     }
     // Pixel X sits at px = 2X/(w-1)-1, so |px - x| <= ext  <=>  |X - cxp| <= ext*hx with cxp = (x+1)*hx.
     // Evaluated in double (once per Gaussian); the float pixel table differs from the exact grid by
@@ -448,6 +474,29 @@ __device__ __forceinline__ float wave_sum(float v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+// The data-derived support cutoff (bounded op, adaptive default only).  A term is skipped only OUTSIDE a Gaussian's
+// window, and in the bounded op (gs_cuda_dmax/gs.cu:41-50) only a Gaussian whose dmax box covers the pixel contributes at
+// all: at most K = max over pixels of #{s : |px - x_s| <= dmax and |py - y_s| <= dmax} terms can be skipped on one pixel,
+// each below exp(-tau') times its colour, so tau' = ln(K / eps) keeps the bound `eps * max|colour|` per pixel of the
+// conservative tau = ln(s / eps) -- for ANY input: K is bounded from the plan's own histogram.  A Gaussian of the normal
+// class is binned by the cell of its (clamped) centre and can cover a pixel only from a cell within
+// m = floor(dmax_px + 1.02) pixels of it in x and in y (the centre is binned by its floor, the pixel table is the grid to
+// < 0.01 px), i.e. from the cells that 2m + 1 consecutive pixels touch: at most Cx = ceil(2 mx / 16) + 1 by Cy, so
+//     K <= (largest cell count) * Cx * Cy + (size of the large class)                        [adapt_cells = Cx * Cy]
+// (Gaussians stacked on one spot make the largest count ~s and tau' = tau: nothing is lost on adversarial input.)
+// The log is the hardware's (1 ulp): 1e-3 is added to tau', a factor 1.001 on the side of the bound.
+__device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, unsigned nlarge, float &tau, unsigned &K)
+{
+    const float tau_cap = 0.5f * P.kcut * P.kcut;
+    if (!(P.adapt_cells > 0.f)) { tau = tau_cap; K = 0u; return P.kcut; }
+    const float Kf = fmaxf((float)maxcount * P.adapt_cells + (float)nlarge, 1.f);
+    K = (unsigned)fminf(Kf, 4.0e9f);
+    const float t = fmaxf(__log2f(Kf * (1.f / GSASR_SPLAT_DEFAULT_EPS)) * 0.69314718f + 1e-3f, 16.f);
+    if (!(t < tau_cap)) { tau = tau_cap; return P.kcut; }
+    tau = t;
+    return fminf(sqrtf(2.f * t) * (1.f + 1e-6f), P.kcut);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -517,6 +566,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int lane = threadIdx.x & 63;
     // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
     for (int k = i; k < P.ncells + 1 + NDEAD; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
+    if (i == 0) V.hdr[2] = 0u;   // largest cell count: the blocks of k_scan_local raise it with atomicMax
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
@@ -556,7 +606,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
             sx = sigmas[i3 + 0]; sy = sigmas[i3 + 1];
             x = coords[i2 + 0]; y = coords[i2 + 1];
         }
-        const Box b = gaussian_box(sx, sy, x, y, P, g);
+        const Box b = gaussian_box(sx, sy, x, y, P, g, P.kcut);
         if (b.cls == 2) {
             // NDEAD counters instead of one: a row band of a large image sees most of the Gaussians here, and one
             // returning atomic per wave on a single word serialises (203 us for 1 M Gaussians, 7/8 dead)
@@ -609,12 +659,12 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     }
 }
 
-__global__ __launch_bounds__(1024) void k_scan(int n, const unsigned *__restrict__ count,
+__global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *__restrict__ count,
                                                unsigned *__restrict__ start, int nblk,
                                                const unsigned *__restrict__ blockmax, unsigned *__restrict__ hdr)
 {
     __shared__ unsigned part[1024];
-    __shared__ unsigned smax[2][16];
+    __shared__ unsigned smax[3][16];
     const int t = threadIdx.x;
     // (a) max half-extents over the classify blocks -> plan header
     unsigned mx = 0, my = 0;
@@ -624,18 +674,30 @@ __global__ __launch_bounds__(1024) void k_scan(int n, const unsigned *__restrict
     }
     mx = wave_max_u32(mx);
     my = wave_max_u32(my);
-    if ((t & 63) == 0) { smax[0][t >> 6] = mx; smax[1][t >> 6] = my; }
-    // (b) exclusive scan of the per-cell counts
+    // (b) exclusive scan of the per-cell counts (+ the largest count of a cell, for adapt_kcut)
     const int per = (n + 1023) / 1024;
     const int b = t * per, e = min(n, b + per);
-    unsigned sum = 0;
-    for (int k = b; k < e; ++k) sum += count[k];
+    unsigned sum = 0, mc = 0;
+    for (int k = b; k < e; ++k) {
+        const unsigned c = count[k];
+        sum += c;
+        if (k < P.ncells) mc = max(mc, c);
+    }
+    mc = wave_max_u32(mc);
+    if ((t & 63) == 0) { smax[0][t >> 6] = mx; smax[1][t >> 6] = my; smax[2][t >> 6] = mc; }
     part[t] = sum;
     __syncthreads();
-    if (t < 2) {
+    if (t < 3) {
         unsigned m = 0;
         for (int k = 0; k < 16; ++k) m = max(m, smax[t][k]);
         hdr[t] = m;
+        if (t == 2) {
+            float tau;
+            unsigned K;
+            hdr[3] = __float_as_uint(adapt_kcut(P, m, count[P.ncells], tau, K));
+            hdr[4] = __float_as_uint(tau);
+            hdr[5] = K;
+        }
     }
     for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partials
         unsigned v = t >= o ? part[t - o] : 0u;
@@ -656,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_scan(int n, const unsigned *__restrict
 // block adds the totals of the blocks before it (<= a few hundred values) to its 4096 entries.
 constexpr int SCAN_CHUNK = 4096;
 
-__global__ __launch_bounds__(1024) void k_scan_local(int n, const unsigned *__restrict__ count,
+__global__ __launch_bounds__(1024) void k_scan_local(int ncells, int n, const unsigned *__restrict__ count,
                                                      unsigned *__restrict__ start, unsigned *__restrict__ tot,
                                                      int nblk, const unsigned *__restrict__ blockmax,
                                                      unsigned *__restrict__ hdr)
@@ -680,6 +742,13 @@ __global__ __launch_bounds__(1024) void k_scan_local(int n, const unsigned *__re
     for (int k = 0; k < 4; ++k) c[k] = base + k < n ? count[base + k] : 0u;
     const unsigned sum = c[0] + c[1] + c[2] + c[3];
     part[t] = sum;
+    {   // largest count of a cell (adapt_kcut): one atomicMax per wave that holds cells
+        unsigned mc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mc = base + k < ncells ? max(mc, c[k]) : mc;
+        mc = wave_max_u32(mc);
+        if ((t & 63) == 0 && mc) atomicMax(&hdr[2], mc);
+    }
     __syncthreads();
     if (blockIdx.x == 0 && t < 2) {
         unsigned m = 0;
@@ -701,11 +770,19 @@ __global__ __launch_bounds__(1024) void k_scan_local(int n, const unsigned *__re
     if (t == 1023) tot[blockIdx.x] = part[1023];
 }
 
-__global__ __launch_bounds__(1024) void k_scan_fix(int n, unsigned *__restrict__ start,
-                                                   const unsigned *__restrict__ tot, int nchunks)
+__global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__restrict__ start,
+                                                   const unsigned *__restrict__ tot, int nchunks,
+                                                   const unsigned *__restrict__ count, unsigned *__restrict__ hdr)
 {
     __shared__ unsigned s_off;
     const int t = threadIdx.x;
+    if (blockIdx.x == 0 && t == 64) {   // every block of k_scan_local has raised hdr[2] by now: the cutoff of the windows
+        float tau;
+        unsigned K;
+        hdr[3] = __float_as_uint(adapt_kcut(P, hdr[2], count[P.ncells], tau, K));
+        hdr[4] = __float_as_uint(tau);
+        hdr[5] = K;
+    }
     if (t < 64) {  // one wave sums the totals of the preceding chunks
         unsigned v = 0;
         for (int k = t; k < (int)blockIdx.x; k += 64) v += tot[k];
@@ -747,21 +824,56 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             c[k] = q < P.ncells + 1 + NDEAD ? V.cell_count[q] : 0u;
         }
     }
+    const unsigned nlarge = FUSED_SCAN && P.adapt_cells > 0.f ? V.cell_count[P.ncells] : 0u;
     unsigned key = 0u, rnk = 0u;
     float4 recA = make_float4(0.f, 0.f, 0.f, 0.f), recB = recA, finA = recA, finB = recA;
     uint4 bb = make_uint4(0u, 0u, 0u, 0u), bc = bb;
     uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);   // quadrant-row spans: every column unless computed below
     bool large = false;
+    float sx = 0.f, sy = 0.f, rho = 0.f, x = 0.f, y = 0.f, col0 = 0.f, col1 = 0.f, col2 = 0.f;
     if (valid) {
         key = V.key[i];
         rnk = V.rank[i];
         const size_t i3 = (size_t)i * stride3(P), i2 = (size_t)i * stride2(P);
-        const float sx = sigmas[i3 + 0], sy = sigmas[i3 + 1], rho = sigmas[i3 + 2];
-        const float x = coords[i2 + 0], y = coords[i2 + 1];
+        sx = sigmas[i3 + 0]; sy = sigmas[i3 + 1]; rho = sigmas[i3 + 2];
+        x = coords[i2 + 0]; y = coords[i2 + 1];
+        col0 = colors[i3 + 0]; col1 = colors[i3 + 1]; col2 = colors[i3 + 2];
+    }
+    // The cutoff the windows are built with (adapt_kcut): from the largest cell count -- every block reduces the histogram it
+    // holds anyway (FUSED_SCAN), or reads what the scan kernels left in the header.
+    float kc = P.kcut, kc_tau = 0.f;
+    unsigned kc_K = 0u, kc_mc = 0u;
+    if (FUSED_SCAN) {
+        if (P.adapt_cells > 0.f) {
+            unsigned mc = 0u;
+#pragma unroll
+            for (int k = 0; k < FUSED_PER_THREAD; ++k) mc = (int)threadIdx.x * FUSED_PER_THREAD + k < P.ncells ? max(mc, c[k]) : mc;
+            mc = wave_max_u32(mc);
+            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mc;
+            __syncthreads();
+            mc = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+            __syncthreads();   // (s_part is reused by the scan below)
+            kc = adapt_kcut(P, mc, nlarge, kc_tau, kc_K);
+            kc_mc = mc;
+        } else {
+            kc_tau = 0.5f * P.kcut * P.kcut;
+        }
+    } else {
+        kc = __uint_as_float(V.hdr[3]);
+    }
+    if (valid) {
         const int smp = P.batch > 1 ? i / P.nper : 0;
         const Geo g = sample_geo(P, V, smp);
-        const Box b = gaussian_box(sx, sy, x, y, P, g);
-        large = b.cls == 1;
+        Box b = gaussian_box(sx, sy, x, y, P, g, kc);
+        // A Gaussian k_classify kept (with the conservative cutoff) whose window under the smaller cutoff holds no pixel keeps
+        // its conservative window: every consumer finds a non-empty window behind a live key, and the classes' extents
+        // (header words 0, 1: the conservative ones) cover it.
+        float kw = kc;
+        if (b.cls == 2 && key <= (unsigned)P.ncells && kc != P.kcut) {
+            b = gaussian_box(sx, sy, x, y, P, g, P.kcut);
+            kw = P.kcut;
+        }
+        large = key == (unsigned)P.ncells;
         // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56);
         // everything per-Gaussian is evaluated ONCE here, in double, and rounded to float
         const double dr = rho, dsx = sx, dsy = sy;
@@ -781,7 +893,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         // record layout {x, y, IX, NR | IY, r, g, b}: after the two 16-byte LDS reads of the forward every value it
         // broadcasts into a packed-fp32 operand (y, IY, r, g, b) is the low or high half of an aligned register pair
         recA = make_float4(x, y, IX, NR);
-        recB = make_float4(IY, colors[i3 + 0], colors[i3 + 1], colors[i3 + 2]);
+        recB = make_float4(IY, col0, col1, col2);
         // constants of the backward epilogue (gs.cu:112-117) + the Gaussian's original index
         // backward constants: c = 1/(1-rho^2) = -2 w1, kappa = 1-rho^2 (formed in double: no cancellation), rho, 1/sigma
         finA = make_float4((float)(-2.0 * w1), (float)(1.0 - dr * dr), rho, (float)(1.0 / dsx));
@@ -791,8 +903,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         // does a pixel of a tile this Gaussian is binned to ever need the dmax test?  Not if its support box
         // lies inside its dmax box: pixels beyond the support box carry < exp(-tau) whether tested or not.
         const float hx = 0.5f * (float)(g.w - 1), hy = 0.5f * (float)(g.h - 1);
-        const bool needs_test = P.bounded && !(P.kcut > 0.f && P.kcut * fabsf(sx) * hx + 1.f <= P.dmax * hx &&
-                                               P.kcut * fabsf(sy) * hy + 1.f <= P.dmax * hy);
+        const bool needs_test = P.bounded && !(kw > 0.f && kw * fabsf(sx) * hx + 1.f <= P.dmax * hx &&
+                                               kw * fabsf(sy) * hy + 1.f <= P.dmax * hy);
         if (b.cls == 2) {
             bb = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);  // c0 = r0 = 32767 > c1 = r1 = 0: overlaps no tile
         } else {
@@ -804,17 +916,17 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             // window's corners are empty for every Gaussian (and most of it for a correlated one), so this
             // removes ~30% of the forward's (tile, Gaussian) visits that the rectangular window admits.
             const int ty0 = (b.r0 - P.row0) >> SUBY_SHIFT, ty1 = (b.r1 - P.row0) >> SUBY_SHIFT;
-            if (P.kcut > 0.f && ty1 - ty0 < 8 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
+            if (kw > 0.f && ty1 - ty0 < 8 && (b.c1 >> SUBX_SHIFT) - (b.c0 >> SUBX_SHIFT) <= 255) {
                 // (fp32 relative to the centre: the plan runs one wave per SIMD, so the length of this dependent
                 // chain is k_bin's run time; an ulp of a <= 128 px offset is far inside WINDOW_EPS.  Only the absolute
                 // pixel coordinates stay in double.)
                 const float spx = sx * hx, spy = sy * hy;                     // sigmas in pixels
                 const double cxp = ((double)x + 1.0) * (double)hx, cyp = ((double)y + 1.0) * (double)hy + (double)g.base;
-                const float tau = 0.5f * P.kcut * P.kcut;
+                const float tau = 0.5f * kw * kw;
                 const float omr = (float)(1.0 - dr * dr);
                 const float iq = 1.f / (omr * spx * spy);
                 const float qa = 0.5f * iq * (spy / spx), qb = -rho * iq, qc = 0.5f * iq * (spx / spy);
-                const float umax = fabsf(spx) * P.kcut, vmax = fabsf(spy) * P.kcut;
+                const float umax = fabsf(spx) * kw, vmax = fabsf(spy) * kw;
                 const float vstar = -qb * umax / (2.f * qc);                  // v of the ellipse's rightmost point (= rho spy k)
                 const float disc0 = 4.f * qa * tau, disc2 = 4.f * qa * qc - qb * qb, i2qa = 0.5f / qa;
                 const float eps = (float)WINDOW_EPS;
@@ -917,6 +1029,10 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             if (t == 0) {
                 V.hdr[0] = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
                 V.hdr[1] = max(max(s_part[4], s_part[5]), max(s_part[6], s_part[7]));
+                V.hdr[2] = kc_mc;
+                V.hdr[3] = __float_as_uint(kc);
+                V.hdr[4] = __float_as_uint(kc_tau);
+                V.hdr[5] = kc_K;
             }
         }
     }
@@ -2792,7 +2908,7 @@ __global__ __launch_bounds__(256) void k_band_select(Params P, int band0, int ba
     if (i < P.s) {
         ra = reinterpret_cast<const float4 *>(packed)[2 * (size_t)i];      // sx sy rho x
         rb = reinterpret_cast<const float4 *>(packed)[2 * (size_t)i + 1];  // y r g b
-        const Box b = gaussian_box(ra.x, ra.y, ra.w, rb.x, P, Geo{P.h, P.w, 0, 0});   // P.row0/row1 = whole grid here
+        const Box b = gaussian_box(ra.x, ra.y, ra.w, rb.x, P, Geo{P.h, P.w, 0, 0}, P.kcut);   // P.row0/row1 = whole grid here
         if (b.cls != 2) {
             go_up = rows_above > 0 && b.r0 < band0;
             go_down = rows_below > 0 && b.r1 >= band1;
@@ -2859,6 +2975,22 @@ float gsasr_get_default_cutoff(void) { return default_cutoff(); }
 
 float gsasr_resolve_cutoff(float cutoff, int s) { return resolve_cutoff(cutoff, s); }
 
+int gsasr_plan_cutoff(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, void *stream, float *tau,
+                      unsigned *k_box)
+{
+    Layout L;
+    if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
+    const PlanView V = make_view(L, const_cast<void *>(workspace));
+    unsigned h[HDR_WORDS];
+    HIP_TRY(hipMemcpyAsync(h, V.hdr, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    float t;
+    memcpy(&t, &h[4], 4);
+    if (tau) *tau = t;
+    if (k_box) *k_box = h[5];
+    return GSASR_OK;
+}
+
 size_t gsasr_splat_workspace_bytes(const gsasr_dims *dims)
 {
     if (!dims_ok(dims)) {
@@ -2900,13 +3032,14 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
         hipLaunchKernelGGL(k_bin<true>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);
     } else {
         if (ncls <= 2 * SCAN_CHUNK) {
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start, nblk, V.blockmax,
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P, ncls, V.cell_count, V.cell_start, nblk, V.blockmax,
                                V.hdr);
         } else {
             const int nchunks = (ncls + SCAN_CHUNK - 1) / SCAN_CHUNK;
-            hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_count, V.cell_start,
+            hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, L.ncells, ncls, V.cell_count, V.cell_start,
                                V.scan_tot, nblk, V.blockmax, V.hdr);
-            hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, ncls, V.cell_start, V.scan_tot, nchunks);
+            hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, P, ncls, V.cell_start, V.scan_tot, nchunks,
+                               V.cell_count, V.hdr);
         }
         if (dims->s > 0)
             hipLaunchKernelGGL(k_bin<false>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);

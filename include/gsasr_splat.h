@@ -271,6 +271,16 @@ GSASR_API void gsasr_set_default_cutoff(float tau);
 GSASR_API float gsasr_get_default_cutoff(void);
 GSASR_API float gsasr_resolve_cutoff(float cutoff, int s);
 
+/* The cutoff the windows of the plan in `workspace` were actually built with (synchronises `stream`; for reports and
+ * tests).  For the bounded op under the adaptive default it is DATA-DERIVED: only a Gaussian whose dmax box covers a pixel
+ * contributes to it (gs_cuda_dmax/gs.cu:41-50), so at most K = max over pixels of the number of such Gaussians terms can be
+ * skipped on one pixel and tau' = ln(K / GSASR_SPLAT_DEFAULT_EPS) <= ln(s / eps) keeps the same 1e-5 * max|colour| bound
+ * for any input; K is bounded on the device from the plan's own cell histogram: (largest cell count) x (cells within
+ * dmax of a pixel) + (large class).  *k_box = that K (0 when the cutoff is not data-derived: explicit tau, unbounded op,
+ * GSASR_SPLAT_ADAPT=0). */
+GSASR_API int gsasr_plan_cutoff(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, void *stream,
+                                float *tau, unsigned *k_box);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ def _backward(sig, xy, col, wgt, h, w, dmax, dev, flag, cutoff=0.0, rows=None, c
     gw = _t(wgt if rows is None else wgt[rows[0]:rows[1]], dev)
     if chw:
         gw = gw.permute(2, 0, 1).contiguous()
+        plan.dims = _cabi.Dims.from_buffer_copy(plan.dims)      # (Plan.dims is shared by the plans of a shape: edit a copy)
         plan.dims.flags |= _cabi.FLAG_CHW_GRAD | _cabi.FLAG_OVERWRITE_GRADS
         L = _cabi.lib()
         import ctypes

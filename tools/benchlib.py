@@ -281,6 +281,15 @@ def time_stage(fn, iters, dev):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
+def effective_tau(step, cutoff):
+    """(tau, K) the step's CURRENT plan built its windows with: read back from the plan header (data-derived under the
+    adaptive default of the bounded op: ln(K / 1e-5), K = the plan's bound on the dmax boxes covering one pixel)"""
+    tau, k = step.cabi.plan_cutoff(step.plan)
+    if not tau > 0:
+        return step.cabi.resolve_cutoff(cutoff, step.plan.dims.s), 0
+    return tau, k
+
+
 def window_pairs(sig, xy, H, W, dmax, tau, rows):
     """(Gaussian, pixel) pairs: inside the reference's dmax box (what gs_cuda_dmax sums) and
     inside the window the kernels sweep (box ∩ marginal support |d| <= sigma*sqrt(2 tau)); exact integer
@@ -363,7 +372,7 @@ def exact_runs(args, dev, pixels):
         a.cutoff = tau
         st = Step(a, dev, 0, 1)
         ms = wall_ms(st, 10, dev)
-        tau_eff = st.cabi.resolve_cutoff(tau, st.plan.dims.s)
+        tau_eff, _ = effective_tau(st, tau)
         in_box, swept = window_pairs(st.sig, st.xy, st.H, st.W, st.dmax, tau_eff, st.rows)
         out[name] = {"cutoff_tau": tau, "ms_per_step": ms, "value": pixels / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
                      "pairs_swept_per_direction": swept, "pairs_in_dmax_box": in_box}
@@ -591,7 +600,7 @@ def stage_times(step, dev, iters=30):
 
 def pair_rates(step, kern, cutoff):
     """swept (Gaussian, pixel) pairs of the step's windows and the fraction of the pair-evaluation ceiling each kernel reaches"""
-    tau = step.cabi.resolve_cutoff(cutoff, step.plan.dims.s)
+    tau, _ = effective_tau(step, cutoff)
     in_box, swept = window_pairs(step.sig, step.xy, step.H, step.W, step.dmax, tau, step.rows)
     frac = {k: swept / (kern[k]["avg_ms"] * 1e-3) / PAIR_CEILING[k]["pairs_per_s"] for k in kern if k in PAIR_CEILING}
     return in_box, swept, frac
@@ -612,6 +621,7 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     kern = stage_times(st, dev, iters=10 if st.H * st.W > 4e7 else 20)
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
     in_box, swept, vfrac = pair_rates(st, kern, a.cutoff)
+    tau_eff, k_box = effective_tau(st, a.cutoff)
     h_lr, w_lr, scale, desc = CONFIGS[config]
     traffic = None
     try:   # HBM bytes per launch of the dominant stage's kernels, replayed from the committed counter passes of this config
@@ -621,7 +631,9 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     except (OSError, ValueError):
         traffic = None
     out = {"workload": desc, "H": st.H, "W": st.W, "gaussians": st.n, "dmax": st.dmax if st.dmax is not None else -1,
-           "cutoff_tau": round(st.cabi.resolve_cutoff(a.cutoff, st.plan.dims.s), 3), "what": "fwd only" if st.fwd_only else "fwd+bwd",
+           "cutoff_tau": round(tau_eff, 3), "cutoff_k_box": k_box,
+           "cutoff_tau_conservative": round(st.cabi.resolve_cutoff(a.cutoff, st.plan.dims.s), 3),
+           "what": "fwd only" if st.fwd_only else "fwd+bwd",
            "steps": n, "ms_per_step": ms, "value": st.H * st.W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
            "kernels": kern,
            "roofline": {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],

@@ -95,7 +95,12 @@ int main(int argc, char **argv)
     CK(hipStreamCreate(&st));
     auto chk = [](int rc, const char *w) { if (rc) { fprintf(stderr, "%s: %d %s\n", w, rc, gsasr_last_error()); exit(1); } };
     chk(gsasr_splat_plan(dsig, dxy, dcol, &d, ws, wsb, st), "plan");
-    const float t_plan = time_us([&] { chk(gsasr_splat_plan(dsig, dxy, dcol, &d, ws, wsb, st), "plan"); }, iters, st);
+    // (as bench.py and the Python pool plan: the workspace persists, every plan zeroes the other parity's counters on the side)
+    int nplans = 1;
+    const float t_plan = time_us([&] {
+        gsasr_dims dp = d;
+        dp.flags |= GSASR_FLAG_COUNTERS_CLEAN | ((++nplans & 1) ? 0u : GSASR_FLAG_PARITY);
+        chk(gsasr_splat_plan(dsig, dxy, dcol, &dp, ws, wsb, st), "plan"); }, iters, st);
     const float t_fwd = time_us([&] { chk(gsasr_splat_forward(&d, ws, wsb, dimg, st), "fwd"); }, iters, st);
     const float t_bwd = time_us([&] { chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d, ws, wsb, st), "bwd"); }, iters, st);
     CK(hipStreamSynchronize(st));
@@ -111,9 +116,11 @@ int main(int argc, char **argv)
     double si = 0, sg = 0;
     for (float v : img) si += v;
     for (float v : gs) sg += fabs(v);
-    unsigned hdr[4];
-    CK(hipMemcpy(hdr, ws, 16, hipMemcpyDeviceToHost));
-    printf("N=%d %dx%d dmax=%g tau=%g | plan %.1f us  fwd %.1f us  bwd %.1f us | sum(img)=%.6e sum|gs|=%.6e | rx=%u ry=%u\n", n, H, W,
-           dmax, tau, t_plan, t_fwd, t_bwd, si, sg, hdr[0], hdr[1]);
+    unsigned hdr[8];
+    CK(hipMemcpy(hdr, ws, 32, hipMemcpyDeviceToHost));
+    float tau_w;
+    memcpy(&tau_w, &hdr[4], 4);
+    printf("N=%d %dx%d dmax=%g tau=%g | plan %.1f us  fwd %.1f us  bwd %.1f us | sum(img)=%.6e sum|gs|=%.6e | rx=%u ry=%u maxcell=%u tau'=%.3f K=%u\n", n, H, W,
+           dmax, tau, t_plan, t_fwd, t_bwd, si, sg, hdr[0], hdr[1], hdr[2], tau_w, hdr[5]);
     return 0;
 }
