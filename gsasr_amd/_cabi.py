@@ -26,7 +26,7 @@ EXPORTS = (
     "gsasr_band_select", "gsasr_band_merge", "gsasr_resolve_cutoff",
     "gsasr_sample_workspace_bytes", "gsasr_splat_sample_forward", "gsasr_splat_sample_backward",
     "gsasr_step_sample_forward", "gsasr_step_sample_backward",
-    "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm", "gsasr_plan_cutoff",
+    "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm", "gsasr_plan_cutoff", "gsasr_release_launcher_scratch",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -223,8 +223,11 @@ _POOL = _WorkspacePool()
 
 def clear_workspace_pool() -> None:
     """Drop the pooled plan workspaces (up to `_WorkspacePool.MAX_BYTES` of device memory that `torch.cuda.empty_cache()`
-    cannot see as free while the pool holds it): call it next to `empty_cache()` when memory is tight."""
+    cannot see as free while the pool holds it): call it next to `empty_cache()` when memory is tight.  Also frees the
+    scratch the reference-shaped C launchers (module `gscuda`) keep per stream."""
     _POOL.clear()
+    if _lib is not None:
+        _lib.gsasr_release_launcher_scratch()
 
 
 @dataclass

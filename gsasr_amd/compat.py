@@ -44,7 +44,6 @@ def install(also_gaussian_splatting: bool = False) -> None:
     from .gs_cuda import gswrapper as unbounded
     from .gs_cuda_dmax import gswrapper as bounded
 
-    sys.modules["gscuda"] = gscuda
     # 1. The LEAF names first, before any parent package is imported: importing the real `basicsr` runs
     #    `from .models import *`, which imports gsasr_model.py, which does `from basicsr.utils.gaussian_splatting import
     #    generate_2D_gaussian_splatting_step` -- the import machinery imports the parents and then finds the leaf already
@@ -58,11 +57,27 @@ def install(also_gaussian_splatting: bool = False) -> None:
             from . import gaussian_splatting, split_and_joint_image
             leaves[f"{root}.gaussian_splatting"] = gaussian_splatting
             leaves[f"{root}.split_and_joint_image"] = split_and_joint_image
+    before = {k: sys.modules.get(k) for k in ("gscuda", *leaves)}
+    known = set(sys.modules)
+    sys.modules["gscuda"] = gscuda
     sys.modules.update(leaves)
-    # 2. The parents: the real packages where they exist, and the leaves attached to them as attributes
-    for name, mod in leaves.items():
-        parts = name.split(".")
-        for k in range(1, len(parts)):
-            _parent(".".join(parts[:k]))
-        setattr(sys.modules[".".join(parts[:-1])], parts[-1], mod)
-        sys.modules[name] = mod       # (a parent's own __init__ may have imported and re-registered its leaf meanwhile)
+    # 2. The parents: the real packages where they exist, and the leaves attached to them as attributes.  If a parent
+    #    that exists fails to import (a missing dependency inside basicsr.utils, say) nothing of this call stays behind: a
+    #    caller that catches the error must not be left with this package's leaves under half-imported parents.
+    try:
+        for name, mod in leaves.items():
+            parts = name.split(".")
+            for k in range(1, len(parts)):
+                _parent(".".join(parts[:k]))
+            setattr(sys.modules[".".join(parts[:-1])], parts[-1], mod)
+            sys.modules[name] = mod       # (a parent's own __init__ may have imported and re-registered its leaf meanwhile)
+    except BaseException:
+        for k, v in before.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        roots = ("utils", "basicsr")
+        for k in [k for k in sys.modules if k not in known and (k in roots or k.startswith(tuple(r + "." for r in roots)))]:
+            sys.modules.pop(k, None)      # stand-ins and partly imported parents this call brought in
+        raise

@@ -375,30 +375,38 @@ Params make_params(const gsasr_dims *d, const Layout &L)
 // spans the plan never wrote.  The plan therefore leaves a note {workspace -> slots per Gaussian} here and every later
 // call on that workspace lays it out from the note (a small direct-mapped table: a lost note only means the old
 // behaviour, trusting the caller's flags).
-struct PlanNote {
-    const void *ws;
-    int part_k;
-};
+// One 64-bit word per note, written and read atomically (no lock on the plan / forward / backward path): the workspace
+// address (256-byte aligned: bits 8..47), a 16-bit hash of the shape the plan was made for, and the slot count.  A note
+// whose shape hash differs from the caller's dims -- a freed workspace address reused for another shape without a new plan,
+// a note overwritten by a colliding workspace -- is ignored.
 constexpr int NOTES = 1024;
-PlanNote g_notes[NOTES];
-std::mutex g_notes_mu;
+std::atomic<unsigned long long> g_notes[NOTES];
 
 unsigned note_slot(const void *ws) { return (unsigned)(((uintptr_t)ws >> 8) * 2654435761u >> 22) & (NOTES - 1); }
 
-void note_plan(const void *ws, int part_k)
+unsigned long long note_shape(const gsasr_dims *d)
 {
-    std::lock_guard<std::mutex> lk(g_notes_mu);
-    g_notes[note_slot(ws)] = PlanNote{ws, part_k};
+    unsigned long long x = (unsigned long long)(unsigned)d->s * 0x9E3779B97F4A7C15ull;
+    x ^= ((unsigned long long)(unsigned)d->h << 32 | (unsigned)d->w) * 0xC2B2AE3D27D4EB4Full;
+    x ^= (unsigned long long)(unsigned)batch_of(d) * 0x27D4EB2F165667C5ull;
+    return (x >> 40) & 0xffffull;
+}
+
+void note_plan(const void *ws, const gsasr_dims *d, int part_k)
+{
+    const unsigned long long w = ((unsigned long long)(uintptr_t)ws & 0x0000ffffffffff00ull) << 16 | note_shape(d) << 8 |
+                                 (unsigned long long)(part_k & 0xff);
+    g_notes[note_slot(ws)].store(w, std::memory_order_relaxed);
 }
 
 // layout of the plan in `ws`: from the note its plan left, else from these dims
 Layout plan_layout(const gsasr_dims *d, const void *ws)
 {
     int part_k = -1;
-    {
-        std::lock_guard<std::mutex> lk(g_notes_mu);
-        const PlanNote &n = g_notes[note_slot(ws)];
-        if (n.ws == ws && ws) part_k = n.part_k;
+    if (ws) {
+        const unsigned long long w = g_notes[note_slot(ws)].load(std::memory_order_relaxed);
+        const unsigned long long key = ((unsigned long long)(uintptr_t)ws & 0x0000ffffffffff00ull) << 16 | note_shape(d) << 8;
+        if ((w & ~0xffull) == key) part_k = (int)(w & 0xffull);
     }
     return make_layout(d, part_k);
 }
@@ -3010,7 +3018,7 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
 {
     Layout L;
     if (int rc = check_ws(dims, workspace, workspace_bytes, L, true)) return rc;
-    note_plan(workspace, L.part_k);
+    note_plan(workspace, dims, L.part_k);
     if (dims->s > 0 && (!sigmas || !coords || !colors)) return fail(GSASR_ERR_ARG, "null input pointer");
     hipStream_t st = (hipStream_t)stream;
     const Params P = make_params(dims, L);
@@ -3594,6 +3602,88 @@ int gsasr_band_merge(float *g_packed, int s, const float *g_up, const float *g_d
 }
 
 // ---- reference-shaped launchers -------------------------------------------------------------------
+// Scratch of the reference-shaped launchers below.  The reference's gs.h launchers take no workspace, so these keep one
+// per (device, stream) between calls -- stream-ordered reuse, exactly like the caching allocator behind the reference's
+// own torch.zeros -- instead of a hipMallocAsync / hipFreeAsync pair per call; a workspace that is planned again for the
+// same shape also skips the memset of its cell counters (GSASR_FLAG_COUNTERS_CLEAN / _PARITY: every plan zeroes the other
+// parity's counters on the side).  gsasr_release_launcher_scratch() frees them.
+struct LauncherScratch {
+    int dev;
+    hipStream_t st;
+    void *ptr;
+    size_t bytes;
+    int s, h, w;          // shape of the last plan made in it (the counters' layout)
+    unsigned plans;       // plans made for that shape so far
+    unsigned long long used;
+};
+constexpr int LAUNCHER_SLOTS = 8;
+static LauncherScratch g_scratch[LAUNCHER_SLOTS];
+static std::mutex g_scratch_mu;
+static unsigned long long g_scratch_clock = 0;
+
+static int launcher_scratch(const gsasr_dims &d, size_t bytes, hipStream_t st, void **ws, unsigned *flags)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    LauncherScratch *e = nullptr;
+    for (LauncherScratch &c : g_scratch)
+        if (c.ptr && c.dev == dev && c.st == st) { e = &c; break; }
+    if (!e) {   // a free slot, else the least recently used one
+        for (LauncherScratch &c : g_scratch)
+            if (!c.ptr) { e = &c; break; }
+        if (!e) {
+            e = &g_scratch[0];
+            for (LauncherScratch &c : g_scratch)
+                if (c.used < e->used) e = &c;
+        }
+        if (e->ptr) {   // evict: freed in the order of ITS stream
+            int cur = dev;
+            if (e->dev != cur) HIP_TRY(hipSetDevice(e->dev));
+            hipError_t fe = hipFreeAsync(e->ptr, e->st);
+            if (e->dev != cur) HIP_TRY(hipSetDevice(cur));
+            if (fe != hipSuccess) return hip_fail(fe, "hipFreeAsync");
+        }
+        *e = LauncherScratch{dev, st, nullptr, 0, 0, 0, 0, 0u, 0ull};
+    }
+    if (e->bytes < bytes) {
+        if (e->ptr) HIP_TRY(hipFreeAsync(e->ptr, st));
+        e->ptr = nullptr;
+        e->bytes = 0;
+        void *p = nullptr;
+        HIP_TRY(hipMallocAsync(&p, bytes, st));
+        e->ptr = p;
+        e->bytes = bytes;
+        e->plans = 0;
+    }
+    if (e->s != d.s || e->h != d.h || e->w != d.w) {
+        e->s = d.s; e->h = d.h; e->w = d.w;
+        e->plans = 0;
+    }
+    *flags = e->plans == 0 ? 0u : (GSASR_FLAG_COUNTERS_CLEAN | ((e->plans & 1u) ? GSASR_FLAG_PARITY : 0u));
+    ++e->plans;
+    e->used = ++g_scratch_clock;
+    *ws = e->ptr;
+    return GSASR_OK;
+}
+
+int gsasr_release_launcher_scratch(void)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    int rc = GSASR_OK;
+    for (LauncherScratch &c : g_scratch) {
+        if (!c.ptr) continue;
+        if (c.dev != cur) (void)hipSetDevice(c.dev);
+        hipError_t e = hipFreeAsync(c.ptr, c.st);
+        if (c.dev != cur) (void)hipSetDevice(cur);
+        if (e != hipSuccess) rc = hip_fail(e, "hipFreeAsync");
+        c = LauncherScratch{};
+    }
+    return rc;
+}
+
 static int render_common(const float *sigmas, const float *coords, const float *colors, float *img,
                          const float *grads, float *gs, float *gc, float *gk, int s, int h, int w, int c,
                          float dmax, bool backward, void *stream)
@@ -3604,8 +3694,11 @@ static int render_common(const float *sigmas, const float *coords, const float *
     if (!bytes) return GSASR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     void *ws = nullptr;
-    HIP_TRY(hipMallocAsync(&ws, bytes, st));
+    unsigned counter_flags = 0u;
+    if (int rc = launcher_scratch(d, bytes, st, &ws, &counter_flags)) return rc;
+    d.flags = counter_flags;
     int rc = gsasr_splat_plan(sigmas, coords, colors, &d, ws, bytes, stream);
+    d.flags = 0;
     if (rc == GSASR_OK) {
         if (!backward) {
             rc = gsasr_splat_forward(&d, ws, bytes, img, stream);
@@ -3614,8 +3707,6 @@ static int render_common(const float *sigmas, const float *coords, const float *
             rc = gsasr_splat_backward(sigmas, coords, colors, grads, gs, gc, gk, &d, ws, bytes, stream);
         }
     }
-    hipError_t e = hipFreeAsync(ws, st);
-    if (rc == GSASR_OK && e != hipSuccess) return hip_fail(e, "hipFreeAsync");
     return rc;
 }
 

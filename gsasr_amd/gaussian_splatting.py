@@ -282,8 +282,9 @@ def _fused_render(gs_parameters, sr_size, step_size, dmax):
     H, W = _hw(sr_size)
     dm = None if dmax is None else float(dmax)
     if step_size.__class__ is _StepSource:
-        deferred_asserts.watch(gs_parameters.device)
-        return _FusedStep.apply(gs_parameters.contiguous(), None, H, W, dm, step_size.scale_modify, step_size.default_step)
+        out = _FusedStep.apply(gs_parameters.contiguous(), None, H, W, dm, step_size.scale_modify, step_size.default_step)
+        deferred_asserts.watch(gs_parameters.device)      # (after the launch: a look covers this call's own pair)
+        return out
     step = _step_tensor(step_size, gs_parameters.device)
     return _FusedStep.apply(gs_parameters.contiguous(), step, H, W, dm)
 
@@ -369,9 +370,13 @@ class _DeferredAsserts:
     * other CUDA-tensor callers (`add()`): the comparison runs on the device, its result and the two values go to
       pinned memory without blocking, and are examined at a LATER call of the API, once the copy has landed.
 
-    Either way: the same AssertionError (with the offending values), at most a few calls late, and no pipeline drain;
-    `flush()` -- also registered with `atexit` -- waits for everything outstanding.  Python numbers and CPU tensors are
-    checked on the spot, exactly as in the reference."""
+    Either way: the same AssertionError (with the offending values) and no pipeline drain -- but LATE: `add()` a few calls
+    late; the fused path after the 1st, 2nd, 4th, 8th ... fused call on a device and then every `WATCH_EVERY` calls (a wrong
+    pair is almost always wrong from the first call on, so the early looks catch it where the reference would), and the
+    image of the offending call has been rendered with `scale_modify[0]` by then.  `flush()` waits for everything
+    outstanding and raises; it is also registered with `atexit`, where an exception cannot propagate: the failure is printed
+    and the process exits with status 1 instead of 0 (`os._exit`), so a short script with a mismatched pair cannot end
+    "successfully".  Python numbers and CPU tensors are checked on the spot, exactly as in the reference."""
 
     RING = 256          # pinned result slots, reused round robin (allocating pinned memory per call costs more than the check)
     WATCH_EVERY = 64
@@ -381,6 +386,7 @@ class _DeferredAsserts:
         self.ring = None
         self.next = 0
         self.watched = {}       # device -> calls since the last look at its mismatch word
+        self.seen = {}          # device -> fused calls so far (the first looks come at calls 1, 2, 4, 8, ...)
 
     def _slot(self):
         if self.ring is None:
@@ -404,7 +410,10 @@ class _DeferredAsserts:
     def watch(self, dev, force: bool = False) -> None:
         """count a fused call on `dev`; every WATCH_EVERY-th one (or `force`) fetches the device's mismatch word"""
         n = self.watched.get(dev, 0) + 1
-        if n < self.WATCH_EVERY and not force:
+        total = self.seen.get(dev, 0) + 1
+        self.seen[dev] = total
+        early = total <= self.WATCH_EVERY and (total & (total - 1)) == 0      # calls 1, 2, 4, ..., WATCH_EVERY
+        if n < self.WATCH_EVERY and not force and not early:
             self.watched[dev] = n
             return
         self.watched[dev] = 0
@@ -452,9 +461,13 @@ deferred_asserts = _DeferredAsserts()
 def _flush_at_exit():
     try:
         deferred_asserts.flush()
-    except AssertionError as e:      # (an exception in an atexit hook is printed, not raised: say it plainly)
+    except AssertionError as e:      # (an exception in an atexit hook is printed, not raised: say it plainly, and fail the process)
+        import os
         import sys
         print(f"gsasr_amd: deferred check failed at exit: {e}", file=sys.stderr)
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)
     except Exception:
         pass
 
@@ -535,9 +548,10 @@ def generate_2D_gaussian_splatting_step(sr_size, gs_parameters, scale, scale_mod
         if pts is not None and 0 < pts.shape[0] <= SAMPLED_MAX_FRACTION * H * W:
             dm = None if dmax_eff is None else float(dmax_eff)
             if step_size.__class__ is _StepSource:
+                out = _FusedStepSampled.apply(gs_parameters.contiguous(), None, H, W, dm, pts, step_size.scale_modify,
+                                              step_size.default_step)
                 deferred_asserts.watch(gs_parameters.device)
-                return _FusedStepSampled.apply(gs_parameters.contiguous(), None, H, W, dm, pts, step_size.scale_modify,
-                                               step_size.default_step)
+                return out
             return _FusedStepSampled.apply(gs_parameters.contiguous(), _step_tensor(step_size, gs_parameters.device), H, W, dm, pts)
         return _sample(_fused_render(gs_parameters, (H, W), step_size, dmax_eff), sample_coords)
     sigma_x, sigma_y, rho, coords, colours_with_alpha = _activate(gs_parameters)
@@ -664,13 +678,17 @@ def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_
             # scale_modify pairs that are already on the device go to the plan's first kernel as they are (one [B,2]
             # tensor: no kernel at all; a list of [2] tensors: one torch.stack): no division, comparison or copy here
             sm = None
-            if torch.is_tensor(scale_modifies) and scale_modifies.dim() == 2 and _sm_source_ok(scale_modifies[0]):
+            # (a [B,2] tensor is read in place as rows of stride >= 2 on the Gaussians' device: an `.expand(B, 2)` view --
+            # row stride 0 -- or a tensor on another GPU takes the evaluated path below)
+            if torch.is_tensor(scale_modifies) and scale_modifies.dim() == 2 and _sm_source_ok(scale_modifies[0]) \
+                    and scale_modifies.stride(0) >= 2 and scale_modifies.device == dev:
                 sm = scale_modifies
-            elif not torch.is_tensor(scale_modifies) and all(_sm_source_ok(v) for v in scale_modifies):
+            elif not torch.is_tensor(scale_modifies) and all(_sm_source_ok(v) and v.device == dev for v in scale_modifies):
                 sm = torch.stack([v[:2] for v in scale_modifies])
             if sm is not None:
+                out = _FusedBatch.apply(gs_parameters.contiguous(), None, tuple(sizes), dm, sm, float(default_step_size))
                 deferred_asserts.watch(dev)
-                return _FusedBatch.apply(gs_parameters.contiguous(), None, tuple(sizes), dm, sm, float(default_step_size))
+                return out
         steps = _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev)
         if sample_coords is None:
             return _FusedBatch.apply(gs_parameters.contiguous(), steps, tuple(sizes), dm)

@@ -231,7 +231,12 @@ GSASR_API int gsasr_step_sample_backward(const float *gs_parameters, const float
                                float *g_parameters, const gsasr_dims *dims, void *workspace, size_t workspace_bytes,
                                const int *points, int n_points, void *sample_ws, size_t sample_ws_bytes, void *stream);
 
-/* Reference-shaped launchers (allocate their scratch stream-ordered, plan, run, free). */
+/* Reference-shaped launchers: the argument lists of `_gs_render` / `_gs_render_backward` in utils/gs_cuda/gs.h:4-24 and
+ * utils/gs_cuda_dmax/gs.h:4-26 (+ the stream, + a status instead of void).  The reference's launchers take no workspace,
+ * so these keep their plan scratch per (device, stream) between calls (allocated stream-ordered on first use, reused in
+ * stream order, re-planned on every call -- a backward never trusts the plan of an earlier forward: the arrays may have
+ * changed); gsasr_release_launcher_scratch() frees what they hold. */
+GSASR_API int gsasr_release_launcher_scratch(void);
 GSASR_API int gsasr_gs_render(const float *sigmas, const float *coords, const float *colors,
                     float *rendered_img, int s, int h, int w, int c, void *stream);
 GSASR_API int gsasr_gs_render_backward(const float *sigmas, const float *coords, const float *colors,

@@ -225,3 +225,12 @@ def test_compat_install_rebinds_models_that_import_at_package_import(tmp_path):
              % (ROOT, str(tmp_path)))
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+    # ... and nothing of the failed install() stays behind: no rasterizer leaf of this package under the
+    # reference's names, no partly imported parent, `gscuda` not registered
+    code3 = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "from gsasr_amd import compat\n"
+             "try:\n    compat.install(also_gaussian_splatting=True)\nexcept ModuleNotFoundError:\n    pass\n"
+             "left = [k for k in sys.modules if k == 'gscuda' or k.startswith(('basicsr', 'utils'))]\n"
+             "assert not left, left\nprint('ok')\n" % (ROOT, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

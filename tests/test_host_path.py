@@ -246,3 +246,85 @@ def test_grad_rows_is_validated(dev):
     z = torch.zeros(10, 3, device=dev)
     rc = _cabi.lib().gsasr_splat_plan(z.data_ptr(), z.data_ptr(), z.data_ptr(), ctypes.byref(one), ws.data_ptr(), ws.numel(), _cabi._stream(dev))
     assert rc == -1
+
+
+def test_expanded_and_foreign_scale_modifies_take_the_evaluated_path(dev):
+    """a `[B,2]` scale_modifies made by `.expand(B, 2)` has row stride 0: it must not reach the fused entry
+    point as a pointer (the C check `stride >= 2` would refuse it) but render through the evaluated step sizes, with the
+    same result as a contiguous copy."""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    B, H, W = 3, 64, 48
+    pb = torch.stack([synthetic.gs_parameters(16, 12, seed=5 + i) for i in range(B)]).to(dev)
+    sm_row = torch.tensor([4.0, 4.0], device=dev)
+    expanded = sm_row.expand(B, 2)
+    assert expanded.stride(0) == 0
+    a = gsp.generate_2D_gaussian_splatting_batch([(H, W)] * B, pb, [4.0] * B, expanded, dmax=0.3)
+    b = gsp.generate_2D_gaussian_splatting_batch([(H, W)] * B, pb, [4.0] * B, expanded.contiguous(), dmax=0.3)
+    gsp.deferred_asserts.flush()
+    assert float((a - b).abs().max()) <= 2e-6
+
+
+def test_scale_modify_mismatch_surfaces_on_an_early_call(dev):
+    """the sticky word of the fused path is looked at after the 1st, 2nd, 4th ... fused call on a device, not only
+    every WATCH_EVERY calls: a pair that is wrong from the start fails within a handful of calls."""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    gsp.deferred_asserts.flush()
+    gsp.deferred_asserts.seen.pop(dev, None)
+    gsp.deferred_asserts.watched.pop(dev, None)
+    p = synthetic.gs_parameters(8, 8, seed=1).to(dev)
+    bad = torch.tensor([2.0, 3.0], device=dev)
+    with pytest.raises(AssertionError, match="scale_modify is not the same"):
+        for _ in range(5):
+            gsp.generate_2D_gaussian_splatting_step((32, 32), p, 4.0, bad, dmax=0.3)
+            torch.cuda.synchronize()
+    gsp.deferred_asserts.flush()
+
+
+def test_mismatch_left_pending_at_exit_fails_the_process(dev):
+    """a short script with a mismatched pair and no flush() must not exit with status 0"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from gsasr_amd import gaussian_splatting as gsp, synthetic\n"
+            "gsp._DeferredAsserts.WATCH_EVERY = 1 << 30\n"
+            "d = torch.device('cuda:0')\n"
+            "p = synthetic.gs_parameters(8, 8, seed=1).to(d)\n"
+            "ok, bad = torch.tensor([4.0, 4.0], device=d), torch.tensor([2.0, 3.0], device=d)\n"
+            "gsp.generate_2D_gaussian_splatting_step((32, 32), p, 4.0, ok, dmax=0.3)\n"
+            "gsp.generate_2D_gaussian_splatting_step((32, 32), p, 4.0, ok, dmax=0.3)\n"
+            "gsp.generate_2D_gaussian_splatting_step((32, 32), p, 4.0, bad, dmax=0.3)\n"      # third call: not an early look
+            "torch.cuda.synchronize(); print('rendered')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "rendered" in r.stdout
+    assert r.returncode == 1 and "deferred check failed at exit" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def test_reference_shaped_launchers_reuse_their_scratch(dev):
+    """module `gscuda` (the pybind surface, gswrapper.cpp:9-73 -> gsasr_gs_render*) keeps its plan
+    scratch per stream between calls; alternating shapes, repeated calls and a release in between all give the oracle's
+    numbers (the counters-clean / parity bookkeeping of a reused workspace must survive a shape change)."""
+    import numpy as np
+    from gsasr_amd import _cabi, gscuda, synthetic
+    from oracle import gs_oracle
+    cases = []
+    for (hl, wl, sc, seed) in ((12, 10, 4.0, 1), (20, 16, 3.0, 2)):
+        sig, xy, col, H, W = synthetic.kernel_inputs(hl, wl, sc, seed=seed)
+        ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, 0.3)
+        wgt = synthetic.grad_image(H, W, seed)
+        gref = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), 0.3)
+        cases.append((sig.to(dev), xy.to(dev), col.to(dev), H, W, ref, wgt.to(dev), gref))
+    for rep in range(6):
+        sig, xy, col, H, W, ref, wgt, gref = cases[rep % 2 if rep < 4 else 0]
+        img = torch.zeros(H, W, 3, device=dev)
+        gscuda.gs_render(sig, xy, col, img, sig.shape[0], H, W, 3, 0.3)
+        g = [torch.zeros_like(t) for t in (sig, xy, col)]
+        gscuda.gs_render_backward(sig, xy, col, wgt, *g, sig.shape[0], H, W, 3, 0.3)
+        torch.cuda.synchronize()
+        assert np.abs(img.cpu().numpy() - ref).max() <= 1e-4
+        for got, want in zip(g, gref):
+            assert np.abs(got.cpu().numpy() - want).max() <= 2e-4 * np.abs(want).max()
+        if rep == 3:
+            _cabi.clear_workspace_pool()      # frees the launchers' scratch as well: the next call allocates again
