@@ -87,8 +87,10 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #endif
 constexpr int BWD_WAVES = BWD_WAVES_N;  // waves (= consecutive cell-ordered Gaussians) per backward workgroup
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
+constexpr int FUSED_CELLS_HOST = 256 * 17;   // = FUSED_CELLS (k_bin<true>): grids up to this many classes never run a scan kernel
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y, [2]=largest cell count,
-                                //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut)
+                                //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut),
+                                //   [6]=largest count of a 4 x 4 block of cells (k_block_max)
 constexpr double LOG2E = 1.4426950408889634074;
 
 struct Params {
@@ -98,6 +100,8 @@ struct Params {
     float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled (the CONSERVATIVE tau: classes, dead set)
     float adapt_cells;  // > 0: the windows are built with the data-derived cutoff tau' = ln(K / eps) <= tau, K = the most Gaussians
                      // whose dmax box can cover one pixel <= (largest cell count) * adapt_cells + (large class); 0: kcut everywhere
+    float adapt_cells4; // > 0: the same bound counted in blocks of 4 x 4 cells (k_block_max; sparse cells on large grids): K is
+                     // the smaller of the two
     int ncx, ncy, ncells;
     unsigned flags;  // GSASR_FLAG_*
     int batch;       // 1: one image.  B > 1: B samples stacked in a canvas of B slots (h = B*slot rows, w columns)
@@ -350,13 +354,19 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.kcut = tau > 0.f ? (float)(std::sqrt(2.0 * (double)tau) * (1.0 + 1e-6)) : 0.f;
     // data-derived cutoff (adapt_kcut): the bounded op under the adaptive default only -- an explicit tau (per call, per
     // process, environment) is used as given, and the unbounded op has no box to count in
-    P.adapt_cells = 0.f;
+    P.adapt_cells = P.adapt_cells4 = 0.f;
     if (P.bounded && d->cutoff == 0.f && default_cutoff() == 0.f && P.kcut > 0.f && adapt_env()) {
         const int B = batch_of(d);
         const double dpx = (double)d->dmax * 0.5 * (double)(d->w - 1), dpy = (double)d->dmax * 0.5 * (double)((B > 1 ? d->slot : d->h) - 1);
         const double cx = std::ceil(2.0 * std::floor(dpx + 1.02) / (double)CELL) + 1.0, cy = std::ceil(2.0 * std::floor(dpy + 1.02) / (double)CELL) + 1.0;
         const double cells = std::fmin(cx, (double)L.ncx) * std::fmin(cy, (double)L.ncy);
         P.adapt_cells = (float)std::fmin(cells, 1.0e9) * (1.f + 1e-6f);
+        // Sparse cells (fewer than 8 Gaussians per cell on average: x8 and up) on a grid with a scan pass of its own: the
+        // largest single cell is several times the mean there, the largest 64 x 64-px block is not -- count in blocks too
+        if ((double)d->s < 8.0 * (double)L.ncells && L.ncells + 1 + NDEAD > FUSED_CELLS_HOST) {
+            const double bx = std::ceil(2.0 * std::floor(dpx + 1.02) / (4.0 * CELL)) + 1.0, by = std::ceil(2.0 * std::floor(dpy + 1.02) / (4.0 * CELL)) + 1.0;
+            P.adapt_cells4 = (float)std::fmin(std::fmin(bx, std::ceil(L.ncx / 4.0)) * std::fmin(by, std::ceil(L.ncy / 4.0)), 1.0e9) * (1.f + 1e-6f);
+        }
     }
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
     P.flags = d->flags;
@@ -495,11 +505,14 @@ __device__ __forceinline__ float wave_sum(float v)
 //     K <= (largest cell count) * Cx * Cy + (size of the large class)                        [adapt_cells = Cx * Cy]
 // (Gaussians stacked on one spot make the largest count ~s and tau' = tau: nothing is lost on adversarial input.)
 // The log is the hardware's (1 ulp): 1e-3 is added to tau', a factor 1.001 on the side of the bound.
-__device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, unsigned nlarge, float &tau, unsigned &K)
+__device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, unsigned nlarge, float &tau, unsigned &K,
+                                            unsigned maxblock = 0u)
 {
     const float tau_cap = 0.5f * P.kcut * P.kcut;
     if (!(P.adapt_cells > 0.f)) { tau = tau_cap; K = 0u; return P.kcut; }
-    const float Kf = fmaxf((float)maxcount * P.adapt_cells + (float)nlarge, 1.f);
+    float Kn = (float)maxcount * P.adapt_cells;
+    if (P.adapt_cells4 > 0.f) Kn = fminf(Kn, (float)maxblock * P.adapt_cells4);   // the same pixels' boxes, counted in 4 x 4-cell blocks
+    const float Kf = fmaxf(Kn + (float)nlarge, 1.f);
     K = (unsigned)fminf(Kf, 4.0e9f);
     const float t = fmaxf(__log2f(Kf * (1.f / GSASR_SPLAT_DEFAULT_EPS)) * 0.69314718f + 1e-3f, 16.f);
     if (!(t < tau_cap)) { tau = tau_cap; return P.kcut; }
@@ -574,7 +587,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int lane = threadIdx.x & 63;
     // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
     for (int k = i; k < P.ncells + 1 + NDEAD; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
-    if (i == 0) V.hdr[2] = 0u;   // largest cell count: the blocks of k_scan_local raise it with atomicMax
+    if (i == 0) V.hdr[2] = V.hdr[6] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / k_block_max
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
@@ -699,13 +712,6 @@ __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *
         unsigned m = 0;
         for (int k = 0; k < 16; ++k) m = max(m, smax[t][k]);
         hdr[t] = m;
-        if (t == 2) {
-            float tau;
-            unsigned K;
-            hdr[3] = __float_as_uint(adapt_kcut(P, m, count[P.ncells], tau, K));
-            hdr[4] = __float_as_uint(tau);
-            hdr[5] = K;
-        }
     }
     for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partials
         unsigned v = t >= o ? part[t - o] : 0u;
@@ -784,13 +790,7 @@ __global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__
 {
     __shared__ unsigned s_off;
     const int t = threadIdx.x;
-    if (blockIdx.x == 0 && t == 64) {   // every block of k_scan_local has raised hdr[2] by now: the cutoff of the windows
-        float tau;
-        unsigned K;
-        hdr[3] = __float_as_uint(adapt_kcut(P, hdr[2], count[P.ncells], tau, K));
-        hdr[4] = __float_as_uint(tau);
-        hdr[5] = K;
-    }
+    (void)P; (void)count; (void)hdr;
     if (t < 64) {  // one wave sums the totals of the preceding chunks
         unsigned v = 0;
         for (int k = t; k < (int)blockIdx.x; k += 64) v += tot[k];
@@ -806,11 +806,28 @@ __global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__
     if ((int)blockIdx.x == nchunks - 1 && t == 0) start[n] = off + tot[blockIdx.x];
 }
 
+// Largest number of Gaussians binned in one aligned block of 4 x 4 cells (adapt_kcut's second granularity), from the finished
+// scan: one thread per block, eight reads of cell_start.
+__global__ __launch_bounds__(256) void k_block_max(int ncx, int ncy, const unsigned *__restrict__ start, unsigned *__restrict__ hdr)
+{
+    const int nbx = (ncx + 3) >> 2, nby = (ncy + 3) >> 2;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    unsigned sum = 0u;
+    if (b < nbx * nby) {
+        const int bx = b % nbx, by = b / nbx;
+        const int x0 = bx * 4, x1 = min(x0 + 4, ncx);
+        for (int r = by * 4; r < min(by * 4 + 4, ncy); ++r) sum += start[r * ncx + x1] - start[r * ncx + x0];
+    }
+    sum = wave_max_u32(sum);
+    if ((threadIdx.x & 63) == 0 && sum) atomicMax(&hdr[6], sum);
+}
+
 // counting-sort placement (slot = cell start + rank, no atomics) fused with record packing
 // FUSED_SCAN (grids of at most FUSED_CELLS cells+2, e.g. 1024^2): every block rebuilds the exclusive scan of
 // the cell histogram in LDS itself (16 counts per thread) instead of waiting for a separate one-block scan
 // kernel -- one launch less on a latency-bound plan; block 0 publishes cell_start[] and the header.
 constexpr int FUSED_PER_THREAD = 17, FUSED_CELLS = 256 * FUSED_PER_THREAD;
+static_assert(FUSED_CELLS == FUSED_CELLS_HOST, "make_params decides with FUSED_CELLS_HOST which plans run a scan kernel");
 
 template <bool FUSED_SCAN>
 __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__ sigmas,
@@ -866,8 +883,13 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         } else {
             kc_tau = 0.5f * P.kcut * P.kcut;
         }
-    } else {
-        kc = __uint_as_float(V.hdr[3]);
+    } else {   // (the scan kernels left the maxima in the header)
+        kc = adapt_kcut(P, V.hdr[2], V.cell_count[P.ncells], kc_tau, kc_K, V.hdr[6]);
+        if (i == 0) {
+            V.hdr[3] = __float_as_uint(kc);
+            V.hdr[4] = __float_as_uint(kc_tau);
+            V.hdr[5] = kc_K;
+        }
     }
     if (valid) {
         const int smp = P.batch > 1 ? i / P.nper : 0;
@@ -3048,6 +3070,10 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
                                V.scan_tot, nblk, V.blockmax, V.hdr);
             hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, P, ncls, V.cell_start, V.scan_tot, nchunks,
                                V.cell_count, V.hdr);
+        }
+        if (P.adapt_cells4 > 0.f && dims->s > 0) {
+            const int nb4 = ((L.ncx + 3) / 4) * ((L.ncy + 3) / 4);
+            hipLaunchKernelGGL(k_block_max, dim3((unsigned)((nb4 + 255) / 256)), dim3(256), 0, st, L.ncx, L.ncy, V.cell_start, V.hdr);
         }
         if (dims->s > 0)
             hipLaunchKernelGGL(k_bin<false>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);

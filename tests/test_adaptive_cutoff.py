@@ -61,8 +61,9 @@ def _synth(h_lr, w_lr, scale, seed, gpp=1):
     return sig.numpy(), xy.numpy(), col.numpy(), H, W
 
 
-@pytest.mark.parametrize("case", [(64, 64, 4.0, 1, 0.1), (48, 40, 4.0, 16, 0.1), (40, 40, 8.0, 1, 0.05), (256, 256, 4.0, 1, 0.1)],
-                         ids=["x4", "x4-16-per-lr-px", "x8", "config2"])
+@pytest.mark.parametrize("case", [(64, 64, 4.0, 1, 0.1), (48, 40, 4.0, 16, 0.1), (40, 40, 8.0, 1, 0.05), (256, 256, 4.0, 1, 0.1),
+                                  (96, 96, 12.0, 1, 0.1), (160, 100, 8.0, 1, 0.2)],
+                         ids=["x4", "x4-16-per-lr-px", "x8", "config2", "x12-sparse-cells-block-count", "x8-two-pass-scan"])
 def test_plan_k_bounds_the_true_k_and_sets_tau(case, dev):
     from gsasr_amd import _cabi
     h_lr, w_lr, scale, gpp, dmax = case
@@ -76,6 +77,9 @@ def test_plan_k_bounds_the_true_k_and_sets_tau(case, dev):
     assert 16.0 <= tau <= tau_n + 1e-6
     if tau < tau_n - 1e-6 and tau > 16.0:
         assert abs(tau - (math.log(k / EPS) + 1e-3)) <= 2e-4 * tau, (tau, k)   # tau' is ln(K / eps) of the K reported
+    if scale >= 12.0:
+        # one Gaussian per 144 px: the largest CELL holds several times the mean, the plan counts in 4 x 4-cell blocks as well
+        assert k <= 4 * k_true, (k, k_true)
     if h_lr >= 256:
         # BASELINE config 2: the plan's K is within 3x of the true one (cells are 16 px, the box 103) and tau' well under ln(N / eps)
         assert k <= 3 * k_true and tau <= tau_n - 3.0, (k, k_true, tau, tau_n)
