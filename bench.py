@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
-                      exact_runs, flush_c_stdio, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
+                      exact_runs, live_hbm_traffic, flush_c_stdio, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
 
 
 def parse():
@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cutoff", type=float, default=0.0, help="support cutoff tau (0 = library default: adaptive ln(N/1e-5))")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not count the dominant kernel's HBM bytes live (two short child runs under rocprofv3 --pmc); "
+                         "roofline.traffic is then replayed from profiles/pmc_latest.json")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-semantics (tau 104 / no cull) and drop-in legs of config 2")
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--exchange", default="halo", choices=["halo", "broadcast"],
@@ -177,11 +180,26 @@ def main():
     # per-kernel device time, measured live (not part of the timed region)
     kern = stage_times(step, dev, iters=30)
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")   # HBM bytes per launch from rocprofv3 --pmc passes
-    if os.path.exists(pmc) and args.config == "c2" and world == 1:
+    dom_kernel = {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom]
+    if world == 1 and rank == 0 and not args.no_live_pmc and not args.force_dist and not getattr(step, "batched", False) \
+            and "GSASR_BENCH_CHILD" not in os.environ:
+        # counted NOW, on this box, for this build: two child runs of the same workload under rocprofv3 --pmc
+        extra = ["--config", args.config, "--dmax", str(args.dmax), "--cutoff", str(args.cutoff)] + (["--fwd-only"] if args.fwd_only else [])
         try:
-            traffic = json.load(open(pmc)).get({"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom], {}).get("hbm_bytes")
+            live, note = live_hbm_traffic(extra, [dom_kernel])
+        except Exception as e:      # the counters must never take the line with them
+            live, note = None, repr(e)
+        if live and live.get(dom_kernel):
+            traffic, traffic_source = live[dom_kernel], note
+        else:
+            print(f"[bench] live HBM counters unavailable ({note}); replaying profiles/pmc_latest.json", file=sys.stderr)
+    if traffic is None and os.path.exists(pmc) and args.config == "c2" and world == 1:
+        try:
+            traffic = json.load(open(pmc)).get(dom_kernel, {}).get("hbm_bytes")
+            traffic_source = ("profiles/pmc_latest.json (REPLAYED: HBM bytes per launch of this kernel from the committed rocprofv3 "
+                              "--pmc FETCH_SIZE / WRITE_SIZE passes of the same command, not counted in this run)")
         except Exception:
             traffic = None
     kname = {"forward": "k_sample_fwd", "backward": "k_sample_bwd"} if getattr(step, "sampled", False) else \
@@ -189,9 +207,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": kname[dom],
                 "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": ("profiles/pmc_latest.json (REPLAYED: HBM bytes per launch of this kernel from the committed rocprofv3 "
-                                   "--pmc FETCH_SIZE / WRITE_SIZE passes of the same command, not counted in this run)"
-                                   if traffic is not None else None),
+                "traffic_source": traffic_source if traffic is not None else None,
                 "note": "stage times from events on the launch stream; outputs are stored, not accumulated (no memsets)"}
     # The binding unit is the fp32 VALU / v_exp_f32 pipe, not HBM: report pair rates and the VALU
     # occupancy next to the HBM fraction.

@@ -313,6 +313,56 @@ def window_pairs(sig, xy, H, W, dmax, tau, rows):
     return out
 
 
+def live_hbm_traffic(argv_extra, kernel_substrings, timeout=150):
+    """HBM bytes per launch of the kernels whose names contain one of `kernel_substrings`, COUNTED IN THIS RUN: two short
+    child runs of bench.py under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters + kernel trace
+    only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), corrected as the guide says: FETCH_SIZE counts half of a
+    wide read stream on gfx950 (x 2); WRITE_SIZE calibrated on the forward's image store.  Returns ({substring: bytes}, note)
+    or (None, why-not)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            env = dict(os.environ, TMPDIR="/tmp", GSASR_BENCH_CHILD="1")
+            cmd = [prof, "--pmc", ctr, "--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.join(root, "bench.py"),
+                   "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-graph", "--no-extras", "--no-live-pmc", *argv_extra]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return None, f"{ctr} pass: {e!r}"
+            db = None
+            for dirpath, _, files in os.walk(tmp):
+                for f in files:
+                    if f.endswith("_results.db"):
+                        db = os.path.join(dirpath, f)
+            if r.returncode != 0 or db is None:
+                return None, f"{ctr} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
+            con = sqlite3.connect(db)
+            pcols = [c[1] for c in con.execute("pragma table_info(pmc_events)")]
+            kcol = "name" if "name" in pcols else "kernel_name"
+            ccol = "counter_name" if "counter_name" in pcols else "pmc_name"
+            vcol = "value" if "value" in pcols else "counter_value"
+            for name, val in con.execute(f"select {kcol}, avg({vcol}) from pmc_events where {ccol} = ? group by {kcol}", (ctr,)):
+                for sub in kernel_substrings:
+                    if name and sub in name:
+                        got.setdefault(sub, {}).setdefault(ctr, 0.0)
+                        got[sub][ctr] += float(val)
+            con.close()
+    out = {sub: int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for sub, v in got.items()}
+    if not out:
+        return None, "no matching kernels in the counter passes"
+    return out, ("LIVE: counted in this run by two child runs of this command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                 "(separate passes, counters + kernel trace only); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch -- the gfx950 "
+                 "FETCH_SIZE correction of MI355X_MICROARCH.md")
+
+
 def copy_bandwidth(dev):
     """measured HBM stream rate on this box: device-to-device copy of 1 GiB (read + write = 2 GiB of traffic)"""
     n = 1 << 28
