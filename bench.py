@@ -280,7 +280,7 @@ def main():
             "roofline": roofline, "kernels": kern,
         }
         if step.dist:
-            out["config"]["exchange"] = ("halo swap with ranks g-1/g+1 (send/recv), "
+            out["config"]["exchange"] = (f"halo swap with ranks g-1/g+1 ({step.ex.transport if step.halo else ''}), "
                                          f"{step.halo_records} records max per edge, capacity {step.ex.cap}"
                                          if step.halo else "broadcast of all Gaussians + reduce_scatter of their gradients")
         if step.dist:
@@ -289,7 +289,8 @@ def main():
             per_rank = (2 * 2 * step.ex.cap * 32 if step.halo else 32 * step.n + 32 * step.n)
             out["config"]["rccl"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
                                      "bytes_sent_per_rank_per_step": per_rank if world > 1 else 0,
-                                     "pattern": "2 x batch_isend_irecv with ranks g-1/g+1 (forward records, backward gradients)"
+                                     "pattern": (("2 x all_to_all_single with non-zero splits for ranks g-1/g+1 only" if step.ex.transport == "alltoall"
+                                                  else "2 x batch_isend_irecv with ranks g-1/g+1") + " (forward records, backward gradients)")
                                                 if step.halo else "broadcast of ONE packed [N,8] buffer + in-place reduce_scatter_tensor of the [N,8] gradients"}
         if world == 1 and args.config == "c2" and not args.no_extras and not args.force_dist:
             out["exact"] = exact_runs(args, dev, step.H * step.W)

@@ -40,6 +40,7 @@ FLAG_BWD_TILE = 256        # GSASR_FLAG_BWD_TILE
 FLAG_BWD_ATOMIC = 512      # GSASR_FLAG_BWD_ATOMIC
 FLAG_COUNTERS_CLEAN = 1024 # GSASR_FLAG_COUNTERS_CLEAN
 FLAG_PARITY = 2048         # GSASR_FLAG_PARITY
+FLAG_CUTOFF_CAP = 4096     # GSASR_FLAG_CUTOFF_CAP
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -462,6 +463,24 @@ def backward_packed(p: Plan, packed: torch.Tensor, grad_img: torch.Tensor, g_pac
     if grad_img.shape[0] != p.dims.row1 - p.dims.row0 or g_packed.shape[0] != p.dims.s or packed.shape[0] != p.dims.s:
         raise RuntimeError("grads / g_packed do not match the plan")
     d = _dims_with(p, FLAG_OVERWRITE_GRADS if overwrite else 0)
+    with _on(p.device):
+        check(lib().gsasr_splat_backward(ps, pc, pk, pg, gs, gc, gk, ctypes.byref(d), p.workspace.data_ptr(),
+                                         p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
+
+
+def backward_to_packed(p: Plan, sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, grad_img: torch.Tensor,
+                       g_packed: torch.Tensor, overwrite: bool = True) -> None:
+    """`backward` of a plan made from three separate arrays, with the gradient written as ONE `[N,8]` array
+    {d sx, d sy, d rho, d x, d y, d r, d g, d b} -- the buffer a collective then runs on in place (gsasr_amd/shard.py).
+    The backward reads the plan, not the input arrays, so only the OUTPUT stride changes (GSASR_FLAG_STRIDE8 at backward time)."""
+    if p.dims.flags & FLAG_STRIDE8:
+        raise RuntimeError("the plan is packed already: use backward_packed")
+    ps, pc, pk = _ptr3(sigmas, "sigmas", 3), _ptr3(coords, "coords", 2), _ptr3(colors, "colors", 3)
+    gs, gc, gk = _cols(g_packed, "g_packed")
+    pg = _chk(grad_img, "grads", (p.dims.w, 3))
+    if grad_img.shape[0] != p.dims.row1 - p.dims.row0 or g_packed.shape[0] != p.dims.s or sigmas.shape[0] != p.dims.s:
+        raise RuntimeError("grads / g_packed do not match the plan")
+    d = _dims_with(p, FLAG_STRIDE8 | (FLAG_OVERWRITE_GRADS if overwrite else 0))
     with _on(p.device):
         check(lib().gsasr_splat_backward(ps, pc, pk, pg, gs, gc, gk, ctypes.byref(d), p.workspace.data_ptr(),
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")

@@ -355,7 +355,7 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     // data-derived cutoff (adapt_kcut): the bounded op under the adaptive default only -- an explicit tau (per call, per
     // process, environment) is used as given, and the unbounded op has no box to count in
     P.adapt_cells = P.adapt_cells4 = 0.f;
-    if (P.bounded && d->cutoff == 0.f && default_cutoff() == 0.f && P.kcut > 0.f && adapt_env()) {
+    if (P.bounded && ((d->cutoff == 0.f && default_cutoff() == 0.f) || (d->flags & GSASR_FLAG_CUTOFF_CAP)) && P.kcut > 0.f && adapt_env()) {
         const int B = batch_of(d);
         const double dpx = (double)d->dmax * 0.5 * (double)(d->w - 1), dpy = (double)d->dmax * 0.5 * (double)((B > 1 ? d->slot : d->h) - 1);
         const double cx = std::ceil(2.0 * std::floor(dpx + 1.02) / (double)CELL) + 1.0, cy = std::ceil(2.0 * std::floor(dpy + 1.02) / (double)CELL) + 1.0;

@@ -60,6 +60,7 @@ def broadcast_gaussians(sigmas, coords, colors, src: int = 0, group=None):
 
 class HipBackend:
     """Local band rasterizer = libgsasr_splat.so through the C ABI (the product path)."""
+    CUTOFF_CAP_FLAG = 4096      # _cabi.FLAG_CUTOFF_CAP: an explicit cutoff is an upper bound for the plan's windows
 
     # ---- packed [N,8] records (BandExchange) ----
     @staticmethod
@@ -110,6 +111,12 @@ class HipBackend:
         _cabi.backward(state, sigmas, coords, colors, grad_slab.contiguous(), *g, overwrite=True)
         return g
 
+    @staticmethod
+    def backward_to_packed(state, sigmas, coords, colors, grad_slab, g_packed):
+        """the same gradient written as ONE `[N,8]` array: the buffer the collective runs on (no pack / unpack copies)"""
+        from . import _cabi
+        _cabi.backward_to_packed(state, sigmas, coords, colors, grad_slab.contiguous(), g_packed, overwrite=True)
+
 
 def reduce_gaussian_grads(g_sigmas, g_coords, g_colors, mode: str = "reduce_scatter", group=None):
     """Sum the per-rank partial gradients. Returns full-shape tensors; with "reduce_scatter" only this
@@ -148,6 +155,19 @@ class _BandSplat(Function):
     @once_differentiable
     def backward(ctx, grad_slab):
         sigmas, coords, colors = ctx.saved_tensors
+        if hasattr(ctx.backend, "backward_to_packed"):
+            # ONE [ceil(N / G) * G, 8] buffer: the backward writes it, the collective reduces it in place, the three
+            # gradients are column views of it -- the only allocation of this backward (reduce_gaussian_grads packs, pads,
+            # scatters and unpacks: five N x 32-byte copies around the same collective)
+            n = sigmas.shape[0]
+            world = dist.get_world_size(ctx.group) if (dist.is_available() and dist.is_initialized()) else 1
+            per = (n + world - 1) // world
+            g = torch.empty(per * world, 8, device=sigmas.device, dtype=sigmas.dtype)
+            if per * world > n:
+                g[n:].zero_()
+            ctx.backend.backward_to_packed(ctx.state, sigmas, coords, colors, grad_slab, g[:n])
+            gp = reduce_packed_grads_(g, n, ctx.grad_reduce, ctx.group)
+            return gp[:, 0:3], gp[:, 3:5], gp[:, 5:8], None, None, None, None, None, None, None
         g = ctx.backend.backward(ctx.state, sigmas, coords, colors, grad_slab)
         gs, gc, gk = reduce_gaussian_grads(*g, mode=ctx.grad_reduce, group=ctx.group)
         return gs, gc, gk, None, None, None, None, None, None, None
@@ -298,8 +318,16 @@ class BandExchange:
     """
 
     def __init__(self, n_local: int, cap: int, h: int, w: int, dmax: Optional[float], cutoff: float = 0.0,
-                 device=None, group=None, backend=None, rank: Optional[int] = None, world: Optional[int] = None):
+                 device=None, group=None, backend=None, rank: Optional[int] = None, world: Optional[int] = None,
+                 transport: str = "alltoall"):
         self.group, self.backend = group, backend or HipBackend
+        # how the two neighbour swaps of a step are issued: "alltoall" = ONE `all_to_all_single` with split sizes that are
+        # zero for every rank but g-1 / g+1 (RCCL turns it into the same grouped send/recv pairs, but the host pays for one
+        # collective call instead of four P2P ops and a coalescing context -- the exchange sits between kernels of tens of
+        # microseconds); "p2p" = `batch_isend_irecv`
+        if transport not in ("alltoall", "p2p"):
+            raise ValueError(f"unknown transport {transport!r}")
+        self.transport = transport
         # rank/world default to the process group's; explicit values let one process drive several bands
         # (single-GPU tests, or a host that time-multiplexes bands)
         self.rank = dist.get_rank(group) if rank is None else int(rank)
@@ -311,6 +339,7 @@ class BandExchange:
         resolve = getattr(self.backend, "resolve_cutoff", None)
         if resolve is not None:
             self.cutoff = resolve(self.cutoff, self.n + 2 * self.cap)
+        self.plan_flags = getattr(self.backend, "CUTOFF_CAP_FLAG", 0)
         self.rows = row_band(self.h, self.rank, self.world)
         span = lambda r: row_band(self.h, r, self.world)[1] - row_band(self.h, r, self.world)[0]
         self.rows_above = span(self.rank - 1) if self.rank > 0 else 0
@@ -319,8 +348,10 @@ class BandExchange:
         n, c = self.n, self.cap
         self.records = torch.full((n + 2 * c, 8), float("nan"), **f)      # [own | from_above | from_below]
         self.g_records = torch.zeros(n + 2 * c, 8, **f)
-        self.send_up, self.send_down = torch.empty(c, 8, **f), torch.empty(c, 8, **f)
-        self.ret_up, self.ret_down = torch.zeros(c, 8, **f), torch.zeros(c, 8, **f)
+        # (each direction's two buffers are halves of ONE tensor, in rank order of the peer: what all_to_all_single wants)
+        self.send, self.ret = torch.empty(2 * c, 8, **f), torch.zeros(2 * c, 8, **f)
+        self.send_up, self.send_down = self.send[:c], self.send[c:]
+        self.ret_up, self.ret_down = self.ret[:c], self.ret[c:]
         self.up_index = torch.zeros(c, device=device, dtype=torch.int32)
         self.down_index = torch.zeros(c, device=device, dtype=torch.int32)
         self.counts = torch.zeros(4, device=device, dtype=torch.int32)
@@ -350,6 +381,25 @@ class BandExchange:
         return self.g_records[: self.n]
 
     def _swap(self, key, to_above, from_above, to_below, from_below):
+        if self.transport == "alltoall":
+            if self.world <= 1:
+                return
+            hit = self._a2a.get(key) if hasattr(self, "_a2a") else None
+            if hit is None:
+                c, n = self.cap, self.n
+                inp, out = (self.send, self.records[n:]) if key == "fwd" else (self.g_records[n:], self.ret)
+                assert inp[:c].data_ptr() == to_above.data_ptr() and out[c:].data_ptr() == from_below.data_ptr()
+                lo, hi = (0 if self.rank > 0 else c), (2 * c if self.rank < self.world - 1 else c)
+                splits = [0] * self.world
+                if self.rank > 0:
+                    splits[self.rank - 1] = c
+                if self.rank < self.world - 1:
+                    splits[self.rank + 1] = c
+                if not hasattr(self, "_a2a"):
+                    self._a2a = {}
+                hit = self._a2a[key] = (out[lo:hi], inp[lo:hi], splits)
+            dist.all_to_all_single(hit[0], hit[1], hit[2], hit[2], group=self.group)
+            return
         # the four P2POps of a direction always name the same buffers and peers: built once (this runs twice per step
         # on the host, in front of kernels that take tens of microseconds)
         ops = self._ops.get(key) if hasattr(self, "_ops") else None
@@ -417,7 +467,9 @@ class _BandLocalSplat(Function):
         if packed_local.data_ptr() != ex.own.data_ptr():
             ex.own.copy_(packed_local)
         records = ex.exchange_forward()
-        slab, state = ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff)
+        # (ex.cutoff is the conservative tau the selection used; the plan may build its windows with the data-derived one below it)
+        slab, state = ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff, ex.plan_flags) if ex.plan_flags \
+            else ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff)
         ctx.ex, ctx.state, ctx.version = ex, state, ex.version
         if slab.numel():
             _poison_if(ex.incomplete(), slab)

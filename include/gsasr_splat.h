@@ -90,6 +90,10 @@ enum gsasr_status {
                                          for parity 1-p: alternate the bit plan by plan.  (First use of a workspace: leave
                                          CLEAN off.) */
 #define GSASR_FLAG_PARITY 2048u        /* which of the two counter arrays this plan counts in */
+#define GSASR_FLAG_CUTOFF_CAP 4096u    /* bounded op with an explicit dims.cutoff: treat it as an UPPER bound -- classes and dead set
+                                         use it as given, the windows the data-derived tau' <= cutoff (gsasr_plan_cutoff).  For
+                                         callers that must name the conservative tau themselves (the row-band exchange: the
+                                         selection of halo Gaussians and the neighbour's plan have to agree on it) */
 
 typedef struct gsasr_dims {
     int s;        /* number of Gaussians                                              */

@@ -973,3 +973,31 @@ def test_raw_op_colours_far_above_one(dmax, dev):
     for got, want, name in zip(grads, gref, ("sigmas", "coords", "colors")):
         assert _relmax(got, want) <= GRAD_RTOL, name
         assert not (np.abs(got - want) > _row_tol(want, sig)).any(), name
+
+
+@pytest.mark.parametrize("kernel", ["gaussian", "tile"])
+def test_splat_band_writes_its_gradient_as_one_packed_buffer(kernel, dev):
+    """`shard.splat_band` with the HIP backend: the backward writes ONE [N,8] gradient (GSASR_FLAG_STRIDE8 at backward time
+    on a plan made from three arrays) and returns column views of it -- equal to the oracle, on a whole image and on a band"""
+    from gsasr_amd import _cabi, shard
+    from oracle import gs_oracle
+    sig, xy, col, H, W, wgt = _synth(24, 20, 4.0, 8)
+    flag = {"gaussian": _cabi.FLAG_BWD_GAUSSIAN, "tile": _cabi.FLAG_BWD_TILE}[kernel]
+    for rows in ((0, H), (16, 64)):
+        a, b, c = (_t(x, dev) for x in (sig, xy, col))
+        plan = _cabi.plan(a, b, c, H, W, 0.3, rows=rows, flags=flag)
+        g = torch.full((sig.shape[0], 8), float("nan"), device=dev)
+        _cabi.backward_to_packed(plan, a, b, c, _t(wgt[rows[0]:rows[1]], dev), g)
+        torch.cuda.synchronize()
+        want = gs_oracle.backward_f64(sig, xy, col, wgt[rows[0]:rows[1]], 0.3, h=H, rows=rows)
+        got = g.cpu().numpy()
+        for part, ref in zip((got[:, 0:3], got[:, 3:5], got[:, 5:8]), want):
+            assert np.isfinite(part).all()
+            assert _relmax(part, ref) <= GRAD_RTOL
+    # through the autograd Function (no process group: one band = the image, no collective)
+    a, b, c = (_t(x, dev).requires_grad_(True) for x in (sig, xy, col))
+    slab = shard.splat_band(a, b, c, H, W, dmax=0.3)
+    (slab * _t(wgt, dev)).sum().backward()
+    want = gs_oracle.backward_f64(sig, xy, col, wgt, 0.3)
+    for t, ref in zip((a, b, c), want):
+        assert t.grad.shape == t.shape and _relmax(t.grad.cpu().numpy(), ref) <= GRAD_RTOL

@@ -31,6 +31,19 @@ class OracleBackend:
         return tuple(torch.from_numpy(a).float() for a in g)
 
 
+class OracleBackendPackedOut(OracleBackend):
+    """the same with the gradient written as one [N,8] array (HipBackend.backward_to_packed): `splat_band` then reduces that
+    buffer in place and returns column views of it instead of packing / padding / unpacking around the collective"""
+
+    @staticmethod
+    def backward_to_packed(state, sigmas, coords, colors, grad_slab, g_packed):
+        g = OracleBackend.backward(state, sigmas, coords, colors, grad_slab)
+        g_packed.copy_(shard.pack(*g))
+
+
+BACKENDS = {"three-tensors": OracleBackend, "packed-out": OracleBackendPackedOut}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -39,7 +52,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, out):
+def _worker(rank, world, port, mode, out, backend="three-tensors"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,7 +63,7 @@ def _worker(rank, world, port, mode, out):
             sig, xy, col = torch.zeros_like(sig), torch.zeros_like(xy), torch.zeros_like(col)
         sig, xy, col = shard.broadcast_gaussians(sig, xy, col, src=0)
         a, b, c = (t.clone().requires_grad_(True) for t in (sig, xy, col))
-        slab = shard.splat_band(a, b, c, H, W, dmax=0.4, grad_reduce=mode, backend=OracleBackend)
+        slab = shard.splat_band(a, b, c, H, W, dmax=0.4, grad_reduce=mode, backend=BACKENDS[backend])
         r0, r1 = shard.row_band(H, rank, world)
         assert slab.shape == (r1 - r0, W, 3)
         wgt = synthetic.grad_image(H, W, 6)
@@ -66,14 +79,16 @@ def _reduce_scatter_supported():
     return True
 
 
-@pytest.mark.parametrize("world,mode", [(2, "all_reduce"), (3, "all_reduce"), (2, "reduce_scatter")])
-def test_row_band_shard_matches_single_process(world, mode):
+@pytest.mark.parametrize("world,mode,backend", [(2, "all_reduce", "three-tensors"), (3, "all_reduce", "three-tensors"),
+                                                (2, "reduce_scatter", "three-tensors"), (2, "all_reduce", "packed-out"),
+                                                (3, "reduce_scatter", "packed-out")])
+def test_row_band_shard_matches_single_process(world, mode, backend):
     from oracle import gs_oracle
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
     try:
-        mp.spawn(_worker, args=(world, port, mode, out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, mode, out, backend), nprocs=world, join=True)
     except Exception as e:  # gloo builds without reduce_scatter: the NCCL/RCCL path has it; skip here
         if mode == "reduce_scatter" and "reduce_scatter" in str(e).lower():
             pytest.skip(f"gloo lacks reduce_scatter_tensor in this build: {e}")
@@ -228,7 +243,7 @@ class OraclePackedBackend(OracleBackend):
 H_LR, W_LR, SCALE, DMAX_X = 12, 10, 3.0, 0.2
 
 
-def _exchange_worker(rank, world, port, cap, out):
+def _exchange_worker(rank, world, port, cap, out, transport="alltoall"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -236,7 +251,7 @@ def _exchange_worker(rank, world, port, cap, out):
         sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
         lr0, lr1 = shard.row_band(H_LR, rank, world)           # this rank "decodes" its own LR rows
         mine = shard.pack(sig, xy, col)[lr0 * W_LR: lr1 * W_LR]
-        ex = shard.BandExchange(mine.shape[0], cap, H, W, DMAX_X, backend=OraclePackedBackend)
+        ex = shard.BandExchange(mine.shape[0], cap, H, W, DMAX_X, backend=OraclePackedBackend, transport=transport)
         p = mine.clone().requires_grad_(True)
         slab = shard.splat_band_local(p, ex)
         err = None
@@ -252,12 +267,14 @@ def _exchange_worker(rank, world, port, cap, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_band_exchange_matches_single_process(world):
+@pytest.mark.parametrize("world,transport", [(2, "alltoall"), (3, "alltoall"), (4, "alltoall"), (2, "p2p"), (3, "p2p")])
+def test_band_exchange_matches_single_process(world, transport):
+    """both ways of issuing the two neighbour swaps of a step: ONE all_to_all_single whose split sizes are zero for every
+    rank but g-1 / g+1 (default), and batched isend / irecv"""
     from oracle import gs_oracle
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_exchange_worker, args=(world, _free_port(), 64, out), nprocs=world, join=True)
+    mp.spawn(_exchange_worker, args=(world, _free_port(), 64, out, transport), nprocs=world, join=True)
     sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
     wgt = synthetic.grad_image(H, W, 6)
     ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, DMAX_X)

@@ -87,21 +87,30 @@ class Step:
             # (x8 row bands: the tile-stationary backward, the library's own choice for whole images at this scale)
             self.plan = _cabi.plan_packed(self.ex.records, H, W, self.dmax, rows=self.rows, cutoff=self.cutoff,
                                           flags=_cabi.FLAG_BWD_TILE if (self.strong and not args.fwd_only) else 0)
-            ok = 1.0
-            try:    # one trial swap each way before anything is timed: a transport that cannot do grouped
-                    # send/recv shows up here and the collective pattern takes over
-                self.ex.exchange_forward()
-                self.ex.exchange_backward()
-                torch.cuda.synchronize(dev)
-            except Exception as e:
-                ok = 0.0
-                print(f"[bench] rank {rank}: halo exchange unavailable ({e!r}); using broadcast + reduce_scatter",
-                      file=sys.stderr)
-            if world > 1:   # every rank takes the same data path: if one of them could not swap, none does
-                flag = torch.tensor([ok], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = float(flag.item())
-            if ok == 1.0:
+            # one trial swap each way before anything is timed, per transport: ONE all_to_all_single per direction first,
+            # batched P2P ops next; a transport that cannot do either shows up here and the collective pattern takes over.
+            # Every rank takes the same data path: the weakest rank's result decides.
+            ok = 0.0
+            for level, transport in ((2.0, "alltoall"), (1.0, "p2p")):
+                self.ex.transport = transport
+                works = level
+                try:
+                    self.ex.exchange_forward()
+                    self.ex.exchange_backward()
+                    torch.cuda.synchronize(dev)
+                except Exception as e:
+                    works = 0.0
+                    print(f"[bench] rank {rank}: halo exchange over {transport} unavailable ({e!r})", file=sys.stderr)
+                if world > 1:
+                    flag = torch.tensor([works], device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    works = float(flag.item())
+                if works == level:
+                    ok = level
+                    break
+            if ok == 0.0:
+                print(f"[bench] rank {rank}: using broadcast + reduce_scatter", file=sys.stderr)
+            if ok > 0.0:
                 return
             self.halo, self.ex = False, None
             self.n_rank = self.n
