@@ -90,7 +90,10 @@ constexpr int NCH = 64;         // row chunks a large Gaussian is split into in 
 constexpr int FUSED_CELLS_HOST = 256 * 17;   // = FUSED_CELLS (k_bin<true>): grids up to this many classes never run a scan kernel
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y, [2]=largest cell count,
                                 //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut),
-                                //   [6]=largest count of a 4 x 4 block of cells (k_block_max)
+                                //   [6]=largest count of a 4 x 4 block of cells (k_block_max),
+                                //   [8],[9]=REACH in x, y: the half-extents the render kernels search with -- words 0, 1 shrunk to the
+                                //   windows' cutoff tau' where no window is capped by the dmax box (reach_of), raised again (atomicMax)
+                                //   by every Gaussian that kept its conservative window
 constexpr double LOG2E = 1.4426950408889634074;
 
 struct Params {
@@ -100,6 +103,8 @@ struct Params {
     float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled (the CONSERVATIVE tau: classes, dead set)
     float adapt_cells;  // > 0: the windows are built with the data-derived cutoff tau' = ln(K / eps) <= tau, K = the most Gaussians
                      // whose dmax box can cover one pixel <= (largest cell count) * adapt_cells + (large class); 0: kcut everywhere
+    float cap_px_x, cap_px_y;  // the dmax box in pixels (smallest over the samples of a batch): a class extent below it means
+                     // no Gaussian's window is capped by the box, so all of them shrink with the cutoff (reach_of)
     float adapt_cells4; // > 0: the same bound counted in blocks of 4 x 4 cells (k_block_max; sparse cells on large grids): K is
                      // the smaller of the two
     int ncx, ncy, ncells;
@@ -355,6 +360,17 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     // data-derived cutoff (adapt_kcut): the bounded op under the adaptive default only -- an explicit tau (per call, per
     // process, environment) is used as given, and the unbounded op has no box to count in
     P.adapt_cells = P.adapt_cells4 = 0.f;
+    {
+        double wmin = d->w, hmin = d->h;
+        if (d->batch > 1) {
+            for (int b = 0; b < d->batch; ++b) {
+                hmin = std::fmin(hmin, (double)d->sample_hw[2 * b]);
+                wmin = std::fmin(wmin, (double)d->sample_hw[2 * b + 1]);
+            }
+        }
+        P.cap_px_x = P.bounded ? (float)((double)d->dmax * 0.5 * (wmin - 1.0)) : INFINITY;
+        P.cap_px_y = P.bounded ? (float)((double)d->dmax * 0.5 * (hmin - 1.0)) : INFINITY;
+    }
     if (P.bounded && ((d->cutoff == 0.f && default_cutoff() == 0.f) || (d->flags & GSASR_FLAG_CUTOFF_CAP)) && P.kcut > 0.f && adapt_env()) {
         const int B = batch_of(d);
         const double dpx = (double)d->dmax * 0.5 * (double)(d->w - 1), dpy = (double)d->dmax * 0.5 * (double)((B > 1 ? d->slot : d->h) - 1);
@@ -520,6 +536,15 @@ __device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, 
     return fminf(sqrtf(2.f * t) * (1.f + 1e-6f), P.kcut);
 }
 
+// Half-extent the render kernels search with, from the class' conservative maximum `ext` (= ceil(largest extent) + 2 under
+// the cutoff k_classify used): with windows built for a smaller cutoff (kc < P.kcut) every extent that is not capped by the
+// dmax box shrinks by kc / P.kcut -- and none is capped when the largest one lies below the box (cap_px).
+__device__ __forceinline__ unsigned reach_of(unsigned ext, float kc, float kcut, float cap_px)
+{
+    if (ext < 2u || !(kc < kcut) || !((float)(ext - 2u) < cap_px - 1.f)) return ext;
+    return min(ext, (unsigned)ceilf((float)(ext - 2u) * (kc / kcut) * (1.f + 1e-6f)) + 2u);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // plan kernels
 // ---------------------------------------------------------------------------------------------------
@@ -587,7 +612,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int lane = threadIdx.x & 63;
     // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
     for (int k = i; k < P.ncells + 1 + NDEAD; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
-    if (i == 0) V.hdr[2] = V.hdr[6] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / k_block_max
+    if (i == 0) V.hdr[2] = V.hdr[6] = V.hdr[8] = V.hdr[9] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / k_block_max
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
@@ -855,6 +880,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     uint4 bb = make_uint4(0u, 0u, 0u, 0u), bc = bb;
     uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);   // quadrant-row spans: every column unless computed below
     bool large = false;
+    unsigned fb_rx = 0u, fb_ry = 0u;
     float sx = 0.f, sy = 0.f, rho = 0.f, x = 0.f, y = 0.f, col0 = 0.f, col1 = 0.f, col2 = 0.f;
     if (valid) {
         key = V.key[i];
@@ -889,6 +915,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             V.hdr[3] = __float_as_uint(kc);
             V.hdr[4] = __float_as_uint(kc_tau);
             V.hdr[5] = kc_K;
+            atomicMax(&V.hdr[8], reach_of(V.hdr[0], kc, P.kcut, P.cap_px_x));
+            atomicMax(&V.hdr[9], reach_of(V.hdr[1], kc, P.kcut, P.cap_px_y));
         }
     }
     if (valid) {
@@ -902,6 +930,10 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         if (b.cls == 2 && key <= (unsigned)P.ncells && kc != P.kcut) {
             b = gaussian_box(sx, sy, x, y, P, g, P.kcut);
             kw = P.kcut;
+            if (key < (unsigned)P.ncells) {   // (normal class: the tiles must search as far as this conservative window reaches)
+                fb_rx = (unsigned)ceilf(b.ex) + 2u;
+                fb_ry = (unsigned)ceilf(b.ey) + 2u;
+            }
         }
         large = key == (unsigned)P.ncells;
         // exponent = w1*(dx^2/sx^2 - 2 rho dx dy/(sx sy) + dy^2/sy^2), w1 = -0.5/(1-rho^2)   (gs.cu:33-56);
@@ -1021,6 +1053,15 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             }
         }
     }
+    {   // Gaussians that kept their conservative window raise the reach (rare: one atomic pair per wave that holds any)
+        if (__ballot(fb_rx != 0u) != 0ull) {
+            const unsigned wx = wave_max_u32(fb_rx), wy = wave_max_u32(fb_ry);
+            if ((threadIdx.x & 63) == 0) {
+                atomicMax(&V.hdr[8], wx);
+                atomicMax(&V.hdr[9], wy);
+            }
+        }
+    }
     if (FUSED_SCAN) {
         const int t = threadIdx.x, ncls = P.ncells + 1 + NDEAD;
         const int b0 = t * FUSED_PER_THREAD;
@@ -1057,8 +1098,12 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             if ((t & 63) == 0) { s_part[t >> 6] = mx; s_part[4 + (t >> 6)] = my; }
             __syncthreads();
             if (t == 0) {
-                V.hdr[0] = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
-                V.hdr[1] = max(max(s_part[4], s_part[5]), max(s_part[6], s_part[7]));
+                const unsigned ex0 = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+                const unsigned ey0 = max(max(s_part[4], s_part[5]), max(s_part[6], s_part[7]));
+                V.hdr[0] = ex0;
+                V.hdr[1] = ey0;
+                atomicMax(&V.hdr[8], reach_of(ex0, kc, P.kcut, P.cap_px_x));
+                atomicMax(&V.hdr[9], reach_of(ey0, kc, P.kcut, P.cap_px_y));
                 V.hdr[2] = kc_mc;
                 V.hdr[3] = __float_as_uint(kc);
                 V.hdr[4] = __float_as_uint(kc_tau);
@@ -1191,7 +1236,7 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
     // Segment table: lane r holds [beg,end) of cell row cy0+r restricted to the columns a normal-class
     // Gaussian can reach this sub-tile from (max half-extent from the plan header); one more lane holds
     // the large class.  One vector round trip instead of a dependent scalar load per row.
-    const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
     int nseg = 0;
     unsigned sbeg = 0, send = 0;
     if (rx > 0) {
@@ -1313,7 +1358,7 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
     const int wtx = sx0 >> SUBX_SHIFT;
 
     // segment table of the 32x16 tile (every wave builds the same one: a single vector round trip)
-    const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
     int nseg = 0;
     unsigned sbeg = 0, send = 0;
     if (rx > 0) {
@@ -2120,7 +2165,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
 
     // ---- segment table of the tile (every wave builds the same one; cf. fwd_block) ------------------------
     const unsigned *__restrict__ cs = V.cell_start;
-    const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
     int nseg = 0;
     unsigned sbeg = 0, send = 0;
     if (rx > 0) {
@@ -2559,7 +2604,7 @@ __global__ __launch_bounds__(64 * SAMPLE_WAVES) __attribute__((amdgpu_waves_per_
     const unsigned *__restrict__ cs = V.cell_start;
 
     // segment table of the rectangle (every wave builds the same one)
-    const int rx = (int)V.hdr[0], ry = (int)V.hdr[1];
+    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
     int nseg = 0;
     unsigned sbeg = 0, send = 0;
     if (rx > 0) {
