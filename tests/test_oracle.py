@@ -34,7 +34,9 @@ def test_forward_f32_matches_reference_torch_version(path):
     img = gs_oracle.forward_f32(z["sigmas"], z["coords"], z["colors"], h, w, dmax)
     # both are fp32 evaluations with different association; agreement is at fp32 rounding level
     # relative to the exponent's conditioning (|rho| -> 1 cases amplify it), checked vs fp64 too
-    tol = 2e-3 if "edge" in path else 2e-5
+    # (the `edge` cases -- off-image, needle, |rho| near the activation limit, sub-pixel sigma -- measure 1e-5: held to 5e-5,
+    # not to the 2e-3 of rounds 1-3)
+    tol = 5e-5 if "edge" in path else 2e-5
     # (the `_rho_` cases, |rho| up to 0.9999: never tighter than twice what the reference's own fp32 run achieves against
     # its fp64 run -- 4e-5 and 1e-4 of the image there)
     own = 2.0 * float(np.abs(z["img_f32"] - z["img_f64"]).max()) if "_rho_" in path else 0.0
@@ -65,7 +67,7 @@ def test_backward_matches_reference_autograd(path):
         # than 2e-5 because the reference's fp64 run keeps pixel coordinates in double
         # (check.py:15-16) while the kernels -- and this oracle -- round them to float (gs.cu:27-28)
         assert _relmax(got64, ref64) <= 2e-5, key
-        tol = 5e-3 if "edge" in path else 2e-4
+        tol = 2e-4      # (the `edge` cases included: they measure <= 7e-6; rounds 1-3 allowed them 5e-3)
         if "_rho_" in path:   # never tighter than twice the reference's own fp32-vs-fp64 distance (7e-4 for the centres)
             tol = max(tol, 2.0 * _relmax(ref32, ref64))
         assert _relmax(got32, ref64) <= tol, key
