@@ -90,7 +90,7 @@ constexpr int NCH = 64;         // row chunks a large Gaussian is split into in 
 constexpr int FUSED_CELLS_HOST = 256 * 17;   // = FUSED_CELLS (k_bin<true>): grids up to this many classes never run a scan kernel
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y, [2]=largest cell count,
                                 //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut),
-                                //   [6]=largest count of a 4 x 4 block of cells (k_block_max),
+                                //   [6]=largest count of a 4 x 4 block of cells (block_count_max),
                                 //   [8],[9]=REACH in x, y: the half-extents the render kernels search with -- words 0, 1 shrunk to the
                                 //   windows' cutoff tau' where no window is capped by the dmax box (reach_of), raised again (atomicMax)
                                 //   by every Gaussian that kept its conservative window
@@ -105,7 +105,7 @@ struct Params {
                      // whose dmax box can cover one pixel <= (largest cell count) * adapt_cells + (large class); 0: kcut everywhere
     float cap_px_x, cap_px_y;  // the dmax box in pixels (smallest over the samples of a batch): a class extent below it means
                      // no Gaussian's window is capped by the box, so all of them shrink with the cutoff (reach_of)
-    float adapt_cells4; // > 0: the same bound counted in blocks of 4 x 4 cells (k_block_max; sparse cells on large grids): K is
+    float adapt_cells4; // > 0: the same bound counted in blocks of 4 x 4 cells (block_count_max; sparse cells on large grids): K is
                      // the smaller of the two
     int ncx, ncy, ncells;
     unsigned flags;  // GSASR_FLAG_*
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int lane = threadIdx.x & 63;
     // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
     for (int k = i; k < P.ncells + 1 + NDEAD; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
-    if (i == 0) V.hdr[2] = V.hdr[6] = V.hdr[8] = V.hdr[9] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / k_block_max
+    if (i == 0) V.hdr[2] = V.hdr[6] = V.hdr[8] = V.hdr[9] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / block_count_max
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
@@ -705,6 +705,23 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     }
 }
 
+// adapt_kcut's second granularity: the largest number of Gaussians binned in one aligned block of 4 x 4 cells, straight
+// from the histogram (final once k_classify is done) -- block `b` of the grid's ceil(ncx/4) x ceil(ncy/4), one per thread
+// of whatever scan kernel runs anyway (no launch of its own); one atomicMax per wave.
+__device__ __forceinline__ void block_count_max(int ncx, int ncy, int b, const unsigned *__restrict__ count, unsigned *hdr)
+{
+    const int nbx = (ncx + 3) >> 2, nby = (ncy + 3) >> 2;
+    unsigned sum = 0u;
+    if (b < nbx * nby) {
+        const int bx = b % nbx, by = b / nbx;
+        const int x0 = bx * 4, x1 = min(x0 + 4, ncx);
+        for (int r = by * 4; r < min(by * 4 + 4, ncy); ++r)
+            for (int xx = x0; xx < x1; ++xx) sum += count[r * ncx + xx];
+    }
+    sum = wave_max_u32(sum);
+    if ((threadIdx.x & 63) == 0 && sum) atomicMax(&hdr[6], sum);
+}
+
 __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *__restrict__ count,
                                                unsigned *__restrict__ start, int nblk,
                                                const unsigned *__restrict__ blockmax, unsigned *__restrict__ hdr)
@@ -712,6 +729,8 @@ __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *
     __shared__ unsigned part[1024];
     __shared__ unsigned smax[3][16];
     const int t = threadIdx.x;
+    if (P.adapt_cells4 > 0.f)
+        for (int b0 = 0; b0 < ((P.ncx + 3) >> 2) * ((P.ncy + 3) >> 2); b0 += 1024) block_count_max(P.ncx, P.ncy, b0 + t, count, hdr);
     // (a) max half-extents over the classify blocks -> plan header
     unsigned mx = 0, my = 0;
     for (int k = t; k < nblk; k += 1024) {
@@ -760,11 +779,14 @@ constexpr int SCAN_CHUNK = 4096;
 __global__ __launch_bounds__(1024) void k_scan_local(int ncells, int n, const unsigned *__restrict__ count,
                                                      unsigned *__restrict__ start, unsigned *__restrict__ tot,
                                                      int nblk, const unsigned *__restrict__ blockmax,
-                                                     unsigned *__restrict__ hdr)
+                                                     unsigned *__restrict__ hdr, int ncx, int ncy, int want_blocks)
 {
     __shared__ unsigned part[1024];
     __shared__ unsigned smax[2][16];
     const int t = threadIdx.x;
+    if (want_blocks)   // (a chunk of 4096 cells holds 256 blocks of 16: the first wave quartet's worth of threads)
+        for (int b0 = (int)blockIdx.x * 1024; b0 < ((ncx + 3) >> 2) * ((ncy + 3) >> 2); b0 += (int)gridDim.x * 1024)
+            block_count_max(ncx, ncy, b0 + t, count, hdr);      // (block-uniform loop: the wave reduction inside needs every lane)
     if (blockIdx.x == 0) {
         unsigned mx = 0, my = 0;
         for (int k = t; k < nblk; k += 1024) {
@@ -829,22 +851,6 @@ __global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__
     for (int k = 0; k < 4; ++k)
         if (base + k < n) start[base + k] += off;
     if ((int)blockIdx.x == nchunks - 1 && t == 0) start[n] = off + tot[blockIdx.x];
-}
-
-// Largest number of Gaussians binned in one aligned block of 4 x 4 cells (adapt_kcut's second granularity), from the finished
-// scan: one thread per block, eight reads of cell_start.
-__global__ __launch_bounds__(256) void k_block_max(int ncx, int ncy, const unsigned *__restrict__ start, unsigned *__restrict__ hdr)
-{
-    const int nbx = (ncx + 3) >> 2, nby = (ncy + 3) >> 2;
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    unsigned sum = 0u;
-    if (b < nbx * nby) {
-        const int bx = b % nbx, by = b / nbx;
-        const int x0 = bx * 4, x1 = min(x0 + 4, ncx);
-        for (int r = by * 4; r < min(by * 4 + 4, ncy); ++r) sum += start[r * ncx + x1] - start[r * ncx + x0];
-    }
-    sum = wave_max_u32(sum);
-    if ((threadIdx.x & 63) == 0 && sum) atomicMax(&hdr[6], sum);
 }
 
 // counting-sort placement (slot = cell start + rank, no atomics) fused with record packing
@@ -3112,13 +3118,9 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
         } else {
             const int nchunks = (ncls + SCAN_CHUNK - 1) / SCAN_CHUNK;
             hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, L.ncells, ncls, V.cell_count, V.cell_start,
-                               V.scan_tot, nblk, V.blockmax, V.hdr);
+                               V.scan_tot, nblk, V.blockmax, V.hdr, L.ncx, L.ncy, (int)(P.adapt_cells4 > 0.f));
             hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, P, ncls, V.cell_start, V.scan_tot, nchunks,
                                V.cell_count, V.hdr);
-        }
-        if (P.adapt_cells4 > 0.f && dims->s > 0) {
-            const int nb4 = ((L.ncx + 3) / 4) * ((L.ncy + 3) / 4);
-            hipLaunchKernelGGL(k_block_max, dim3((unsigned)((nb4 + 255) / 256)), dim3(256), 0, st, L.ncx, L.ncy, V.cell_start, V.hdr);
         }
         if (dims->s > 0)
             hipLaunchKernelGGL(k_bin<false>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);
