@@ -62,7 +62,11 @@ namespace {
 
 constexpr int CELL = 16;        // binning cell side in pixels
 constexpr int CELL_SHIFT = 4;
-constexpr int NDEAD = 64;       // "dead" (nothing to draw) sub-classes: spreads the classify atomics of off-band Gaussians
+constexpr int NDEAD = 128;      // "dead" (nothing to draw) sub-classes: spreads the classify atomics of off-band Gaussians.
+                                // Sub-classes 0..63: Gaussians that add EXACTLY nothing to this plan's pixels (non-finite; the
+                                // bounded op's box misses the rows); 64..127: "near dead" -- the support does not reach, yet every
+                                // term it would have added (< exp(-tau) each) is a skipped term the cutoff's bound must count
+constexpr int NDEAD_NEAR = 64;
 constexpr int SUBX = 8;         // forward sub-tile: 8 px wide x 16 px tall per wave64 (2 px per lane)
 constexpr int SUBY = 16;
 constexpr int SUBX_SHIFT = 3, SUBY_SHIFT = 4;
@@ -90,7 +94,7 @@ constexpr int NCH = 64;         // row chunks a large Gaussian is split into in 
 constexpr int FUSED_CELLS_HOST = 256 * 17;   // = FUSED_CELLS (k_bin<true>): grids up to this many classes never run a scan kernel
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y, [2]=largest cell count,
                                 //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut),
-                                //   [6]=largest count of a 4 x 4 block of cells (block_count_max),
+                                //   [6]=largest count of a 4 x 4 block of cells (block_count_max), [7]=near-dead Gaussians (adapt_kcut (3)),
                                 //   [8],[9]=REACH in x, y: the half-extents the render kernels search with -- words 0, 1 shrunk to the
                                 //   windows' cutoff tau' where no window is capped by the dmax box (reach_of), raised again (atomicMax)
                                 //   by every Gaussian that kept its conservative window
@@ -103,6 +107,9 @@ struct Params {
     float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled (the CONSERVATIVE tau: classes, dead set)
     float adapt_cells;  // > 0: the windows are built with the data-derived cutoff tau' = ln(K / eps) <= tau, K = the most Gaussians
                      // whose dmax box can cover one pixel <= (largest cell count) * adapt_cells + (large class); 0: kcut everywhere
+    int count_words; // words of one parity's counter array (cell counters + extent groups): what k_classify zeroes for the next plan
+    int ext_groups;  // groups of 32 k_classify blocks (PlanView::blockmax)
+    int adapt_ring;  // 1: K also bounded from the SUPPORT (adapt_kcut: cells within the class' largest extent + a geometric tail)
     float cap_px_x, cap_px_y;  // the dmax box in pixels (smallest over the samples of a batch): a class extent below it means
                      // no Gaussian's window is capped by the box, so all of them shrink with the cutoff (reach_of)
     float adapt_cells4; // > 0: the same bound counted in blocks of 4 x 4 cells (block_count_max; sparse cells on large grids): K is
@@ -135,7 +142,9 @@ struct PlanView {
     float *px, *py;         // [w], [h]
     unsigned *key;          // [s] class/cell of Gaussian i
     unsigned *rank;         // [s] position of Gaussian i inside its cell
-    unsigned *blockmax;     // [2*nblk] per-classify-block max half-extents
+    unsigned *blockmax;     // [16 * groups] max half-extents {x, y, -...} of the normal class per GROUP of 32 k_classify blocks, one
+                            //       64-byte line each (atomicMax by the blocks: 64 atomics per line); they live behind the cell
+                            //       counters of this plan's parity, so whoever zeroes those zeroes these
     unsigned *scan_tot;     // [ceil((ncells+1+NDEAD)/4096)] per-chunk totals of the two-pass scan
     float4 *rec;            // [2*s] {x,y,A,B},{C,r,g,b}   (cell order)
     float4 *fin;            // [2*s] backward constants {1/(1-rho^2), 1-rho^2, rho, 1/sx}, {1/sy, -, -, original index}
@@ -163,7 +172,9 @@ __device__ __forceinline__ Geo sample_geo(const Params &P, const PlanView &V, in
 struct Layout {
     size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox, off_win, off_part, off_qspan;
     int part_k;
-    size_t count_bytes;  // one array of per-cell counters (there are two, used alternately: GSASR_FLAG_PARITY)
+    size_t count_bytes;  // one array of per-cell counters + extent groups (there are two, used alternately: GSASR_FLAG_PARITY)
+    size_t ext_off_words; // where the extent groups start inside such an array
+    int ext_groups;
     size_t total;
     int ncx, ncy, ncells;
 };
@@ -259,7 +270,9 @@ Layout make_layout(const gsasr_dims *d, int part_k = -1)
     const size_t ncls = (size_t)L.ncells + 1 + NDEAD, s = (size_t)d->s;
     size_t o = 0;
     L.off_hdr = o;    o += HDR_WORDS * 4;
-    L.count_bytes = align_up(ncls * 4, 256);
+    L.ext_groups = (classify_blocks(d) + 31) / 32;
+    L.ext_off_words = align_up(ncls, 16);
+    L.count_bytes = align_up((L.ext_off_words + 16 * (size_t)L.ext_groups) * 4, 256);
     L.off_count = o;  o += 2 * L.count_bytes;
     L.off_geo = o;    o += GSASR_MAX_BATCH * 16;   // (outside the zeroed region: written once by k_batch_geo)
     L.off_start = o;  o += align_up((ncls + 1) * 4, 256);
@@ -267,7 +280,7 @@ Layout make_layout(const gsasr_dims *d, int part_k = -1)
     L.off_py = o;     o += align_up((size_t)d->h * 4, 256);
     L.off_key = o;    o += align_up(s * 4, 256);
     L.off_rank = o;   o += align_up(s * 4, 256);
-    L.off_bmax = o;   o += align_up((size_t)classify_blocks(d) * 8, 256);
+    L.off_bmax = o;   // (unused since round 4: the per-block maxima became per-group maxima inside the counter arrays)
     L.off_stot = o;   o += align_up((ncls / 4096 + 2) * 4, 256);
     L.off_rec = o;    o += align_up(s * 32, 256);
     // (a forward-only plan -- inference -- carries none of the backward's records)
@@ -297,7 +310,7 @@ PlanView make_view(const Layout &L, void *ws, unsigned flags = 0u)
     V.py = (float *)(b + L.off_py);
     V.key = (unsigned *)(b + L.off_key);
     V.rank = (unsigned *)(b + L.off_rank);
-    V.blockmax = (unsigned *)(b + L.off_bmax);
+    V.blockmax = V.cell_count + L.ext_off_words;
     V.scan_tot = (unsigned *)(b + L.off_stot);
     V.rec = (float4 *)(b + L.off_rec);
     V.fin = (float4 *)(b + L.off_fin);
@@ -360,6 +373,9 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     // data-derived cutoff (adapt_kcut): the bounded op under the adaptive default only -- an explicit tau (per call, per
     // process, environment) is used as given, and the unbounded op has no box to count in
     P.adapt_cells = P.adapt_cells4 = 0.f;
+    P.adapt_ring = 0;
+    P.count_words = (int)(L.count_bytes / 4);
+    P.ext_groups = L.ext_groups;
     {
         double wmin = d->w, hmin = d->h;
         if (d->batch > 1) {
@@ -371,7 +387,9 @@ Params make_params(const gsasr_dims *d, const Layout &L)
         P.cap_px_x = P.bounded ? (float)((double)d->dmax * 0.5 * (wmin - 1.0)) : INFINITY;
         P.cap_px_y = P.bounded ? (float)((double)d->dmax * 0.5 * (hmin - 1.0)) : INFINITY;
     }
-    if (P.bounded && ((d->cutoff == 0.f && default_cutoff() == 0.f) || (d->flags & GSASR_FLAG_CUTOFF_CAP)) && P.kcut > 0.f && adapt_env()) {
+    const bool adapt = ((d->cutoff == 0.f && default_cutoff() == 0.f) || (d->flags & GSASR_FLAG_CUTOFF_CAP)) && P.kcut > 0.f && adapt_env();
+    P.adapt_ring = adapt && tau >= 16.f;       // (the tail constant of adapt_kcut is derived for tau >= 16)
+    if (P.bounded && adapt) {
         const int B = batch_of(d);
         const double dpx = (double)d->dmax * 0.5 * (double)(d->w - 1), dpy = (double)d->dmax * 0.5 * (double)((B > 1 ? d->slot : d->h) - 1);
         const double cx = std::ceil(2.0 * std::floor(dpx + 1.02) / (double)CELL) + 1.0, cy = std::ceil(2.0 * std::floor(dpy + 1.02) / (double)CELL) + 1.0;
@@ -458,6 +476,7 @@ struct Box {
     int c0, c1, r0, r1;  // inclusive pixel-index window, clipped to the image and the owned rows
     float ex, ey;        // half-extents in pixels (before clipping)
     int cls;             // 0 normal, 1 large, 2 dead
+    bool near;           // dead, but the op would add its (tiny) tails to pixels of these rows: adapt_kcut's kind (3)
 };
 
 constexpr double WINDOW_EPS = 0.02;  // px; covers every rounding between these windows and the kernels' float tests
@@ -488,19 +507,49 @@ __device__ __forceinline__ Box gaussian_box(float sx, float sy, float x, float y
     b.c1 = (int)fmin(hix, (double)(g.w - 1));
     b.r0 = (int)fmax(loy, (double)max(P.row0, g.base));
     b.r1 = (int)fmin(hiy, (double)(min(P.row1, g.base + g.h) - 1));
-    if (!finite || b.c0 > b.c1 || b.r0 > b.r1 || !(hix >= 0.0) || !(hiy >= (double)g.base))
+    b.near = false;
+    if (!finite || b.c0 > b.c1 || b.r0 > b.r1 || !(hix >= 0.0) || !(hiy >= (double)g.base)) {
         b.cls = 2;
-    else if (!(b.ex <= (float)RCAP_PX && b.ey <= (float)RCAP_PX))
+        if (finite) {   // unbounded op: every pixel gets a term of it; bounded op: the pixels inside its dmax box do
+            const double rmin = (double)max(P.row0, g.base), rmax = (double)(min(P.row1, g.base + g.h) - 1);
+            const double dpx = (double)P.dmax * hx + 1.0, dpy = (double)P.dmax * hy + 1.0;    // (+1 px: on the counting side)
+            b.near = !P.bounded || (cxp - dpx <= (double)(g.w - 1) && cxp + dpx >= 0.0 && cyp - dpy <= rmax && cyp + dpy >= rmin);
+        }
+    } else if (!(b.ex <= (float)RCAP_PX && b.ey <= (float)RCAP_PX))
         b.cls = 1;
     else
         b.cls = 0;
     return b;
 }
 
+// wave64 reductions of an unsigned, result uniform: four DPP row rotations leave every lane of a row of 16 with its row's
+// result (VALU only; a __shfl_xor butterfly is six ds_bpermute round trips through the LDS pipe, on kernels whose run time is
+// their dependent chain), the four rows are combined on the scalar unit.
+template <int N>
+__device__ __forceinline__ unsigned dpp_row_ror(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
+    v = max(v, dpp_row_ror<1>(v));
+    v = max(v, dpp_row_ror<2>(v));
+    v = max(v, dpp_row_ror<4>(v));
+    v = max(v, dpp_row_ror<8>(v));
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ unsigned wave_add_u32(unsigned v)
+{
+    v += dpp_row_ror<1>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<8>(v);
+    return ((unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16)) +
+           ((unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48));
 }
 
 // wave64 sum; result valid in every lane (butterfly)
@@ -510,28 +559,55 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// The data-derived support cutoff (bounded op, adaptive default only).  A term is skipped only OUTSIDE a Gaussian's
-// window, and in the bounded op (gs_cuda_dmax/gs.cu:41-50) only a Gaussian whose dmax box covers the pixel contributes at
-// all: at most K = max over pixels of #{s : |px - x_s| <= dmax and |py - y_s| <= dmax} terms can be skipped on one pixel,
-// each below exp(-tau') times its colour, so tau' = ln(K / eps) keeps the bound `eps * max|colour|` per pixel of the
-// conservative tau = ln(s / eps) -- for ANY input: K is bounded from the plan's own histogram.  A Gaussian of the normal
-// class is binned by the cell of its (clamped) centre and can cover a pixel only from a cell within
-// m = floor(dmax_px + 1.02) pixels of it in x and in y (the centre is binned by its floor, the pixel table is the grid to
-// < 0.01 px), i.e. from the cells that 2m + 1 consecutive pixels touch: at most Cx = ceil(2 mx / 16) + 1 by Cy, so
-//     K <= (largest cell count) * Cx * Cy + (size of the large class)                        [adapt_cells = Cx * Cy]
-// (Gaussians stacked on one spot make the largest count ~s and tau' = tau: nothing is lost on adversarial input.)
-// The log is the hardware's (1 ulp): 1e-3 is added to tau', a factor 1.001 on the side of the bound.
-__device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, unsigned nlarge, float &tau, unsigned &K,
-                                            unsigned maxblock = 0u)
+// The data-derived support cutoff (adaptive default; GSASR_FLAG_CUTOFF_CAP).  The windows are built with tau' <= tau (the
+// conservative cutoff k_classify used) such that, on any pixel p of the rows rendered and for ANY input,
+//     sum of the skipped terms  <  eps * max|colour|.
+// A term is skipped when p lies outside its Gaussian's window.  Three kinds of Gaussians can lose terms at p:
+//   (1) LIVE ones binned near p.  Each skipped term is < exp(-tau') |colour|.  How many there can be is bounded from the
+//       plan's own histogram, two ways, the smaller count wins (K_live = min(box, ring) * (largest cell count) + large class):
+//       box  (bounded op, gs_cuda_dmax/gs.cu:41-50: only a Gaussian whose dmax box covers p adds anything): a normal-class
+//            Gaussian is binned by the cell of its (clamped, floored) centre and covers p only from the cells that the
+//            2m + 1 pixels around p touch, m = floor(dmax_px + 1.02): Cx * Cy cells, C = ceil(2m / 16) + 1
+//            [adapt_cells; on large sparse grids the same count in aligned 4 x 4-cell blocks, adapt_cells4];
+//       ring (either op): with E = the class' largest half-extent under tau (header words 0, 1: <= 130 px) and
+//            j0 = ceil(E / 16) + 1, a Gaussian binned at Chebyshev cell distance j >= j0 from p's cell is at least
+//            16 (j - 1) >= E + 16 (j - j0) pixels away along one axis, where its value is at most
+//            exp(-tau (d / E)^2) <= exp(-tau) q^(j - j0), q = exp(-32 tau / E) <= 0.02 (marginal of the bivariate normal;
+//            a Gaussian whose window is capped by the dmax box adds exactly nothing beyond the cap).  The 8 j cells of ring j,
+//            summed over j >= j0, therefore add at most 9 j0 cells' worth of exp(-tau) <= exp(-tau') terms:
+//            (2 j0 - 1)^2 + 9 j0 cells in all.  At x8 this is 85 cells against the 2 809 of the box.
+//   (2) the LARGE class (extent > 128 px): counted in full.
+//   (3) NEAR-DEAD ones: classified dead because their support (under tau) does not reach the rows, though the op would
+//       add their tails (bounded op: the dmax box does reach; unbounded op: every dead Gaussian).  Each term is
+//       < exp(-tau); k_classify counts them in their own sub-classes (n_near) and the budget left for (1) + (2) is
+//       eps - n_near exp(-tau)  [= eps (1 - n_near / s) under the adaptive tau = ln(s / eps)].
+//   Gaussians whose box misses the rows (bounded op) and non-finite ones add exactly nothing, skipped or not.
+// tau' = ln(K_live / budget) + 1e-3 (the log is the hardware's: 1 ulp), clamped to [16, tau].  Gaussians stacked on one spot
+// make the largest count ~s and tau' = tau: nothing is lost on adversarial input (tests/test_adaptive_cutoff.py).
+__device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, unsigned nlarge, unsigned nnear, unsigned ext,
+                                            float &tau, unsigned &K, unsigned maxblock = 0u)
 {
     const float tau_cap = 0.5f * P.kcut * P.kcut;
-    if (!(P.adapt_cells > 0.f)) { tau = tau_cap; K = 0u; return P.kcut; }
-    float Kn = (float)maxcount * P.adapt_cells;
-    if (P.adapt_cells4 > 0.f) Kn = fminf(Kn, (float)maxblock * P.adapt_cells4);   // the same pixels' boxes, counted in 4 x 4-cell blocks
+    tau = tau_cap;
+    K = 0u;
+    if (!(P.adapt_cells > 0.f) && !P.adapt_ring) return P.kcut;
+    float Kn = INFINITY;
+    if (P.adapt_cells > 0.f) {
+        Kn = (float)maxcount * P.adapt_cells;
+        if (P.adapt_cells4 > 0.f) Kn = fminf(Kn, (float)maxblock * P.adapt_cells4);   // the same pixels' boxes, in 4 x 4-cell blocks
+    }
+    if (P.adapt_ring) {
+        const float j0 = ceilf((float)min(ext, 130u) * (1.f / CELL)) + 1.f;
+        const float cells = fminf((2.f * j0 - 1.f) * (2.f * j0 - 1.f) + 9.f * j0, (float)P.ncells);
+        Kn = fminf(Kn, (float)maxcount * cells * (1.f + 1e-6f));
+    }
     const float Kf = fmaxf(Kn + (float)nlarge, 1.f);
     K = (unsigned)fminf(Kf, 4.0e9f);
-    const float t = fmaxf(__log2f(Kf * (1.f / GSASR_SPLAT_DEFAULT_EPS)) * 0.69314718f + 1e-3f, 16.f);
-    if (!(t < tau_cap)) { tau = tau_cap; return P.kcut; }
+    // what the near-dead tails leave of eps; with less than a quarter left the conservative cutoff stays
+    const float budget = GSASR_SPLAT_DEFAULT_EPS - (float)nnear * __builtin_amdgcn_exp2f(-tau_cap * 1.44269504f) * (1.f + 1e-5f);
+    if (!(budget >= 0.25f * GSASR_SPLAT_DEFAULT_EPS)) return P.kcut;
+    const float t = fmaxf(__log2f(Kf / budget) * 0.69314718f + 1e-3f, 16.f);
+    if (!(t < tau_cap)) return P.kcut;
     tau = t;
     return fminf(sqrtf(2.f * t) * (1.f + 1e-6f), P.kcut);
 }
@@ -611,8 +687,8 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
-    for (int k = i; k < P.ncells + 1 + NDEAD; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
-    if (i == 0) V.hdr[2] = V.hdr[6] = V.hdr[8] = V.hdr[9] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / block_count_max
+    for (int k = i; k < P.count_words; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
+    if (i == 0) V.hdr[2] = V.hdr[6] = V.hdr[7] = V.hdr[8] = V.hdr[9] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / block_count_max
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
@@ -656,7 +732,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
         if (b.cls == 2) {
             // NDEAD counters instead of one: a row band of a large image sees most of the Gaussians here, and one
             // returning atomic per wave on a single word serialises (203 us for 1 M Gaussians, 7/8 dead)
-            key = (unsigned)P.ncells + 1u + (unsigned)((i >> 6) & (NDEAD - 1));
+            key = (unsigned)P.ncells + 1u + (unsigned)((i >> 6) & (NDEAD_NEAR - 1)) + (b.near ? (unsigned)NDEAD_NEAR : 0u);
         } else if (b.cls == 1) {
             key = (unsigned)P.ncells;
         } else {
@@ -694,14 +770,18 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
         V.key[i] = key;
         V.rank[i] = rank;
     }
-    // per-block max half-extent of the normal class -> blockmax[] (reduced by k_scan; no contended atomics)
+    // per-block max half-extent of the normal class -> one atomicMax pair per block on its group's line (32 blocks per line:
+    // a single word for all blocks serialises at ~12 ns per atomic; the readers then reduce groups, not blocks)
     rx = wave_max_u32(rx);
     ry = wave_max_u32(ry);
     if (lane == 0) { s_rx[threadIdx.x >> 6] = rx; s_ry[threadIdx.x >> 6] = ry; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        V.blockmax[2 * blockIdx.x + 0] = max(max(s_rx[0], s_rx[1]), max(s_rx[2], s_rx[3]));
-        V.blockmax[2 * blockIdx.x + 1] = max(max(s_ry[0], s_ry[1]), max(s_ry[2], s_ry[3]));
+        const unsigned mx = max(max(s_rx[0], s_rx[1]), max(s_rx[2], s_rx[3])), my = max(max(s_ry[0], s_ry[1]), max(s_ry[2], s_ry[3]));
+        if (mx | my) {
+            atomicMax(&V.blockmax[16 * (blockIdx.x >> 5) + 0], mx);
+            atomicMax(&V.blockmax[16 * (blockIdx.x >> 5) + 1], my);
+        }
     }
 }
 
@@ -734,8 +814,8 @@ __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *
     // (a) max half-extents over the classify blocks -> plan header
     unsigned mx = 0, my = 0;
     for (int k = t; k < nblk; k += 1024) {
-        mx = max(mx, blockmax[2 * k + 0]);
-        my = max(my, blockmax[2 * k + 1]);
+        mx = max(mx, blockmax[16 * k + 0]);
+        my = max(my, blockmax[16 * k + 1]);
     }
     mx = wave_max_u32(mx);
     my = wave_max_u32(my);
@@ -790,8 +870,8 @@ __global__ __launch_bounds__(1024) void k_scan_local(int ncells, int n, const un
     if (blockIdx.x == 0) {
         unsigned mx = 0, my = 0;
         for (int k = t; k < nblk; k += 1024) {
-            mx = max(mx, blockmax[2 * k + 0]);
-            my = max(my, blockmax[2 * k + 1]);
+            mx = max(mx, blockmax[16 * k + 0]);
+            my = max(my, blockmax[16 * k + 1]);
         }
         mx = wave_max_u32(mx);
         my = wave_max_u32(my);
@@ -880,7 +960,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             c[k] = q < P.ncells + 1 + NDEAD ? V.cell_count[q] : 0u;
         }
     }
-    const unsigned nlarge = FUSED_SCAN && P.adapt_cells > 0.f ? V.cell_count[P.ncells] : 0u;
+    const bool adapting = P.adapt_cells > 0.f || P.adapt_ring != 0;
+    const unsigned nlarge = FUSED_SCAN && adapting ? V.cell_count[P.ncells] : 0u;
     unsigned key = 0u, rnk = 0u;
     float4 recA = make_float4(0.f, 0.f, 0.f, 0.f), recB = recA, finA = recA, finB = recA;
     uint4 bb = make_uint4(0u, 0u, 0u, 0u), bc = bb;
@@ -899,28 +980,50 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     // The cutoff the windows are built with (adapt_kcut): from the largest cell count -- every block reduces the histogram it
     // holds anyway (FUSED_SCAN), or reads what the scan kernels left in the header.
     float kc = P.kcut, kc_tau = 0.f;
-    unsigned kc_K = 0u, kc_mc = 0u;
+    unsigned kc_K = 0u, kc_mc = 0u, kc_nn = 0u;
     if (FUSED_SCAN) {
-        if (P.adapt_cells > 0.f) {
-            unsigned mc = 0u;
+        if (adapting) {
+            // block-wide: the largest cell count, the near-dead count (both from the histogram this block holds anyway) and the
+            // class' largest extent (every block reduces k_classify's per-block maxima: block 0 alone publishes the header
+            // further down, too late for the windows)
+            unsigned mc = 0u, nn = 0u, ext = 0u;
 #pragma unroll
-            for (int k = 0; k < FUSED_PER_THREAD; ++k) mc = (int)threadIdx.x * FUSED_PER_THREAD + k < P.ncells ? max(mc, c[k]) : mc;
+            for (int k = 0; k < FUSED_PER_THREAD; ++k) {
+                const int q = (int)threadIdx.x * FUSED_PER_THREAD + k;
+                mc = q < P.ncells ? max(mc, c[k]) : mc;
+                nn += q >= P.ncells + 1 + NDEAD_NEAR ? c[k] : 0u;      // (c[k] = 0 past the last class)
+            }
+            if (P.adapt_ring) {
+                for (int k = (int)threadIdx.x; k < nblk; k += 256) ext = max(ext, max(V.blockmax[16 * k], V.blockmax[16 * k + 1]));
+            }
             mc = wave_max_u32(mc);
-            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mc;
+            ext = wave_max_u32(ext);
+            nn = wave_add_u32(nn);
+            if ((threadIdx.x & 63) == 0) {
+                s_part[threadIdx.x >> 6] = mc;
+                s_part[4 + (threadIdx.x >> 6)] = nn;
+                s_part[8 + (threadIdx.x >> 6)] = ext;
+            }
             __syncthreads();
             mc = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
+            nn = (s_part[4] + s_part[5]) + (s_part[6] + s_part[7]);
+            ext = max(max(s_part[8], s_part[9]), max(s_part[10], s_part[11]));
             __syncthreads();   // (s_part is reused by the scan below)
-            kc = adapt_kcut(P, mc, nlarge, kc_tau, kc_K);
+            kc = adapt_kcut(P, mc, nlarge, nn, ext, kc_tau, kc_K);
             kc_mc = mc;
+            kc_nn = nn;
         } else {
             kc_tau = 0.5f * P.kcut * P.kcut;
         }
-    } else {   // (the scan kernels left the maxima in the header)
-        kc = adapt_kcut(P, V.hdr[2], V.cell_count[P.ncells], kc_tau, kc_K, V.hdr[6]);
+    } else {   // (the scan kernels left the maxima in the header and the finished scan)
+        const int ncls = P.ncells + 1 + NDEAD;
+        kc = adapt_kcut(P, V.hdr[2], V.cell_start[P.ncells + 1] - V.cell_start[P.ncells],
+                        V.cell_start[ncls] - V.cell_start[P.ncells + 1 + NDEAD_NEAR], max(V.hdr[0], V.hdr[1]), kc_tau, kc_K, V.hdr[6]);
         if (i == 0) {
             V.hdr[3] = __float_as_uint(kc);
             V.hdr[4] = __float_as_uint(kc_tau);
             V.hdr[5] = kc_K;
+            V.hdr[7] = V.cell_start[ncls] - V.cell_start[P.ncells + 1 + NDEAD_NEAR];
             atomicMax(&V.hdr[8], reach_of(V.hdr[0], kc, P.kcut, P.cap_px_x));
             atomicMax(&V.hdr[9], reach_of(V.hdr[1], kc, P.kcut, P.cap_px_y));
         }
@@ -1095,8 +1198,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             for (int k = t; k <= ncls; k += 256) V.cell_start[k] = s_start[k];
             unsigned mx = 0, my = 0;
             for (int k = t; k < nblk; k += 256) {
-                mx = max(mx, V.blockmax[2 * k + 0]);
-                my = max(my, V.blockmax[2 * k + 1]);
+                mx = max(mx, V.blockmax[16 * k + 0]);
+                my = max(my, V.blockmax[16 * k + 1]);
             }
             mx = wave_max_u32(mx);
             my = wave_max_u32(my);
@@ -1114,6 +1217,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 V.hdr[3] = __float_as_uint(kc);
                 V.hdr[4] = __float_as_uint(kc_tau);
                 V.hdr[5] = kc_K;
+                V.hdr[7] = kc_nn;
             }
         }
     }
@@ -3110,20 +3214,20 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
     const unsigned nbin = (unsigned)((dims->s + 255) / 256);
     if (ncls <= FUSED_CELLS && dims->s > 0) {
         // small grid: k_bin rebuilds the scan per block (no separate scan launch)
-        hipLaunchKernelGGL(k_bin<true>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);
+        hipLaunchKernelGGL(k_bin<true>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
     } else {
         if (ncls <= 2 * SCAN_CHUNK) {
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P, ncls, V.cell_count, V.cell_start, nblk, V.blockmax,
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P, ncls, V.cell_count, V.cell_start, L.ext_groups, V.blockmax,
                                V.hdr);
         } else {
             const int nchunks = (ncls + SCAN_CHUNK - 1) / SCAN_CHUNK;
             hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, L.ncells, ncls, V.cell_count, V.cell_start,
-                               V.scan_tot, nblk, V.blockmax, V.hdr, L.ncx, L.ncy, (int)(P.adapt_cells4 > 0.f));
+                               V.scan_tot, L.ext_groups, V.blockmax, V.hdr, L.ncx, L.ncy, (int)(P.adapt_cells4 > 0.f));
             hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, P, ncls, V.cell_start, V.scan_tot, nchunks,
                                V.cell_count, V.hdr);
         }
         if (dims->s > 0)
-            hipLaunchKernelGGL(k_bin<false>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, nblk);
+            hipLaunchKernelGGL(k_bin<false>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
     }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;

@@ -123,17 +123,28 @@ typedef struct gsasr_dims {
 
 #define GSASR_MAX_BATCH 64
 
-/* Default tau is ADAPTIVE: tau = ln(s / GSASR_SPLAT_DEFAULT_EPS), clamped to [16, 104].  Every skipped
- * term is < exp(-tau) times its colour, and at most s terms can be skipped on one pixel, so the image error is
- * < s * exp(-tau) * max|colour| = 1e-5 * max|colour| per pixel for ANY input: a bound RELATIVE to the colour scale.
- * After the host prologue (sigmoid * alpha) colours are <= 1 and the bound is 1e-5 absolute -- an order below the
- * 1e-4 parity tolerance and at the level of fp32 summation noise; the raw op accepts any float as a colour, and
- * there the bound scales with it exactly as the fp32 rounding of the sum itself does
- * (tests/test_hip_parity.py::test_raw_op_colours_far_above_one).  In practice the
- * skipped mass is ~1e-9 because terms decay further outside the ellipse.  Gradients lose the same tail:
- * relative error ~ tau * exp(-tau) < 1e-8.  (s = 65 536 -> tau = 22.6; s = 2^20 -> tau = 25.4.)
+/* Default tau is ADAPTIVE and keeps the sum of the skipped terms on any pixel below
+ * GSASR_SPLAT_DEFAULT_EPS * max|colour| for ANY input: a bound RELATIVE to the colour scale.  After the host prologue
+ * (sigmoid * alpha) colours are <= 1 and the bound is 1e-5 absolute -- an order below the 1e-4 parity tolerance and at the
+ * level of fp32 summation noise; the raw op accepts any float as a colour, and there the bound scales with it exactly as the
+ * fp32 rounding of the sum itself does (tests/test_hip_parity.py::test_raw_op_colours_far_above_one).  Gradients lose the
+ * same tail: relative error ~ tau * exp(-tau) < 1e-7.
+ *   conservative   tau = ln(s / eps), clamped to [16, 104]: every skipped term is < exp(-tau) times its colour and at most s
+ *                  terms can be skipped on one pixel.  Classes, the dead set and the halo selection of the multi-GPU exchange
+ *                  use it.  (s = 65 536 -> 22.6; s = 2^20 -> 25.4.)
+ *   data-derived   the WINDOWS are built with tau' = ln(K / budget) <= tau, where K bounds the live Gaussians that can lose
+ *                  a non-negligible term on one pixel and is counted on the device from the plan's own cell histogram:
+ *                  (largest cell count) x (cells that can hold such a Gaussian) + (large class), the cells being the
+ *                  smaller of (a) those a dmax box around a pixel touches (bounded op: utils/gs_cuda_dmax/gs.cu:41-50, only
+ *                  a Gaussian whose box covers the pixel adds anything) and (b) those within the class' largest support of
+ *                  the pixel plus 9 cells per ring index for the geometric tail of everything farther (both ops); `budget`
+ *                  is eps minus exp(-tau) for every dead Gaussian whose tails the op would still add to these rows.  Config
+ *                  2: K = 1 092, tau' = 18.5; x8 (config 4): K = 680, tau' = 18.0.  gsasr_plan_cutoff reports both;
+ *                  gsasr_amd/csrc/gsasr_splat.hip (adapt_kcut) has the derivation, tests/test_adaptive_cutoff.py the checks
+ *                  incl. adversarial inputs (everything stacked on one spot: K ~ s, tau' = tau).
  * A fixed tau can be set per call (dims.cutoff) or per process (gsasr_set_default_cutoff / environment
- * GSASR_SPLAT_CUTOFF): tau = 104 (GSASR_SPLAT_EXACT_CUTOFF) skips only terms for which fp32 expf() in the
+ * GSASR_SPLAT_CUTOFF) and is used as given (GSASR_FLAG_CUTOFF_CAP: as an upper bound for the data-derived one):
+ * tau = 104 (GSASR_SPLAT_EXACT_CUTOFF) skips only terms for which fp32 expf() in the
  * reference returns exactly +0 (exp(-104) < 2^-150), i.e. it sums the same set of non-zero terms as the
  * reference; tau < 0 never skips. */
 #define GSASR_SPLAT_DEFAULT_EPS 1e-5f
@@ -281,12 +292,8 @@ GSASR_API float gsasr_get_default_cutoff(void);
 GSASR_API float gsasr_resolve_cutoff(float cutoff, int s);
 
 /* The cutoff the windows of the plan in `workspace` were actually built with (synchronises `stream`; for reports and
- * tests).  For the bounded op under the adaptive default it is DATA-DERIVED: only a Gaussian whose dmax box covers a pixel
- * contributes to it (gs_cuda_dmax/gs.cu:41-50), so at most K = max over pixels of the number of such Gaussians terms can be
- * skipped on one pixel and tau' = ln(K / GSASR_SPLAT_DEFAULT_EPS) <= ln(s / eps) keeps the same 1e-5 * max|colour| bound
- * for any input; K is bounded on the device from the plan's own cell histogram: (largest cell count) x (cells within
- * dmax of a pixel) + (large class).  *k_box = that K (0 when the cutoff is not data-derived: explicit tau, unbounded op,
- * GSASR_SPLAT_ADAPT=0). */
+ * tests): under the adaptive default the data-derived tau' described above, *k_box = its K (0 when the cutoff is not
+ * data-derived: explicit tau without GSASR_FLAG_CUTOFF_CAP, GSASR_SPLAT_ADAPT=0). */
 GSASR_API int gsasr_plan_cutoff(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, void *stream,
                                 float *tau, unsigned *k_box);
 

@@ -1,10 +1,16 @@
-"""The data-derived support cutoff of the bounded op (include/gsasr_splat.h, `gsasr_plan_cutoff`; adapt_kcut in
-gsasr_splat.hip).  Only a Gaussian whose dmax box covers a pixel contributes to it (utils/gs_cuda_dmax/gs.cu:41-50), so
-at most K = max over pixels of the number of such Gaussians terms can be skipped on one pixel and tau' = ln(K / 1e-5)
-keeps the bound `1e-5 * max|colour|` per pixel of the conservative tau = ln(N / 1e-5).  Checked here:
+"""The data-derived support cutoff (include/gsasr_splat.h, `gsasr_plan_cutoff`; adapt_kcut in gsasr_splat.hip).  A term is
+skipped outside its Gaussian's window; tau' = ln(K / budget) <= ln(N / 1e-5) keeps the skipped sum on every pixel below
+`1e-5 * max|colour|` when K bounds the live Gaussians that can lose a non-negligible term there -- counted by the plan from
+its own cell histogram, either as the Gaussians whose dmax box covers the pixel (bounded op, utils/gs_cuda_dmax/gs.cu:41-50)
+or as those binned within the class' largest support of it (+ a geometric tail for everything farther; both ops), the
+smaller of the two -- and `budget` is what the tails of the dead Gaussians whose box still reaches the rows leave of 1e-5.
+Checked here:
 
-  * the K the plan derives from its cell histogram is an upper bound of the true K (brute force on the CPU) and
-    tau' is the logarithm of THAT K -- on GSASR-shaped input it is well below ln(N / 1e-5);
+  * THE GUARANTEE itself, on every case: the default render stays within 1e-5 * max|colour| of the exact one (tau = 104, the
+    reference's set of non-zero fp32 terms);
+  * the K the plan derives is an upper bound of the true count (brute force on the CPU: the smaller of "boxes over a pixel"
+    and "centres within the largest support of a pixel") and tau' is the logarithm of THAT K -- on GSASR-shaped input it is
+    well below ln(N / 1e-5), for the unbounded op too;
   * adversarial input (every Gaussian stacked on one spot, or half of them) cannot break the bound: the image stays
     within 1e-5 * max|colour| of the exact render (tau = 104, the reference's set of non-zero fp32 terms);
   * an explicit cutoff, the process default and the unbounded op keep their cutoff;
@@ -34,11 +40,41 @@ def _t(a, dev):
 
 def _true_k(xy, h, w, dmax):
     """max over pixels of #{s : |px - x_s| <= dmax and |py - y_s| <= dmax} with the kernels' float pixel grid"""
+    if dmax is None:
+        return xy.shape[0]
     px = (2.0 * np.arange(w) / (w - 1) - 1.0).astype(np.float32)
     py = (2.0 * np.arange(h) / (h - 1) - 1.0).astype(np.float32)
     inx = (np.abs(px[None, :] - xy[:, 0:1]) <= np.float32(dmax)).astype(np.float32)   # [N, w]
     iny = (np.abs(py[None, :] - xy[:, 1:2]) <= np.float32(dmax)).astype(np.float32)   # [N, h]
     return int((iny.T @ inx).max())
+
+
+def _true_near(sig, xy, h, w, dmax, tau):
+    """max over pixels of the Gaussians centred within E pixels of it in x and in y, E = the largest half-extent any of
+    them has under `tau` (box-capped): what the plan's ring count must cover"""
+    hx, hy = 0.5 * (w - 1), 0.5 * (h - 1)
+    k = math.sqrt(2.0 * tau)
+    cap = np.inf if dmax is None else dmax
+    ex, ey = np.minimum(cap, k * np.abs(sig[:, 0])) * hx, np.minimum(cap, k * np.abs(sig[:, 1])) * hy
+    live = (ex <= 128.0) & (ey <= 128.0)          # (the large class is counted separately, in full)
+    e = float(max(ex[live].max(initial=0.0), ey[live].max(initial=0.0)))
+    cx, cy = (xy[:, 0].astype(np.float64) + 1.0) * hx, (xy[:, 1].astype(np.float64) + 1.0) * hy
+    inx = (np.abs(np.arange(w)[None, :] - cx[live, None]) <= e).astype(np.float32)
+    iny = (np.abs(np.arange(h)[None, :] - cy[live, None]) <= e).astype(np.float32)
+    return int((iny.T @ inx).max()) + int((~live).sum())
+
+
+def _within_eps_of_exact(sig, xy, col, h, w, dmax, dev, plan=None):
+    """the guarantee: |default render - exact render| <= eps * max|colour| (+ fp32 noise of a differently grouped sum)"""
+    if plan is None:
+        plan, _ = _plan(sig, xy, col, h, w, dmax, dev)
+    img = _image(plan, h, w, dev)
+    exact, _ = _plan(sig, xy, col, h, w, dmax, dev, cutoff=104.0)
+    ref = _image(exact, h, w, dev)
+    err = np.abs(img - ref)
+    lim = EPS * 1.002 * max(1.0, float(np.abs(col).max())) + 5e-6 * np.abs(ref)
+    assert (err <= lim).all(), float((err - lim).max())
+    return float(err.max())
 
 
 def _plan(sig, xy, col, h, w, dmax, dev, cutoff=0.0, flags=0):
@@ -62,8 +98,9 @@ def _synth(h_lr, w_lr, scale, seed, gpp=1):
 
 
 @pytest.mark.parametrize("case", [(64, 64, 4.0, 1, 0.1), (48, 40, 4.0, 16, 0.1), (40, 40, 8.0, 1, 0.05), (256, 256, 4.0, 1, 0.1),
-                                  (96, 96, 12.0, 1, 0.1), (160, 100, 8.0, 1, 0.2)],
-                         ids=["x4", "x4-16-per-lr-px", "x8", "config2", "x12-sparse-cells-block-count", "x8-two-pass-scan"])
+                                  (96, 96, 12.0, 1, 0.1), (160, 100, 8.0, 1, 0.2), (64, 64, 4.0, 1, None), (48, 48, 4.0, 16, 0.5)],
+                         ids=["x4", "x4-16-per-lr-px", "x8", "config2", "x12-sparse-cells", "x8-two-pass-scan", "x4-unbounded-op",
+                              "training-crop-dmax0.5"])
 def test_plan_k_bounds_the_true_k_and_sets_tau(case, dev):
     from gsasr_amd import _cabi
     h_lr, w_lr, scale, gpp, dmax = case
@@ -72,24 +109,24 @@ def test_plan_k_bounds_the_true_k_and_sets_tau(case, dev):
     tau, k = _cabi.plan_cutoff(plan)
     n = sig.shape[0]
     tau_n = _cabi.resolve_cutoff(0.0, n)
-    k_true = _true_k(xy, H, W, dmax)
+    k_true = min(_true_k(xy, H, W, dmax), _true_near(sig, xy, H, W, dmax, tau_n))
     assert k >= k_true, (k, k_true)
     assert 16.0 <= tau <= tau_n + 1e-6
     if tau < tau_n - 1e-6 and tau > 16.0:
-        assert abs(tau - (math.log(k / EPS) + 1e-3)) <= 2e-4 * tau, (tau, k)   # tau' is ln(K / eps) of the K reported
-    if scale >= 12.0:
-        # one Gaussian per 144 px: the largest CELL holds several times the mean, the plan counts in 4 x 4-cell blocks as well
-        assert k <= 4 * k_true, (k, k_true)
+        assert abs(tau - (math.log(k / EPS) + 1e-3)) <= 2e-4 * tau, (tau, k)   # tau' is ln(K / eps) of the K reported (no near-dead here)
     if h_lr >= 256:
-        # BASELINE config 2: the plan's K is within 3x of the true one (cells are 16 px, the box 103) and tau' well under ln(N / eps)
-        assert k <= 3 * k_true and tau <= tau_n - 3.0, (k, k_true, tau, tau_n)
+        # BASELINE config 2: tau well under ln(N / eps) (K is 1 092 cells-worth against a true near count of ~120: cells are 16 px)
+        assert tau <= tau_n - 3.0, (k, k_true, tau, tau_n)
+    if scale >= 8.0:
+        # x8 and up: the dmax box (0.1: 409 px at 8192) is far wider than any support -- the ring count is what binds
+        assert tau <= tau_n - 2.0, (tau, tau_n)
+    _within_eps_of_exact(sig, xy, col, H, W, dmax, dev, plan)
 
 
-def test_explicit_cutoff_process_default_and_unbounded_op_are_not_touched(dev):
+def test_explicit_cutoff_and_process_default_are_not_touched(dev):
     from gsasr_amd import _cabi
     sig, xy, col, H, W = _synth(32, 32, 4.0, 3)
-    n = sig.shape[0]
-    for cutoff, dmax, want in ((32.0, 0.1, 32.0), (104.0, 0.1, 104.0), (0.0, None, _cabi.resolve_cutoff(0.0, n))):
+    for cutoff, dmax, want in ((32.0, 0.1, 32.0), (104.0, 0.1, 104.0), (40.0, None, 40.0)):
         plan, _ = _plan(sig, xy, col, H, W, dmax, dev, cutoff=cutoff)
         tau, k = _cabi.plan_cutoff(plan)
         assert abs(tau - want) <= 1e-4 * want and k == 0, (cutoff, dmax, tau, k)
@@ -181,3 +218,34 @@ def test_gaussians_out_of_reach_under_the_smaller_cutoff(kernel, dev):
         assert np.abs(got - ref_g).max() <= 2e-4 * np.abs(ref_g).max(), name
         # the extra ones: their whole gradient is a tail term (< exp(-tau') of anything), written, not NaN, ~0
         assert np.abs(got[n:]).max() <= 1e-4 * np.abs(ref_g).max() + 1e-6, name
+
+
+@pytest.mark.parametrize("dmax", [0.3, None], ids=["bounded", "unbounded"])
+def test_near_dead_gaussians_are_charged_to_the_budget(dmax, dev):
+    """Gaussians centred just outside the image whose support (under the conservative tau) stops short of the first column:
+    k_classify drops them as dead, yet the op adds their tails (each < exp(-tau)) -- terms the windows' cutoff has to pay
+    for.  They must be counted (tau' rises by ln(1 / (1 - n_near / s))) and the guarantee must hold with thousands of them
+    stacked on one row."""
+    from gsasr_amd import _cabi
+    sig, xy, col, H, W = _synth(48, 48, 4.0, 31)
+    n = sig.shape[0]
+    m = n                                   # as many near-dead as live ones: half of the budget goes to their tails
+    s_tot = n + m
+    tau_c = _cabi.resolve_cutoff(0.0, s_tot)
+    hx = 0.5 * (W - 1)
+    sp = 3.0                                 # sigma in pixels; support = sqrt(2 tau_c) * 3 px
+    d = math.sqrt(2.0 * tau_c) * sp * 1.000002 + 0.05      # px beyond column 0: just out of reach
+    s2, x2, c2 = np.zeros((m, 3), np.float32), np.zeros((m, 2), np.float32), np.ones((m, 3), np.float32)
+    s2[:, 0] = s2[:, 1] = sp / hx
+    x2[:, 0] = -1.0 - d / hx
+    x2[:, 1] = 0.1
+    plan0, _ = _plan(sig, xy, col, H, W, dmax, dev)
+    tau0, k0 = _cabi.plan_cutoff(plan0)
+    sig2, xy2, col2 = np.concatenate([sig, s2]), np.concatenate([xy, x2]), np.concatenate([col, c2])
+    plan, _ = _plan(sig2, xy2, col2, H, W, dmax, dev)
+    tau, k = _cabi.plan_cutoff(plan)
+    assert k == k0                                                   # the dead ones sit in no cell
+    want = math.log(k / (EPS * (1.0 - m / s_tot))) + 1e-3            # budget = eps - m * exp(-tau_c) = eps * (1 - m / s)
+    assert abs(tau - want) <= 3e-4 * want, (tau, want, tau0)
+    err = _within_eps_of_exact(sig2, xy2, col2, H, W, dmax, dev, plan)
+    assert err > 0.0

@@ -120,7 +120,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(hdr, ws, 64, hipMemcpyDeviceToHost));
     float tau_w;
     memcpy(&tau_w, &hdr[4], 4);
-    printf("N=%d %dx%d dmax=%g tau=%g | plan %.1f us  fwd %.1f us  bwd %.1f us | sum(img)=%.6e sum|gs|=%.6e | rx=%u ry=%u reach=%u,%u maxcell=%u tau'=%.3f K=%u\n", n, H, W,
-           dmax, tau, t_plan, t_fwd, t_bwd, si, sg, hdr[0], hdr[1], hdr[8], hdr[9], hdr[2], tau_w, hdr[5]);
+    printf("N=%d %dx%d dmax=%g tau=%g | plan %.1f us  fwd %.1f us  bwd %.1f us | sum(img)=%.6e sum|gs|=%.6e | rx=%u ry=%u reach=%u,%u maxcell=%u tau'=%.3f K=%u near-dead=%u\n", n, H, W,
+           dmax, tau, t_plan, t_fwd, t_bwd, si, sg, hdr[0], hdr[1], hdr[8], hdr[9], hdr[2], tau_w, hdr[5], hdr[7]);
     return 0;
 }
