@@ -574,13 +574,14 @@ __device__ __forceinline__ float wave_sum(float v)
 //            16 (j - 1) >= E + 16 (j - j0) pixels away along one axis, where its value is at most
 //            exp(-tau (d / E)^2) <= exp(-tau) q^(j - j0), q = exp(-32 tau / E) <= 0.02 (marginal of the bivariate normal;
 //            a Gaussian whose window is capped by the dmax box adds exactly nothing beyond the cap).  The 8 j cells of ring j,
-//            summed over j >= j0, therefore add at most 9 j0 cells' worth of exp(-tau) <= exp(-tau') terms:
-//            (2 j0 - 1)^2 + 9 j0 cells in all.  At x8 this is 85 cells against the 2 809 of the box.
+//            summed over j >= j0, therefore add at most 9 j0 cells' worth of terms below exp(-tau) -- the CONSERVATIVE
+//            tau: they are paid from the budget like (3), not counted at exp(-tau') -- and the count is the (2 j0 - 1)^2 cells
+//            of the core.  At x8 that is 49 cells against the 2 809 of the box.
 //   (2) the LARGE class (extent > 128 px): counted in full.
 //   (3) NEAR-DEAD ones: classified dead because their support (under tau) does not reach the rows, though the op would
 //       add their tails (bounded op: the dmax box does reach; unbounded op: every dead Gaussian).  Each term is
 //       < exp(-tau); k_classify counts them in their own sub-classes (n_near) and the budget left for (1) + (2) is
-//       eps - n_near exp(-tau)  [= eps (1 - n_near / s) under the adaptive tau = ln(s / eps)].
+//       eps - (n_near + ring tail) exp(-tau)  [n_near exp(-tau) = eps n_near / s under the adaptive tau = ln(s / eps)].
 //   Gaussians whose box misses the rows (bounded op) and non-finite ones add exactly nothing, skipped or not.
 // tau' = ln(K_live / budget) + 1e-3 (the log is the hardware's: 1 ulp), clamped to [16, tau].  Gaussians stacked on one spot
 // make the largest count ~s and tau' = tau: nothing is lost on adversarial input (tests/test_adaptive_cutoff.py).
@@ -596,15 +597,19 @@ __device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, 
         Kn = (float)maxcount * P.adapt_cells;
         if (P.adapt_cells4 > 0.f) Kn = fminf(Kn, (float)maxblock * P.adapt_cells4);   // the same pixels' boxes, in 4 x 4-cell blocks
     }
+    float far_terms = (float)nnear;    // terms worth < exp(-tau) each, paid from the budget: near-dead Gaussians, ring tails
     if (P.adapt_ring) {
         const float j0 = ceilf((float)min(ext, 130u) * (1.f / CELL)) + 1.f;
-        const float cells = fminf((2.f * j0 - 1.f) * (2.f * j0 - 1.f) + 9.f * j0, (float)P.ncells);
-        Kn = fminf(Kn, (float)maxcount * cells * (1.f + 1e-6f));
+        const float core = fminf((2.f * j0 - 1.f) * (2.f * j0 - 1.f), (float)P.ncells);
+        if ((float)maxcount * core < Kn) {
+            Kn = (float)maxcount * core * (1.f + 1e-6f);
+            far_terms += (float)maxcount * 9.f * j0;
+        }
     }
     const float Kf = fmaxf(Kn + (float)nlarge, 1.f);
     K = (unsigned)fminf(Kf, 4.0e9f);
-    // what the near-dead tails leave of eps; with less than a quarter left the conservative cutoff stays
-    const float budget = GSASR_SPLAT_DEFAULT_EPS - (float)nnear * __builtin_amdgcn_exp2f(-tau_cap * 1.44269504f) * (1.f + 1e-5f);
+    // what the far terms leave of eps; with less than a quarter left the conservative cutoff stays
+    const float budget = GSASR_SPLAT_DEFAULT_EPS - far_terms * __builtin_amdgcn_exp2f(-tau_cap * 1.44269504f) * (1.f + 1e-5f);
     if (!(budget >= 0.25f * GSASR_SPLAT_DEFAULT_EPS)) return P.kcut;
     const float t = fmaxf(__log2f(Kf / budget) * 0.69314718f + 1e-3f, 16.f);
     if (!(t < tau_cap)) return P.kcut;

@@ -113,7 +113,8 @@ def test_plan_k_bounds_the_true_k_and_sets_tau(case, dev):
     assert k >= k_true, (k, k_true)
     assert 16.0 <= tau <= tau_n + 1e-6
     if tau < tau_n - 1e-6 and tau > 16.0:
-        assert abs(tau - (math.log(k / EPS) + 1e-3)) <= 2e-4 * tau, (tau, k)   # tau' is ln(K / eps) of the K reported (no near-dead here)
+        # tau is ln(K / budget) of the K reported; no near-dead here, the tail of the ring takes a few % of the budget (more when N is small)
+        assert -2e-4 * tau <= tau - (math.log(k / EPS) + 1e-3) <= 0.35, (tau, k)
     if h_lr >= 256:
         # BASELINE config 2: tau well under ln(N / eps) (K is 1 092 cells-worth against a true near count of ~120: cells are 16 px)
         assert tau <= tau_n - 3.0, (k, k_true, tau, tau_n)
@@ -245,7 +246,7 @@ def test_near_dead_gaussians_are_charged_to_the_budget(dmax, dev):
     plan, _ = _plan(sig2, xy2, col2, H, W, dmax, dev)
     tau, k = _cabi.plan_cutoff(plan)
     assert k == k0                                                   # the dead ones sit in no cell
-    want = math.log(k / (EPS * (1.0 - m / s_tot))) + 1e-3            # budget = eps - m * exp(-tau_c) = eps * (1 - m / s)
-    assert abs(tau - want) <= 3e-4 * want, (tau, want, tau0)
+    want = math.log(k / (EPS * (1.0 - m / s_tot))) + 1e-3            # budget = eps - m * exp(-tau_c) = eps * (1 - m / s) - ring tail
+    assert -3e-4 * want <= tau - want <= 0.35, (tau, want, tau0)
     err = _within_eps_of_exact(sig2, xy2, col2, H, W, dmax, dev, plan)
     assert err > 0.0
