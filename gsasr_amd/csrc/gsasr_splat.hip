@@ -569,14 +569,14 @@ __device__ __forceinline__ float wave_sum(float v)
 //            Gaussian is binned by the cell of its (clamped, floored) centre and covers p only from the cells that the
 //            2m + 1 pixels around p touch, m = floor(dmax_px + 1.02): Cx * Cy cells, C = ceil(2m / 16) + 1
 //            [adapt_cells; on large sparse grids the same count in aligned 4 x 4-cell blocks, adapt_cells4];
-//       ring (either op): with E = the class' largest half-extent under tau (header words 0, 1: <= 130 px) and
-//            j0 = ceil(E / 16) + 1, a Gaussian binned at Chebyshev cell distance j >= j0 from p's cell is at least
-//            16 (j - 1) >= E + 16 (j - j0) pixels away along one axis, where its value is at most
-//            exp(-tau (d / E)^2) <= exp(-tau) q^(j - j0), q = exp(-32 tau / E) <= 0.02 (marginal of the bivariate normal;
-//            a Gaussian whose window is capped by the dmax box adds exactly nothing beyond the cap).  The 8 j cells of ring j,
-//            summed over j >= j0, therefore add at most 9 j0 cells' worth of terms below exp(-tau) -- the CONSERVATIVE
-//            tau: they are paid from the budget like (3), not counted at exp(-tau') -- and the count is the (2 j0 - 1)^2 cells
-//            of the core.  At x8 that is 49 cells against the 2 809 of the box.
+//       ring (either op): with E = the class' largest half-extent under tau in x / in y (header words 0, 1: <= 130 px),
+//            the CORE = the Cx * Cy cells that the 2 m + 1 pixels around p touch, m = E + 1, C = ceil(2m / 16) + 1: every
+//            Gaussian within E pixels of p is binned there.  A Gaussian binned r >= 1 cells beyond the core along an axis is
+//            at least E + 16 (r - 1) pixels away along it, where it is worth at most exp(-tau (d / E)^2) <= exp(-tau) q^(r-1),
+//            q = exp(-32 tau / E) <= 0.02 (marginal of the bivariate normal; a window capped by the dmax box adds exactly
+//            nothing beyond the cap).  Ring r holds 2 (Cx + Cy) + 8 r - 4 cells; summed over r >= 1 they add at most
+//            2.1 (Cx + Cy) + 5 cells' worth of terms below exp(-tau) -- the CONSERVATIVE tau: they are paid from the budget
+//            like (3), not counted at exp(-tau').  At x8 the core is 49 cells against the 2 809 of the box; at x4 16 against 64.
 //   (2) the LARGE class (extent > 128 px): counted in full.
 //   (3) NEAR-DEAD ones: classified dead because their support (under tau) does not reach the rows, though the op would
 //       add their tails (bounded op: the dmax box does reach; unbounded op: every dead Gaussian).  Each term is
@@ -585,8 +585,8 @@ __device__ __forceinline__ float wave_sum(float v)
 //   Gaussians whose box misses the rows (bounded op) and non-finite ones add exactly nothing, skipped or not.
 // tau' = ln(K_live / budget) + 1e-3 (the log is the hardware's: 1 ulp), clamped to [16, tau].  Gaussians stacked on one spot
 // make the largest count ~s and tau' = tau: nothing is lost on adversarial input (tests/test_adaptive_cutoff.py).
-__device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, unsigned nlarge, unsigned nnear, unsigned ext,
-                                            float &tau, unsigned &K, unsigned maxblock = 0u)
+__device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, unsigned nlarge, unsigned nnear, unsigned ext_x,
+                                            unsigned ext_y, float &tau, unsigned &K, unsigned maxblock = 0u)
 {
     const float tau_cap = 0.5f * P.kcut * P.kcut;
     tau = tau_cap;
@@ -599,11 +599,12 @@ __device__ __forceinline__ float adapt_kcut(const Params &P, unsigned maxcount, 
     }
     float far_terms = (float)nnear;    // terms worth < exp(-tau) each, paid from the budget: near-dead Gaussians, ring tails
     if (P.adapt_ring) {
-        const float j0 = ceilf((float)min(ext, 130u) * (1.f / CELL)) + 1.f;
-        const float core = fminf((2.f * j0 - 1.f) * (2.f * j0 - 1.f), (float)P.ncells);
-        if ((float)maxcount * core < Kn) {
-            Kn = (float)maxcount * core * (1.f + 1e-6f);
-            far_terms += (float)maxcount * 9.f * j0;
+        // cells the 2 m + 1 pixels around a pixel touch, m = E + 1 (the centre is binned by its floor), per axis
+        const float cx = fminf(ceilf((float)(2u * (min(ext_x, 130u) + 1u)) * (1.f / CELL)) + 1.f, (float)P.ncx);
+        const float cy = fminf(ceilf((float)(2u * (min(ext_y, 130u) + 1u)) * (1.f / CELL)) + 1.f, (float)P.ncy);
+        if ((float)maxcount * cx * cy < Kn) {
+            Kn = (float)maxcount * cx * cy * (1.f + 1e-6f);
+            far_terms += (float)maxcount * (2.1f * (cx + cy) + 5.f);
         }
     }
     const float Kf = fmaxf(Kn + (float)nlarge, 1.f);
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             // block-wide: the largest cell count, the near-dead count (both from the histogram this block holds anyway) and the
             // class' largest extent (every block reduces k_classify's per-block maxima: block 0 alone publishes the header
             // further down, too late for the windows)
-            unsigned mc = 0u, nn = 0u, ext = 0u;
+            unsigned mc = 0u, nn = 0u, ext = 0u, eyt = 0u;
 #pragma unroll
             for (int k = 0; k < FUSED_PER_THREAD; ++k) {
                 const int q = (int)threadIdx.x * FUSED_PER_THREAD + k;
@@ -999,22 +1000,28 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 nn += q >= P.ncells + 1 + NDEAD_NEAR ? c[k] : 0u;      // (c[k] = 0 past the last class)
             }
             if (P.adapt_ring) {
-                for (int k = (int)threadIdx.x; k < nblk; k += 256) ext = max(ext, max(V.blockmax[16 * k], V.blockmax[16 * k + 1]));
+                for (int k = (int)threadIdx.x; k < nblk; k += 256) {
+                    ext = max(ext, V.blockmax[16 * k]);
+                    eyt = max(eyt, V.blockmax[16 * k + 1]);
+                }
             }
             mc = wave_max_u32(mc);
             ext = wave_max_u32(ext);
+            eyt = wave_max_u32(eyt);
             nn = wave_add_u32(nn);
             if ((threadIdx.x & 63) == 0) {
                 s_part[threadIdx.x >> 6] = mc;
                 s_part[4 + (threadIdx.x >> 6)] = nn;
                 s_part[8 + (threadIdx.x >> 6)] = ext;
+                s_part[12 + (threadIdx.x >> 6)] = eyt;
             }
             __syncthreads();
             mc = max(max(s_part[0], s_part[1]), max(s_part[2], s_part[3]));
             nn = (s_part[4] + s_part[5]) + (s_part[6] + s_part[7]);
             ext = max(max(s_part[8], s_part[9]), max(s_part[10], s_part[11]));
+            eyt = max(max(s_part[12], s_part[13]), max(s_part[14], s_part[15]));
             __syncthreads();   // (s_part is reused by the scan below)
-            kc = adapt_kcut(P, mc, nlarge, nn, ext, kc_tau, kc_K);
+            kc = adapt_kcut(P, mc, nlarge, nn, ext, eyt, kc_tau, kc_K);
             kc_mc = mc;
             kc_nn = nn;
         } else {
@@ -1023,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     } else {   // (the scan kernels left the maxima in the header and the finished scan)
         const int ncls = P.ncells + 1 + NDEAD;
         kc = adapt_kcut(P, V.hdr[2], V.cell_start[P.ncells + 1] - V.cell_start[P.ncells],
-                        V.cell_start[ncls] - V.cell_start[P.ncells + 1 + NDEAD_NEAR], max(V.hdr[0], V.hdr[1]), kc_tau, kc_K, V.hdr[6]);
+                        V.cell_start[ncls] - V.cell_start[P.ncells + 1 + NDEAD_NEAR], V.hdr[0], V.hdr[1], kc_tau, kc_K, V.hdr[6]);
         if (i == 0) {
             V.hdr[3] = __float_as_uint(kc);
             V.hdr[4] = __float_as_uint(kc_tau);

@@ -139,7 +139,7 @@ typedef struct gsasr_dims {
  *                  a Gaussian whose box covers the pixel adds anything) and (b) those within the class' largest support of
  *                  the pixel (both ops); `budget` is eps minus exp(-tau) for every term of the geometric tail of everything
  *                  farther and for every dead Gaussian whose tails the op would still add to these rows.  Config
- *                  2: K = 525, tau' = 17.8; x8 (config 4): K = 392, tau' = 17.5.  gsasr_plan_cutoff reports both;
+ *                  2: K = 336, tau' = 17.3; x8 (config 4): K = 392, tau' = 17.5.  gsasr_plan_cutoff reports both;
  *                  gsasr_amd/csrc/gsasr_splat.hip (adapt_kcut) has the derivation, tests/test_adaptive_cutoff.py the checks
  *                  incl. adversarial inputs (everything stacked on one spot: K ~ s, tau' = tau).
  * A fixed tau can be set per call (dims.cutoff) or per process (gsasr_set_default_cutoff / environment
