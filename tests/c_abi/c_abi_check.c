@@ -303,6 +303,38 @@ int main(void)
         CK(hipFree(ws)); CK(hipFree(d_chw));
         free(chw);
     }
+    /* the cutoff a plan actually used (data-derived under the adaptive default) and the launchers' kept scratch, from plain C */
+    {
+        gsasr_dims d = {s, h, w, 3, 0.3f, 0, h, 0.f, 0u};
+        const size_t bytes = gsasr_splat_workspace_bytes(&d);
+        void *ws = NULL;
+        CK(hipMalloc(&ws, bytes));
+        OK(gsasr_splat_plan(d_sig, d_xy, d_col, &d, ws, bytes, st));
+        float tau = -1.f;
+        unsigned k = 0u;
+        OK(gsasr_plan_cutoff(&d, ws, bytes, st, &tau, &k));
+        const float tau_n = gsasr_resolve_cutoff(0.f, s);
+        printf("plan cutoff: tau' = %.3f (K = %u) against the conservative %.3f\n", tau, k, tau_n);
+        if (!(tau >= 16.f && tau <= tau_n + 1e-4f && k > 0u)) bad = 1;
+        d.cutoff = 32.f;
+        OK(gsasr_splat_plan(d_sig, d_xy, d_col, &d, ws, bytes, st));
+        OK(gsasr_plan_cutoff(&d, ws, bytes, st, &tau, &k));
+        if (!(fabsf(tau - 32.f) < 1e-3f && k == 0u)) { printf("explicit cutoff not kept: %.3f %u\n", tau, k); bad = 1; }
+        CK(hipFree(ws));
+        /* the launchers above left their scratch behind for this stream: a second round reuses it, a release frees it,
+         * and the round after that allocates again -- same image every time */
+        for (int round = 0; round < 3; ++round) {
+            CK(hipMemsetAsync(d_img, 0, sizeof(float) * 3 * h * w, st));
+            OK(gsasr_gs_render_dmax(d_sig, d_xy, d_col, d_img, s, h, w, 3, 0.3f, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(img, d_img, sizeof(float) * 3 * h * w, hipMemcpyDeviceToHost));
+            gsref_forward_f64(sig, xy, col, ref, s, h, w, 0.3f, 0, h);
+            double e = 0;
+            for (int i = 0; i < 3 * h * w; ++i) { double dd = fabs((double)img[i] - ref[i]); if (dd > e) e = dd; }
+            if (!(e <= 1e-4)) { printf("launcher round %d: image max|err| %.3e\n", round, e); bad = 1; }
+            if (round == 1) OK(gsasr_release_launcher_scratch());
+        }
+    }
     /* error behaviour: status + message instead of a crash */
     if (gsasr_gs_render_dmax(d_sig, d_xy, d_col, d_img, s, h, w, 4, 0.1f, st) == 0) { printf("c=4 accepted\n"); bad = 1; }
     printf("%s\n", bad ? "C-ABI CHECK FAILED" : "C-ABI CHECK OK");
