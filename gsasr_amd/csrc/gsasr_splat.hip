@@ -6,14 +6,16 @@
 //   backward: analytic gradient of sum(grad_img * img) w.r.t. sigmas[s,3], coords[s,2], colors[s,3]
 //
 // Pipeline (all on the caller's stream, no host sync; DESIGN.md has the measurements):
-//   plan     k_classify  per Gaussian: pixel window of (dmax box  ∩  sigma*sqrt(2 tau) support box), tight to
-//                        the pixel; class {normal -> 16x16-px cell of its centre | large | dead}; rank in
-//                        its cell (one returning atomic per wave and distinct cell, one round trip);
-//                        per-block max extent of the normal class; the px/py pixel-coordinate tables
-//                        (double expression rounded to float, as gs.cu:27-28 does per pixel).
+//   plan     k_classify  per Gaussian: pixel window of (dmax box  ∩  sigma*sqrt(2 tau) support box) under the
+//                        CONSERVATIVE cutoff tau = ln(s / eps); class {normal -> 16x16-px cell of its centre | large |
+//                        dead (far / near: adapt_kcut)}; rank in its cell (one returning atomic per wave and distinct
+//                        cell, one round trip); max extent of the normal class per group of 32 blocks; the px/py
+//                        pixel-coordinate tables (double expression rounded to float, as gs.cu:27-28 does per pixel).
 //            k_scan      exclusive scan of the cell histogram + max-extent reduction (one workgroup;
 //                        k_scan_local + k_scan_fix for grids above 8192 cells).
-//            k_bin       counting-sort placement (cell start + rank) fused with packing: 32-byte records
+//            k_bin       the cutoff the WINDOWS are built with -- tau' = ln(K / budget) <= tau, K counted from the cell
+//                        histogram (adapt_kcut: same eps * max|colour| bound per pixel, 20-30% fewer pairs) -- then
+//                        counting-sort placement (cell start + rank) fused with packing: 32-byte records
 //                        {x, y, IX, NR, IY, r, g, b} (the coefficients of the completed-square exponent
 //                        -(IX dx)^2 - (IY dy + NR IX dx)^2 in log2 units, computed in double), backward-epilogue constants, 16-byte windows with the
 //                        per-tile-band column spans of the ellipse {exponent >= -tau}, and the first 8 bytes of the
