@@ -229,6 +229,8 @@ def clear_workspace_pool() -> None:
     _POOL.clear()
     if _lib is not None:
         _lib.gsasr_release_launcher_scratch()
+    from . import _cpp_node
+    _cpp_node.clear_pool()
 
 
 @dataclass

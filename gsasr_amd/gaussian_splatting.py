@@ -281,11 +281,32 @@ def _fused_render(gs_parameters, sr_size, step_size, dmax):
     H, W = _hw(sr_size)
     dm = None if dmax is None else float(dmax)
     if step_size.__class__ is _StepSource:
-        out = _FusedStep.apply(gs_parameters.contiguous(), None, H, W, dm, step_size.scale_modify, step_size.default_step)
+        out = _fused_step(gs_parameters.contiguous(), None, H, W, dm, step_size.scale_modify, step_size.default_step)
         deferred_asserts.watch(gs_parameters.device)      # (after the launch: a look covers this call's own pair)
         return out
     step = _step_tensor(step_size, gs_parameters.device)
-    return _FusedStep.apply(gs_parameters.contiguous(), step, H, W, dm)
+    return _fused_step(gs_parameters.contiguous(), step, H, W, dm)
+
+
+def _fused_step(gs_parameters, step, H, W, dm, scale_modify=None, default_step=1.2):
+    """`_FusedStep.apply`, as a C++ autograd node when the extension is there (gsasr_amd/_cpp_node.py: the engine calls its
+    backward without taking the GIL -- the reference's training loop makes sixteen of these nodes per step)"""
+    from . import _cpp_node
+    if _cpp_node.load() is None:
+        return _FusedStep.apply(gs_parameters, step, H, W, dm, scale_modify, default_step)
+    needs_grad = gs_parameters.requires_grad and torch.is_grad_enabled()
+    flags = _plan_flags(needs_grad, _tile_backward(H * W, gs_parameters.shape[0]))
+    return _cpp_node.fused_step_apply(gs_parameters, step, H, W, dm, flags, scale_modify, default_step)
+
+
+def _fused_batch(gs_parameters, steps, sizes, dm, scale_modify=None, default_step=1.2):
+    """`_FusedBatch.apply`, through the same C++ node when it is there"""
+    from . import _cpp_node
+    if _cpp_node.load() is None:
+        return _FusedBatch.apply(gs_parameters, steps, sizes, dm, scale_modify, default_step)
+    needs_grad = gs_parameters.requires_grad and torch.is_grad_enabled()
+    tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1])
+    return _cpp_node.fused_step_apply(gs_parameters, steps, 0, 0, dm, _plan_flags(needs_grad, tile), scale_modify, default_step, sizes=sizes)
 
 
 def rendering_cuda(sigma_x, sigma_y, rho, coords, colours_with_alpha, sr_size, step_size, device):
@@ -574,12 +595,12 @@ def generate_2D_gaussian_splatting_batch(sr_sizes, gs_parameters, scales, scale_
             elif not torch.is_tensor(scale_modifies) and all(_sm_source_ok(v) and v.device == dev for v in scale_modifies):
                 sm = torch.stack([v[:2] for v in scale_modifies])
             if sm is not None:
-                out = _FusedBatch.apply(gs_parameters.contiguous(), None, tuple(sizes), dm, sm, float(default_step_size))
+                out = _fused_batch(gs_parameters.contiguous(), None, tuple(sizes), dm, sm, float(default_step_size))
                 deferred_asserts.watch(dev)
                 return out
         steps = _batch_step_sizes(scales, scale_modifies, default_step_size, mode, dev)
         if sample_coords is None:
-            return _FusedBatch.apply(gs_parameters.contiguous(), steps, tuple(sizes), dm)
+            return _fused_batch(gs_parameters.contiguous(), steps, tuple(sizes), dm)
         pts = sample_coords if torch.is_tensor(sample_coords) else torch.as_tensor(sample_coords)
         if pts.dim() == 3 and pts.shape[0] == B and pts.shape[2] == 2 and not pts.dtype.is_floating_point \
                 and 0 < pts.shape[1] <= SAMPLED_MAX_FRACTION * min(h * w for h, w in sizes):

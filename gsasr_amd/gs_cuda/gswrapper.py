@@ -38,6 +38,15 @@ class GSCUDA(Function):
         return (*_cabi.backward_new(ctx.plan, sigmas, coords, colors, grad_output), None)
 
 
+# The same node in C++ when the extension has been built (gsasr_amd/_cpp_node.py): the autograd engine then calls the backward
+# without taking the GIL.  `GSCUDA.apply` keeps its signature; `GSCUDA.forward` / `.backward` above remain the Python path.
+from .. import _cpp_node  # noqa: E402
+
+if _cpp_node.load() is not None:
+    GSCUDA.python_apply = GSCUDA.apply
+    GSCUDA.apply = staticmethod(lambda sigmas, coords, colors, rendered_img: _cpp_node.fast_apply(sigmas, coords, colors, rendered_img, None))
+
+
 def gaussiansplatting_render(sigmas, coords, colors, image_size):
     """reference: utils/gs_cuda/gswrapper.py:41-48"""
     sigmas = sigmas.contiguous()  # (gs num, 3)
