@@ -93,6 +93,12 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #endif
 constexpr int BWD_WAVES = BWD_WAVES_N;  // waves (= consecutive cell-ordered Gaussians) per backward workgroup
 constexpr int NCH = 64;         // row chunks a large Gaussian is split into in backward
+#ifndef FUSED_MAX_BLOCKS
+#define FUSED_MAX_BLOCKS 1536         // k_bin blocks up to which every block rebuilds the scan itself; beyond (393 216 Gaussians) the
+                                      // 4 161 counter loads per block outweigh the scan kernel's launch: 16 Gaussians per LR pixel at
+                                      // 1024^2 54.0 -> 44.7 us, the config-5 canvas 35.4 -> 32.4; at 262 144 Gaussians fused 22.8 vs 24.0
+                                      // (development: GSASR_SPLAT_FUSED_MAX)
+#endif
 constexpr int FUSED_CELLS_HOST = 256 * 17;   // = FUSED_CELLS (k_bin<true>): grids up to this many classes never run a scan kernel
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y, [2]=largest cell count,
                                 //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut),
@@ -3226,8 +3232,9 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
                            SS, (float *)nullptr, (float *)nullptr, (float *)nullptr);
     const int ncls = L.ncells + 1 + NDEAD;
     const unsigned nbin = (unsigned)((dims->s + 255) / 256);
-    if (ncls <= FUSED_CELLS && dims->s > 0) {
-        // small grid: k_bin rebuilds the scan per block (no separate scan launch)
+    static const int fused_max_blocks = getenv("GSASR_SPLAT_FUSED_MAX") ? atoi(getenv("GSASR_SPLAT_FUSED_MAX")) : FUSED_MAX_BLOCKS;
+    if (ncls <= FUSED_CELLS && dims->s > 0 && (int)nbin <= fused_max_blocks) {
+        // small grid, not too many blocks: k_bin rebuilds the scan per block (no separate scan launch)
         hipLaunchKernelGGL(k_bin<true>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
     } else {
         if (ncls <= 2 * SCAN_CHUNK) {
