@@ -258,7 +258,9 @@ bool bwd_wants_tile(const gsasr_dims *d)
     // its pixels per Gaussian say nothing about the window size -- the shard's caller knows the scale and sets the flag)
     if (bwd_env() != 0 || d->batch > 1 || d->row0 != 0 || d->row1 != d->h) return false;
     const double px_per_gaussian = (double)d->h * (double)d->w / (double)(d->s > 0 ? d->s : 1);
-    return px_per_gaussian >= 32.0 && (double)d->h * (double)d->w >= 524288.0;
+    // (round 4, with the windows of the data-derived cutoff: at 2048^2 x8 the Gaussian-stationary kernel is 7% ahead, at
+    // 3072^2 x6 the tile-stationary one 3%, from 5120^2 up 4..10%: the line is drawn at 8 Mpx)
+    return px_per_gaussian >= 32.0 && (double)d->h * (double)d->w >= 8388608.0;
 }
 
 int bwd_part_k(const gsasr_dims *d)
