@@ -117,6 +117,7 @@ struct Params {
                      // whose dmax box can cover one pixel <= (largest cell count) * adapt_cells + (large class); 0: kcut everywhere
     int count_words; // words of one parity's counter array (cell counters + extent groups): what k_classify zeroes for the next plan
     int ext_groups;  // groups of 32 k_classify blocks (PlanView::blockmax)
+    int dead_off;    // word offset of the dead sub-classes' counters inside a parity's counter array (count_at)
     int adapt_ring;  // 1: K also bounded from the SUPPORT (adapt_kcut: cells within the class' largest extent + a geometric tail)
     float cap_px_x, cap_px_y;  // the dmax box in pixels (smallest over the samples of a batch): a class extent below it means
                      // no Gaussian's window is capped by the box, so all of them shrink with the cutoff (reach_of)
@@ -182,6 +183,7 @@ struct Layout {
     int part_k;
     size_t count_bytes;  // one array of per-cell counters + extent groups (there are two, used alternately: GSASR_FLAG_PARITY)
     size_t ext_off_words; // where the extent groups start inside such an array
+    size_t dead_off_words; // ... and the counters of the dead sub-classes, ONE PER 64-BYTE LINE (count_at)
     int ext_groups;
     size_t total;
     int ncx, ncy, ncells;
@@ -282,7 +284,8 @@ Layout make_layout(const gsasr_dims *d, int part_k = -1)
     L.off_hdr = o;    o += HDR_WORDS * 4;
     L.ext_groups = (classify_blocks(d) + 31) / 32;
     L.ext_off_words = align_up(ncls, 16);
-    L.count_bytes = align_up((L.ext_off_words + 16 * (size_t)L.ext_groups) * 4, 256);
+    L.dead_off_words = L.ext_off_words + 16 * (size_t)L.ext_groups;
+    L.count_bytes = align_up((L.dead_off_words + 16 * (size_t)NDEAD) * 4, 256);
     L.off_count = o;  o += 2 * L.count_bytes;
     L.off_geo = o;    o += GSASR_MAX_BATCH * 16;   // (outside the zeroed region: written once by k_batch_geo)
     L.off_start = o;  o += align_up((ncls + 1) * 4, 256);
@@ -386,6 +389,7 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.adapt_ring = 0;
     P.count_words = (int)(L.count_bytes / 4);
     P.ext_groups = L.ext_groups;
+    P.dead_off = (int)L.dead_off_words;
     {
         double wmin = d->w, hmin = d->h;
         if (d->batch > 1) {
@@ -637,6 +641,14 @@ __device__ __forceinline__ unsigned reach_of(unsigned ext, float kc, float kcut,
     return min(ext, (unsigned)ceilf((float)(ext - 2u) * (kc / kcut) * (1.f + 1e-6f)) + 2u);
 }
 
+// Histogram entry of class k.  Cells and the large class are dense; the dead sub-classes' counters sit one per 64-byte line
+// behind them: a row band of a sharded image sees 7/8 of a million Gaussians there, one wave-aggregated atomic each, and
+// atomics serialise per cache LINE (~12 ns): 64 dense counters are four lines (86 us of queueing), 128 padded ones 128 lines.
+__device__ __forceinline__ unsigned count_index(int k, int ncells, int dead_off)
+{
+    return k <= ncells ? (unsigned)k : (unsigned)(dead_off + (k - ncells - 1) * 16);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // plan kernels
 // ---------------------------------------------------------------------------------------------------
@@ -777,7 +789,7 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
         if (mine) {
             const int leader = __builtin_ctzll(mine);
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(&V.cell_count[key], (unsigned)__builtin_popcountll(mine));
+            if (lane == leader) base = atomicAdd(&V.cell_count[count_index((int)key, P.ncells, P.dead_off)], (unsigned)__builtin_popcountll(mine));
             base = (unsigned)__shfl((int)base, leader);
             rank = base + (unsigned)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
         }
@@ -840,7 +852,7 @@ __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *
     const int b = t * per, e = min(n, b + per);
     unsigned sum = 0, mc = 0;
     for (int k = b; k < e; ++k) {
-        const unsigned c = count[k];
+        const unsigned c = count[count_index(k, P.ncells, P.dead_off)];
         sum += c;
         if (k < P.ncells) mc = max(mc, c);
     }
@@ -862,7 +874,7 @@ __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *
     unsigned run = part[t] - sum;
     for (int k = b; k < e; ++k) {
         start[k] = run;
-        run += count[k];
+        run += count[count_index(k, P.ncells, P.dead_off)];
     }
     if (t == 1023) start[n] = part[1023];
 }
@@ -875,7 +887,7 @@ constexpr int SCAN_CHUNK = 4096;
 __global__ __launch_bounds__(1024) void k_scan_local(int ncells, int n, const unsigned *__restrict__ count,
                                                      unsigned *__restrict__ start, unsigned *__restrict__ tot,
                                                      int nblk, const unsigned *__restrict__ blockmax,
-                                                     unsigned *__restrict__ hdr, int ncx, int ncy, int want_blocks)
+                                                     unsigned *__restrict__ hdr, int ncx, int ncy, int want_blocks, int dead_off)
 {
     __shared__ unsigned part[1024];
     __shared__ unsigned smax[2][16];
@@ -896,7 +908,7 @@ __global__ __launch_bounds__(1024) void k_scan_local(int ncells, int n, const un
     const int base = blockIdx.x * SCAN_CHUNK + t * 4;
     unsigned c[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c[k] = base + k < n ? count[base + k] : 0u;
+    for (int k = 0; k < 4; ++k) c[k] = base + k < n ? count[count_index(base + k, ncells, dead_off)] : 0u;
     const unsigned sum = c[0] + c[1] + c[2] + c[3];
     part[t] = sum;
     {   // largest count of a cell (adapt_kcut): one atomicMax per wave that holds cells
@@ -973,7 +985,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
 #pragma unroll
         for (int k = 0; k < FUSED_PER_THREAD; ++k) {
             const int q = (int)threadIdx.x * FUSED_PER_THREAD + k;
-            c[k] = q < P.ncells + 1 + NDEAD ? V.cell_count[q] : 0u;
+            c[k] = q < P.ncells + 1 + NDEAD ? V.cell_count[count_index(q, P.ncells, P.dead_off)] : 0u;
         }
     }
     const bool adapting = P.adapt_cells > 0.f || P.adapt_ring != 0;
@@ -997,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     // holds anyway (FUSED_SCAN), or reads what the scan kernels left in the header.
     float kc = P.kcut, kc_tau = 0.f;
     unsigned kc_K = 0u, kc_mc = 0u, kc_nn = 0u;
-    if (FUSED_SCAN) {
+    if constexpr (FUSED_SCAN) {
         if (adapting) {
             // block-wide: the largest cell count, the near-dead count (both from the histogram this block holds anyway) and the
             // class' largest extent (every block reduces k_classify's per-block maxima: block 0 alone publishes the header
@@ -1193,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             }
         }
     }
-    if (FUSED_SCAN) {
+    if constexpr (FUSED_SCAN) {
         const int t = threadIdx.x, ncls = P.ncells + 1 + NDEAD;
         const int b0 = t * FUSED_PER_THREAD;
         unsigned sum = 0;
@@ -3245,7 +3257,7 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
         } else {
             const int nchunks = (ncls + SCAN_CHUNK - 1) / SCAN_CHUNK;
             hipLaunchKernelGGL(k_scan_local, dim3(nchunks), dim3(1024), 0, st, L.ncells, ncls, V.cell_count, V.cell_start,
-                               V.scan_tot, L.ext_groups, V.blockmax, V.hdr, L.ncx, L.ncy, (int)(P.adapt_cells4 > 0.f));
+                               V.scan_tot, L.ext_groups, V.blockmax, V.hdr, L.ncx, L.ncy, (int)(P.adapt_cells4 > 0.f), P.dead_off);
             hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, P, ncls, V.cell_start, V.scan_tot, nchunks,
                                V.cell_count, V.hdr);
         }
