@@ -815,39 +815,46 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
 
 // adapt_kcut's second granularity: the largest number of Gaussians binned in one aligned block of 4 x 4 cells, straight
 // from the histogram (final once k_classify is done) -- block `b` of the grid's ceil(ncx/4) x ceil(ncy/4), one per thread
-// of whatever scan kernel runs anyway (no launch of its own); one atomicMax per wave.
-__device__ __forceinline__ void block_count_max(int ncx, int ncy, int b, const unsigned *__restrict__ count, unsigned *hdr)
+// of whatever scan kernel runs anyway (no launch of its own); the caller reduces over its workgroup and issues ONE atomicMax
+// (one per wave -- 1 024 of them on one word at config 4 -- serialised for 12 us).
+__device__ __forceinline__ unsigned block_count(int ncx, int ncy, int b, const unsigned *__restrict__ count)
 {
     const int nbx = (ncx + 3) >> 2, nby = (ncy + 3) >> 2;
     unsigned sum = 0u;
     if (b < nbx * nby) {
         const int bx = b % nbx, by = b / nbx;
         const int x0 = bx * 4, x1 = min(x0 + 4, ncx);
-        for (int r = by * 4; r < min(by * 4 + 4, ncy); ++r)
-            for (int xx = x0; xx < x1; ++xx) sum += count[r * ncx + xx];
+        if ((ncx & 3) == 0) {   // (whole rows of four counts, 16-byte aligned: one load per row)
+            for (int r = by * 4; r < min(by * 4 + 4, ncy); ++r) {
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(count + (size_t)r * ncx + x0);
+                sum += (c4.x + c4.y) + (c4.z + c4.w);
+            }
+        } else {
+            for (int r = by * 4; r < min(by * 4 + 4, ncy); ++r)
+                for (int xx = x0; xx < x1; ++xx) sum += count[r * ncx + xx];
+        }
     }
-    sum = wave_max_u32(sum);
-    if ((threadIdx.x & 63) == 0 && sum) atomicMax(&hdr[6], sum);
+    return sum;
 }
 
 __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *__restrict__ count,
                                                unsigned *__restrict__ start, int nblk,
                                                const unsigned *__restrict__ blockmax, unsigned *__restrict__ hdr)
 {
-    __shared__ unsigned part[1024];
-    __shared__ unsigned smax[3][16];
-    const int t = threadIdx.x;
+    __shared__ unsigned part[16];
+    __shared__ unsigned smax[4][16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    unsigned bm = 0u;
     if (P.adapt_cells4 > 0.f)
-        for (int b0 = 0; b0 < ((P.ncx + 3) >> 2) * ((P.ncy + 3) >> 2); b0 += 1024) block_count_max(P.ncx, P.ncy, b0 + t, count, hdr);
-    // (a) max half-extents over the classify blocks -> plan header
+        for (int b0 = 0; b0 < ((P.ncx + 3) >> 2) * ((P.ncy + 3) >> 2); b0 += 1024) bm = max(bm, block_count(P.ncx, P.ncy, b0 + t, count));
+    // (a) max half-extents over the classify groups -> plan header
     unsigned mx = 0, my = 0;
     for (int k = t; k < nblk; k += 1024) {
         mx = max(mx, blockmax[16 * k + 0]);
         my = max(my, blockmax[16 * k + 1]);
     }
-    mx = wave_max_u32(mx);
-    my = wave_max_u32(my);
-    // (b) exclusive scan of the per-cell counts (+ the largest count of a cell, for adapt_kcut)
+    // (b) exclusive scan of the per-cell counts (+ the largest count of a cell, for adapt_kcut): up to eight consecutive
+    // counts per thread, the 1024 partial sums scanned inside the waves with shuffles and across them through LDS
     const int per = (n + 1023) / 1024;
     const int b = t * per, e = min(n, b + per);
     unsigned sum = 0, mc = 0;
@@ -856,27 +863,34 @@ __global__ __launch_bounds__(1024) void k_scan(Params P, int n, const unsigned *
         sum += c;
         if (k < P.ncells) mc = max(mc, c);
     }
+    unsigned inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)inc, o);
+        if (lane >= o) inc += v;
+    }
+    mx = wave_max_u32(mx);
+    my = wave_max_u32(my);
     mc = wave_max_u32(mc);
-    if ((t & 63) == 0) { smax[0][t >> 6] = mx; smax[1][t >> 6] = my; smax[2][t >> 6] = mc; }
-    part[t] = sum;
+    bm = wave_max_u32(bm);
+    if (lane == 63) part[wv] = inc;
+    if (lane == 0) { smax[0][wv] = mx; smax[1][wv] = my; smax[2][wv] = mc; smax[3][wv] = bm; }
     __syncthreads();
-    if (t < 3) {
+    if (t < 4) {
         unsigned m = 0;
         for (int k = 0; k < 16; ++k) m = max(m, smax[t][k]);
-        hdr[t] = m;
+        hdr[t < 3 ? t : 6] = m;
     }
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partials
-        unsigned v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    unsigned run = inc - sum, total = 0;
+    for (int k = 0; k < 16; ++k) {
+        const unsigned p = part[k];
+        run += k < wv ? p : 0u;
+        total += p;
     }
-    unsigned run = part[t] - sum;
     for (int k = b; k < e; ++k) {
         start[k] = run;
         run += count[count_index(k, P.ncells, P.dead_off)];
     }
-    if (t == 1023) start[n] = part[1023];
+    if (t == 0) start[n] = total;
 }
 
 // Large grids (> 8192 cells): two-pass scan.  Pass 1: every block scans 4096 counts (4 per thread,
@@ -889,54 +903,61 @@ __global__ __launch_bounds__(1024) void k_scan_local(int ncells, int n, const un
                                                      int nblk, const unsigned *__restrict__ blockmax,
                                                      unsigned *__restrict__ hdr, int ncx, int ncy, int want_blocks, int dead_off)
 {
-    __shared__ unsigned part[1024];
-    __shared__ unsigned smax[2][16];
-    const int t = threadIdx.x;
-    if (want_blocks)   // (a chunk of 4096 cells holds 256 blocks of 16: the first wave quartet's worth of threads)
+    __shared__ unsigned part[16];
+    __shared__ unsigned smax[4][16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    unsigned bm = 0u;
+    if (want_blocks)
         for (int b0 = (int)blockIdx.x * 1024; b0 < ((ncx + 3) >> 2) * ((ncy + 3) >> 2); b0 += (int)gridDim.x * 1024)
-            block_count_max(ncx, ncy, b0 + t, count, hdr);      // (block-uniform loop: the wave reduction inside needs every lane)
+            bm = max(bm, block_count(ncx, ncy, b0 + t, count));
+    unsigned mx = 0, my = 0;
     if (blockIdx.x == 0) {
-        unsigned mx = 0, my = 0;
         for (int k = t; k < nblk; k += 1024) {
             mx = max(mx, blockmax[16 * k + 0]);
             my = max(my, blockmax[16 * k + 1]);
         }
-        mx = wave_max_u32(mx);
-        my = wave_max_u32(my);
-        if ((t & 63) == 0) { smax[0][t >> 6] = mx; smax[1][t >> 6] = my; }
     }
     const int base = blockIdx.x * SCAN_CHUNK + t * 4;
     unsigned c[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) c[k] = base + k < n ? count[count_index(base + k, ncells, dead_off)] : 0u;
     const unsigned sum = c[0] + c[1] + c[2] + c[3];
-    part[t] = sum;
-    {   // largest count of a cell (adapt_kcut): one atomicMax per wave that holds cells
-        unsigned mc = 0;
+    unsigned mc = 0;   // largest count of a cell (adapt_kcut)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mc = base + k < ncells ? max(mc, c[k]) : mc;
-        mc = wave_max_u32(mc);
-        if ((t & 63) == 0 && mc) atomicMax(&hdr[2], mc);
+    for (int k = 0; k < 4; ++k) mc = base + k < ncells ? max(mc, c[k]) : mc;
+    // scan of the 1024 partial sums: inside the waves with shuffles, across the sixteen waves through LDS (one barrier pair
+    // instead of the twenty of a Hillis-Steele loop); the maxima ride along: ONE atomicMax per workgroup and word
+    unsigned inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)inc, o);
+        if (lane >= o) inc += v;
     }
+    mc = wave_max_u32(mc);
+    bm = wave_max_u32(bm);
+    mx = wave_max_u32(mx);
+    my = wave_max_u32(my);
+    if (lane == 63) part[wv] = inc;
+    if (lane == 0) { smax[0][wv] = mx; smax[1][wv] = my; smax[2][wv] = mc; smax[3][wv] = bm; }
     __syncthreads();
-    if (blockIdx.x == 0 && t < 2) {
+    if (t < 4) {
         unsigned m = 0;
         for (int k = 0; k < 16; ++k) m = max(m, smax[t][k]);
-        hdr[t] = m;
+        if (t < 2) { if (blockIdx.x == 0) hdr[t] = m; }
+        else if (m) atomicMax(&hdr[t == 2 ? 2 : 6], m);
     }
-    for (int o = 1; o < 1024; o <<= 1) {
-        unsigned v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    unsigned run = inc - sum, total = 0;
+    for (int k = 0; k < 16; ++k) {
+        const unsigned p = part[k];
+        run += k < wv ? p : 0u;
+        total += p;
     }
-    unsigned run = part[t] - sum;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (base + k < n) start[base + k] = run;
         run += c[k];
     }
-    if (t == 1023) tot[blockIdx.x] = part[1023];
+    if (t == 0) tot[blockIdx.x] = total;
+
 }
 
 __global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__restrict__ start,
