@@ -255,8 +255,7 @@ def main():
         dist.barrier()
     if rank == 0:
         h_lr, w_lr, scale, desc = CONFIGS[args.config]
-        tau_eff, k_box = (effective_tau(step, args.cutoff) if not step.batched
-                          else (step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 0))
+        tau_eff, k_box = effective_tau(step, args.cutoff)      # (read back from the plan header: data-derived under the default)
         out = {
             "metric": ("HR Mpixels/sec fwd+bwd (x4, 1 Gaussian/LR px); achieved HBM GB/s vs roofline" if args.config == "c2"
                        else "sampled HR Mpixels/sec prologue+fwd+bwd (x4, 16 Gaussians/LR px, batch 16, sample_coords)" if getattr(step, "sampled", False)
