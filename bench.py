@@ -240,7 +240,7 @@ def main():
                     pass
             roofline["valu"] = valu
 
-    c4_strong = None
+    c4_strong = c4_strong_halo = None
     if (world > 1 or args.force_dist) and args.config in ("c2", "c4") and not step.batched:
         # BASELINE config 4's own pattern -- strong-scaled 8192^2, packed broadcast + in-place reduce-scatter -- as a leg of
         # EVERY multi-rank line, whatever exchange the headline used
@@ -248,6 +248,12 @@ def main():
             c4_strong = strong_c4_leg(args, dev, rank, world)
         except Exception as e:
             c4_strong = {"error": repr(e)}
+        # ... and the same image with a sharded producer and the nearest-neighbour halo swap (what DESIGN.md section 5 proposes
+        # for this path: 64 MB per rank and step of collectives become a few hundred KB)
+        try:
+            c4_strong_halo = strong_c4_leg(args, dev, rank, world, exchange="halo")
+        except Exception as e:
+            c4_strong_halo = {"error": repr(e)}
     if world > 1:      # every rank's C-stdio output (RCCL banner) is out before rank 0 prints the line
         import torch.distributed as dist
         flush_c_stdio()
@@ -306,6 +312,8 @@ def main():
                     out["configs"][name] = {"error": repr(e)}
         if c4_strong is not None:
             out["c4_strong"] = c4_strong
+        if c4_strong_halo is not None:
+            out["c4_strong_halo"] = c4_strong_halo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         emit(out)

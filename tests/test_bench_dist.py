@@ -42,3 +42,10 @@ def test_bench_two_ranks_functional(launcher, extra):
     assert leg["scaling"] == "strong" and leg["n_gpus"] == 2 and leg["value"] > 0 and leg["rows_per_rank"] == 4096
     assert leg["rccl"]["ranks"] == 2 and leg["rccl"]["bytes_sent_per_rank_per_step"] == 64 * 1048576
     assert "reduce_scatter" in leg["rccl"]["pattern"] and "broadcast" in leg["rccl"]["pattern"]
+    # ... and the same image with the sharded producer + nearest-neighbour halo swap
+    halo = d["c4_strong_halo"]
+    assert "error" not in halo and "note" not in halo, halo
+    assert halo["scaling"] == "strong" and halo["n_gpus"] == 2 and halo["value"] > 0 and halo["rows_per_rank"] == 4096
+    assert halo["gaussians_per_rank"] == 1048576 // 2
+    assert 0 < halo["rccl"]["bytes_sent_per_rank_per_step"] < 64 * 1048576 // 8
+    assert halo["rccl"]["halo_records_max_per_edge"] <= halo["rccl"]["capacity"]

@@ -706,15 +706,17 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     return out
 
 
-def strong_c4_leg(args, dev, rank, world, steps=5):
-    """BASELINE config 4 as stated, on whatever group this run has: the 8192^2 image strong-scaled over the ranks' row
-    bands, Gaussians broadcast once per step as ONE packed [N,8] buffer, per-Gaussian gradients reduce-scattered in
-    place (RCCL over xGMI).  Every multi-rank line carries it, so that the first real `--gpus 8` run measures the pattern
-    the north star names whatever its default exchange is."""
+def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast"):
+    """BASELINE config 4 on whatever group this run has: the 8192^2 image strong-scaled over the ranks' row bands.
+    exchange = "broadcast": as the north star states it -- Gaussians broadcast once per step as ONE packed [N,8] buffer,
+    per-Gaussian gradients reduce-scattered in place (64 MB per rank and step over xGMI whatever the band height);
+    exchange = "halo": the same image with a SHARDED producer -- every rank holds the Gaussians of its own LR rows and swaps
+    only those whose footprint crosses a band edge with ranks g-1 / g+1 (shard.BandExchange: a few hundred KB per step).
+    Every multi-rank line carries both, so that a real `--gpus 8` run measures them side by side whatever its headline is."""
     import copy
     import torch.distributed as dist
     a = copy.copy(args)
-    a.config, a.exchange, a.fwd_only, a.force_dist = "c4", "broadcast", False, True
+    a.config, a.exchange, a.fwd_only, a.force_dist = "c4", exchange, False, True
     st = Step(a, dev, rank, world)
 
     def barrier():
@@ -742,6 +744,15 @@ def strong_c4_leg(args, dev, rank, world, steps=5):
            "rccl": {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
                     "bytes_sent_per_rank_per_step": (32 * st.n + 32 * st.n) if world > 1 else 0,
                     "pattern": "broadcast of ONE packed [N,8] buffer (binned where it lands) + in-place reduce_scatter_tensor of the [N,8] gradients"}}
+    if st.halo:
+        st.ex.check()       # the timed steps dropped nothing (capacity) -- raises otherwise
+        out["gaussians_per_rank"] = st.n_rank
+        out["rccl"].update({"bytes_sent_per_rank_per_step": 2 * 2 * st.ex.cap * 32 if world > 1 else 0,
+                            "halo_records_max_per_edge": st.halo_records, "capacity": st.ex.cap,
+                            "pattern": ("2 x all_to_all_single with non-zero splits for ranks g-1/g+1 only" if st.ex.transport == "alltoall"
+                                        else "2 x batch_isend_irecv with ranks g-1/g+1") + " (forward records, backward gradients)"})
+    elif exchange == "halo":
+        out["note"] = "halo exchange unavailable on this group (see stderr): this leg ran broadcast + reduce_scatter"
     del st
     torch.cuda.empty_cache()
     return out
