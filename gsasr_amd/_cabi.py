@@ -26,7 +26,7 @@ EXPORTS = (
     "gsasr_band_select", "gsasr_band_merge", "gsasr_resolve_cutoff",
     "gsasr_sample_workspace_bytes", "gsasr_splat_sample_forward", "gsasr_splat_sample_backward",
     "gsasr_step_sample_forward", "gsasr_step_sample_backward",
-    "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm", "gsasr_plan_cutoff", "gsasr_release_launcher_scratch",
+    "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm", "gsasr_plan_cutoff", "gsasr_release_launcher_scratch", "gsasr_forward_subtile_width",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -41,6 +41,7 @@ FLAG_BWD_ATOMIC = 512      # GSASR_FLAG_BWD_ATOMIC
 FLAG_COUNTERS_CLEAN = 1024 # GSASR_FLAG_COUNTERS_CLEAN
 FLAG_PARITY = 2048         # GSASR_FLAG_PARITY
 FLAG_CUTOFF_CAP = 4096     # GSASR_FLAG_CUTOFF_CAP
+FLAG_FWD_WIDE, FLAG_FWD_NARROW = 8192, 16384      # forward kernel choice (development A/B, tests): 16x16 / 8x16 sub-tiles
 EXACT_CUTOFF = 104.0    # GSASR_SPLAT_EXACT_CUTOFF
 NO_CUTOFF = -1.0
 
@@ -119,6 +120,8 @@ def lib():
         L.gsasr_get_default_cutoff.restype = f
         L.gsasr_resolve_cutoff.restype = f
         L.gsasr_resolve_cutoff.argtypes = [f, i]
+        L.gsasr_forward_subtile_width.restype = i
+        L.gsasr_forward_subtile_width.argtypes = [dp]
         L.gsasr_plan_cutoff.restype = i
         L.gsasr_plan_cutoff.argtypes = [dp, vp, sz, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]
         if L.gsasr_abi_version() != 4:
@@ -344,9 +347,9 @@ def _dims_with(p: Plan, extra_flags: int) -> Dims:
     return d
 
 
-def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = False) -> torch.Tensor:
+def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = False, flags: int = 0) -> torch.Tensor:
     """img += splat (reference contract), or img = splat when `overwrite` (img may be torch.empty).
-    `chw`: img is planar [3, rows, W] instead of [rows, W, 3]."""
+    `chw`: img is planar [3, rows, W] instead of [rows, W, 3].  `flags`: FLAG_FWD_WIDE / FLAG_FWD_NARROW (kernel choice)."""
     d0 = p.dims
     rows = d0.row1 - d0.row0
     if chw:
@@ -357,11 +360,17 @@ def forward(p: Plan, img: torch.Tensor, overwrite: bool = False, chw: bool = Fal
         pi = _ptr3(img, "rendered_img", 3)
         if img.dim() != 3 or img.shape[0] != rows or img.shape[1] != d0.w or img.device != p.device:
             raise RuntimeError("rendered_img does not match the plan (shape / device)")
-    d = _dims_with(p, (FLAG_OVERWRITE_IMAGE if overwrite else 0) | (FLAG_CHW_IMAGE if chw else 0))
+    d = _dims_with(p, (FLAG_OVERWRITE_IMAGE if overwrite else 0) | (FLAG_CHW_IMAGE if chw else 0) |
+                   (flags & (FLAG_FWD_WIDE | FLAG_FWD_NARROW)))
     with _on(p.device):
         check(lib().gsasr_splat_forward(ctypes.byref(d), p.workspace.data_ptr(), p.workspace.numel(), pi,
                                         _stream(p.device)), "gsasr_splat_forward")
     return img
+
+
+def forward_subtile_width(p: Plan, flags: int = 0) -> int:
+    """16 when `forward(p, ..., flags=flags)` runs the wide forward (16 x 16 sub-tiles), 8 for the 8 x 16 kernels"""
+    return int(lib().gsasr_forward_subtile_width(ctypes.byref(_dims_with(p, flags & (FLAG_FWD_WIDE | FLAG_FWD_NARROW)))))
 
 
 def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors, overwrite: bool = False) -> None:

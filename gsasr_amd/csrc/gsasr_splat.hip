@@ -82,11 +82,9 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #ifndef BWD_UNROLL_OCC
 #define BWD_UNROLL_OCC 6
 #endif
-#ifndef FWD_TALL_ROWS
-#define FWD_TALL_ROWS 4     // sub-tile rows per workgroup tile at large scale factors
-#endif
-#ifndef FWD_TALL_MIN
-#define FWD_TALL_MIN 200.0   // HR pixels per Gaussian from which the tall tile is used (x24: -11%; x12, x8: no gain)
+#ifndef FWD_WIDE_MIN
+#define FWD_WIDE_MIN 25.0    // HR pixels per Gaussian from which the wide forward (16 x 16 sub-tiles, k_render_fwd16) is used:
+                             // x5 -3..-7%, x8 -4..-10%, x12 -13..-15%, x16 -20%, x32 -25%; x4: +8% (profiles/r04_fwd_wide.txt)
 #endif
 #ifndef BWD_UNROLL_MIN
 #define BWD_UNROLL_MIN 32.0
@@ -216,17 +214,31 @@ int classify_blocks(const gsasr_dims *d)
 }
 
 // which backward kernel: explicit flag > environment GSASR_SPLAT_BWD (gaussian | tile | atomic; development A/B) > default
-// development switch (like GSASR_SPLAT_BWD): GSASR_SPLAT_FWD_TALL=0 / 1 forces the tall forward tile off / on
-int fwd_tall_env()
+// development switch: GSASR_SPLAT_FWD_WIDE=0 / 1 forces the wide forward (16 x 16 sub-tiles) off / on
+int fwd_wide_env()
 {
-    static std::atomic<int> cached{-2};   // -2 = not read yet; a race re-reads the same environment: benign
+    static std::atomic<int> cached{-2};
     int v = cached.load(std::memory_order_relaxed);
     if (v == -2) {
-        const char *e = getenv("GSASR_SPLAT_FWD_TALL");
+        const char *e = getenv("GSASR_SPLAT_FWD_WIDE");
         v = !e ? -1 : atoi(e) != 0;
         cached.store(v, std::memory_order_relaxed);
     }
     return v;
+}
+
+// Which forward kernel.  Scale factors from x5 up (FWD_WIDE_MIN HR pixels per Gaussian: windows of ~25 px and more), single
+// images of at least 2 Mpx (16 384 sub-tiles of 8 x 16): 16 x 16 sub-tiles, four pixels per lane (k_render_fwd16).
+// GSASR_FLAG_FWD_WIDE / _NARROW (or the environment) override the rule for A/B runs and tests -- the wide kernel renders any
+// single image.
+bool fwd_wants_wide(const gsasr_dims *d)
+{
+    const int want = (d->flags & GSASR_FLAG_FWD_WIDE) ? 1 : (d->flags & GSASR_FLAG_FWD_NARROW) ? 0 : fwd_wide_env();
+    if (d->batch > 1 || want == 0) return false;
+    if (want == 1) return true;
+    const int rows = d->row1 - d->row0;
+    const long nsub = (long)((d->w + SUBX - 1) / SUBX) * ((rows + SUBY - 1) / SUBY);
+    return nsub >= 2 * 8192 && (double)rows * (double)d->w >= FWD_WIDE_MIN * (double)d->s;
 }
 
 int bwd_env()
@@ -1346,6 +1358,67 @@ __device__ __forceinline__ void fwd_eval_one(const float4 a, const float4 b, flo
     }
 }
 
+// The same evaluation split into its column part and its row part: the pixels of a lane of the WIDE forward
+// (k_render_fwd16: four per lane, one column) share dx, U, -U^2 and NR U of a record -- four of the ten instructions.
+struct FwdCol {
+    float k0, ru;   // -U^2, NR U
+    bool inx;       // (TEST) |dx| <= dmax
+};
+
+template <bool TEST>
+__device__ __forceinline__ FwdCol fwd_eval_col(const float4 a, float px, float dmax)
+{
+    const float dx = px - a.x;
+    const float u = a.z * dx;
+    FwdCol c;
+    c.k0 = -u * u;
+    c.ru = a.w * u;
+    c.inx = !TEST || fabsf(dx) <= dmax;
+    return c;
+}
+
+template <bool TEST>
+__device__ __forceinline__ void fwd_eval_row(const FwdCol c, const float4 a, const float4 b, v2f py, float dmax, v2f &ar,
+                                             v2f &ag, v2f &ab)
+{
+    const v2f dy = py - a.y;
+    const v2f bq = b.x * dy + c.ru;
+    const v2f pw = c.k0 - bq * bq;
+    v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+    if (TEST) {
+        v.x = (c.inx && fabsf(dy.x) <= dmax) ? v.x : 0.f;
+        v.y = (c.inx && fabsf(dy.y) <= dmax) ? v.y : 0.f;
+    }
+    ar += v * b.y;
+    ag += v * b.z;
+    {   // (see fwd_eval_one: b.w as the high half of the (g, b) pair; s_nop for the trans-use hazard)
+        const v2f gb = {b.z, b.w};
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(ab) : "v"(gb), "v"(v));
+    }
+}
+
+// records [beg, end) of the stage on the lane's four pixels (row pairs pyA, pyB); acc = {rA, gA, bA, rB, gB, bB}
+template <bool TEST>
+__device__ __forceinline__ void fwd_eval_lds16(const float4 *__restrict__ st, int beg, int end, float px, v2f pyA, v2f pyB,
+                                               float dmax, v2f (&acc)[6])
+{
+    int i = beg;
+    for (; i + 1 < end; i += 2) {   // two records per iteration so their dependent chains interleave
+        const float4 a0 = st[2 * i], b0 = st[2 * i + 1], a1 = st[2 * i + 2], b1 = st[2 * i + 3];
+        const FwdCol c0 = fwd_eval_col<TEST>(a0, px, dmax), c1 = fwd_eval_col<TEST>(a1, px, dmax);
+        fwd_eval_row<TEST>(c0, a0, b0, pyA, dmax, acc[0], acc[1], acc[2]);
+        fwd_eval_row<TEST>(c1, a1, b1, pyA, dmax, acc[0], acc[1], acc[2]);
+        fwd_eval_row<TEST>(c0, a0, b0, pyB, dmax, acc[3], acc[4], acc[5]);
+        fwd_eval_row<TEST>(c1, a1, b1, pyB, dmax, acc[3], acc[4], acc[5]);
+    }
+    if (i < end) {
+        const float4 a = st[2 * i], b = st[2 * i + 1];
+        const FwdCol c = fwd_eval_col<TEST>(a, px, dmax);
+        fwd_eval_row<TEST>(c, a, b, pyA, dmax, acc[0], acc[1], acc[2]);
+        fwd_eval_row<TEST>(c, a, b, pyB, dmax, acc[3], acc[4], acc[5]);
+    }
+}
+
 template <bool TEST>
 __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int beg, int end, float px, v2f py,
                                              float dmax, v2f &ar, v2f &ag, v2f &ab)
@@ -1495,28 +1568,19 @@ constexpr int COARSE_LIST = 4 * COARSE_CHUNKS * 64;       // candidates per roun
 
 // PARTS = 2: eight waves per workgroup, two per sub-tile taking alternate chunks of the survivor list (images with
 // fewer sub-tiles than the chip has wave slots); the caller adds the two partial sums.
-// ROWS > 1 (large scale factors, single images): the workgroup's tile is 32 x 16 ROWS pixels -- the cooperative
-// level 1 runs once for ROWS sub-tile rows, and every wave then takes its column of ROWS sub-tiles one after the other
-// (same px, its own py, its own accumulators).  At x24 finding the hits was 37% of the forward (one candidate per
-// 2.3 cells, 17 x 17 cells within reach of a tile: segment table, candidate lookup and window tests are per TILE work).
-template <bool BOUNDED, int PARTS, int ROWS>
+template <bool BOUNDED, int PARTS>
 __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, int bx0, int by0, int wv, int lane,
-                                          float4 *stage, unsigned *s_list, unsigned *s_cnt, v2f (&ar)[ROWS], v2f (&ag)[ROWS],
-                                          v2f (&ab)[ROWS])
+                                          float4 *stage, unsigned *s_list, unsigned *s_cnt, v2f &ar, v2f &ag, v2f &ab)
 {
-    const int bx1 = min(bx0 + 4 * SUBX - 1, P.w - 1), by1 = min(by0 + ROWS * SUBY - 1, P.row1 - 1);
+    const int bx1 = min(bx0 + 4 * SUBX - 1, P.w - 1), by1 = min(by0 + SUBY - 1, P.row1 - 1);
     const int sx0 = bx0 + (wv & 3) * SUBX;
     const unsigned part = (unsigned)(wv >> 2);
     const bool live = sx0 < P.w;                              // wave-uniform (image width not a multiple of 32)
     const int sx1 = min(sx0 + SUBX - 1, P.w - 1);
     const int X = sx0 + (lane & 7);
     const float px = V.px[(P.batch > 1 ? (by0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
-    v2f pyr[ROWS];
-#pragma unroll
-    for (int sr = 0; sr < ROWS; ++sr) {
-        const int Y0 = by0 + sr * SUBY + (lane >> 3);
-        pyr[sr] = (v2f){V.py[min(Y0, P.h - 1)], V.py[min(Y0 + 8, P.h - 1)]};
-    }
+    const int Y0 = by0 + (lane >> 3);
+    const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y0 + 8, P.h - 1)]};
     const float4 *__restrict__ rec = V.rec;
     const uint4 *__restrict__ bbox = V.bbox;
     const unsigned *__restrict__ cs = V.cell_start;
@@ -1581,12 +1645,9 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
         if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0u;   // nobody touches the other counter before the next barrier
         const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)*cnt);
         // ---- phase B: the full test of the tile's survivors against this wave's sub-tile(s) -------------
-#pragma unroll
-        for (int sr = 0; sr < ROWS; ++sr) {
-        const int sy0 = by0 + sr * SUBY, sy1 = min(sy0 + SUBY - 1, P.row1 - 1);
+        const int sy0 = by0, sy1 = by1;
         const int wty = (sy0 - P.row0) >> SUBY_SHIFT;
-        const v2f py = pyr[sr];
-        if (live && (ROWS == 1 || sy0 < P.row1)) {
+        if (live) {
             const unsigned q0 = part * 64u;
             unsigned j = q0 + lane < n ? s_list[q0 + lane] : 0xffffffffu;
             const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);
@@ -1626,12 +1687,11 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
                         stage[2 * slot + 1] = src[1];
                     }
                     __builtin_amdgcn_wave_barrier();
-                    fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar[sr], ag[sr], ab[sr]);
-                    if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar[sr], ag[sr], ab[sr]);
+                    fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
+                    if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
                 }
                 j = nj; bb = nbb; bs = nbs;
             }
-        }
         }
         __syncthreads();   // the list is rewritten in the next round
     }
@@ -1692,10 +1752,9 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nb)
 
 // Two-level walk (fwd_block).  PARTS = 1: large images, the workgroup shape of k_render_fwd.  PARTS = 2: images
 // with fewer sub-tiles than wave slots -- eight waves, two per sub-tile, partial sums combined through LDS.
-template <bool BOUNDED, int PARTS, int ROWS>
+template <bool BOUNDED, int PARTS>
 __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView V, float *__restrict__ img, int tiles_x)
 {
-    static_assert(PARTS == 1 || ROWS == 1, "two waves per sub-tile only with one sub-tile row");
     const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
     const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
     const int lane = threadIdx.x & 63;
@@ -1706,26 +1765,188 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView 
     __shared__ float s_part[PARTS > 1 ? 4 : 1][6][64];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    v2f ar[ROWS], ag[ROWS], ab[ROWS];
-#pragma unroll
-    for (int sr = 0; sr < ROWS; ++sr) ar[sr] = ag[sr] = ab[sr] = (v2f){0.f, 0.f};
-    const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY * ROWS;
-    fwd_block<BOUNDED, PARTS, ROWS>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
+    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
+    const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
+    fwd_block<BOUNDED, PARTS>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
     const int sub = wv & 3;
     if (PARTS > 1) {   // (fwd_block ends on a barrier)
         if (wv >= 4) {
             float (*o)[64] = s_part[sub];
-            o[0][lane] = ar[0].x; o[1][lane] = ar[0].y; o[2][lane] = ag[0].x; o[3][lane] = ag[0].y; o[4][lane] = ab[0].x; o[5][lane] = ab[0].y;
+            o[0][lane] = ar.x; o[1][lane] = ar.y; o[2][lane] = ag.x; o[3][lane] = ag.y; o[4][lane] = ab.x; o[5][lane] = ab.y;
         }
         __syncthreads();
         if (wv >= 4) return;
         float (*o)[64] = s_part[sub];
-        ar[0].x += o[0][lane]; ar[0].y += o[1][lane]; ag[0].x += o[2][lane]; ag[0].y += o[3][lane]; ab[0].x += o[4][lane]; ab[0].y += o[5][lane];
+        ar.x += o[0][lane]; ar.y += o[1][lane]; ag.x += o[2][lane]; ag.y += o[3][lane]; ab.x += o[4][lane]; ab.y += o[5][lane];
     }
-    if (bx0 + sub * SUBX < P.w) {
+    if (bx0 + sub * SUBX < P.w) fwd_store(P, V, img, bx0 + sub * SUBX, by0, lane, ar, ag, ab);
+}
+
+// WIDE forward (large windows: x8 and up, single images).  A wave owns a 16 x 16 sub-tile, lane = column sx0 + lane%16 and
+// the four rows sy0 + lane/16 + {0, 4 | 8, 12}: two packed row pairs in ONE column, so a record's column arithmetic is done
+// once for four pixels (ten instructions + four v_exp_f32 per record and 256 pixels, against two times six + two for the
+// 8 x 16 sub-tile), and half as many waves search.  The workgroup's tile is 32 x 32 (2 x 2 sub-tiles), walked like
+// fwd_block: cooperative window test of the candidates against the tile, then every wave tests the survivors against its
+// own sub-tile.  Against this stands the coarser cull ((w + 16)(h + 16) instead of (w + 8)(h + 16) evaluated pixels per
+// window): it pays from ~40-px windows up.
+constexpr int WIDE = 16;   // sub-tile side
+
+__device__ __forceinline__ void fwd_store_px(const Params &P, float *__restrict__ img, int X, int Y, float r, float g, float b)
+{
+    if (Y >= P.row1) return;
+    const bool store = P.flags & GSASR_FLAG_OVERWRITE_IMAGE;
+    if (P.flags & GSASR_FLAG_CHW_IMAGE) {
+        const size_t plane = (size_t)(P.row1 - P.row0) * P.w;
+        float *o = img + (size_t)(Y - P.row0) * P.w + X;
+        if (store) { o[0] = r; o[plane] = g; o[2 * plane] = b; }
+        else { o[0] += r; o[plane] += g; o[2 * plane] += b; }
+        return;
+    }
+    float *o = img + ((size_t)(Y - P.row0) * P.w + X) * 3;
+    if (store) { o[0] = r; o[1] = g; o[2] = b; }
+    else { o[0] += r; o[1] += g; o[2] += b; }
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) void k_render_fwd16(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+{
+    const unsigned tt = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float4 s_stage[4][128];
+    __shared__ unsigned s_list[COARSE_LIST];
+    __shared__ unsigned s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int bx0 = (int)(tt % (unsigned)tiles_x) * 2 * WIDE, by0 = P.row0 + (int)(tt / (unsigned)tiles_x) * 2 * WIDE;
+    const int bx1 = min(bx0 + 2 * WIDE - 1, P.w - 1), by1 = min(by0 + 2 * WIDE - 1, P.row1 - 1);
+    const int sx0 = bx0 + (wv & 1) * WIDE, sy0 = by0 + (wv >> 1) * WIDE;
+    const bool live = sx0 < P.w && sy0 < P.row1;                  // wave-uniform
+    const int sx1 = min(sx0 + WIDE - 1, P.w - 1), sy1 = min(sy0 + WIDE - 1, P.row1 - 1);
+    const int X = sx0 + (lane & 15), Y = sy0 + (lane >> 4);
+    const float px = V.px[min(X, P.w - 1)];
+    const v2f pyA = {V.py[min(Y, P.h - 1)], V.py[min(Y + 4, P.h - 1)]};
+    const v2f pyB = {V.py[min(Y + 8, P.h - 1)], V.py[min(Y + 12, P.h - 1)]};
+    float4 *stage = s_stage[wv];
+    const float4 *__restrict__ rec = V.rec;
+    const uint4 *__restrict__ bbox = V.bbox;
+    const unsigned *__restrict__ cs = V.cell_start;
+    const int wtx = sx0 >> SUBX_SHIFT, wty = (sy0 - P.row0) >> SUBY_SHIFT;   // in the units of k_bin's spans (8 columns, 16 rows)
+
+    // segment table of the 32x32 tile (every wave builds the same one; cf. fwd_block)
+    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
+    int nseg = 0;
+    unsigned sbeg = 0, send = 0;
+    if (rx > 0) {
+        const int cx0 = max(bx0 - rx, 0) >> CELL_SHIFT, cx1 = min((bx1 + rx) >> CELL_SHIFT, P.ncx - 1);
+        const int cy0 = max(by0 - ry, 0) >> CELL_SHIFT, cy1 = min((by1 + ry) >> CELL_SHIFT, P.ncy - 1);
+        nseg = cy1 - cy0 + 1;
+        if (lane < nseg) {
+            sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+            send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
+        }
+    }
+    if (lane == nseg) {
+        sbeg = cs[P.ncells];
+        send = cs[P.ncells + 1];
+    }
+    ++nseg;
+    const unsigned len = send - sbeg;
+    unsigned pin = len;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)pin, o);
+        if (lane >= o) pin += v;
+    }
+    const unsigned pex = pin - len;
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+    const unsigned nchunks = (total + 63u) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rseg = 0;
+    v2f acc[6];
 #pragma unroll
-        for (int sr = 0; sr < ROWS; ++sr)
-            if (ROWS == 1 || by0 + sr * SUBY < P.row1) fwd_store(P, V, img, bx0 + sub * SUBX, by0 + sr * SUBY, lane, ar[sr], ag[sr], ab[sr]);
+    for (int k = 0; k < 6; ++k) acc[k] = (v2f){0.f, 0.f};
+
+    for (unsigned base = 0, round = 0; base < nchunks; base += 4u * COARSE_CHUNKS, ++round) {
+        unsigned *cnt = s_cnt + (round & 1u);
+        // ---- phase A: this wave's share of the round's chunks against the whole tile -------------------
+        unsigned cj[COARSE_CHUNKS];
+        uint2 cw[COARSE_CHUNKS];
+#pragma unroll
+        for (int k = 0; k < COARSE_CHUNKS; ++k) {
+            const unsigned c = base + (unsigned)wv + 4u * (unsigned)k;
+            cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
+            cw[k] = make_uint2(0x7fffu, 0x7fffu);
+            if (cj[k] != 0xffffffffu) cw[k] = V.win[cj[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < COARSE_CHUNKS; ++k) {
+            const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
+            const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
+            const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                unsigned at = 0;
+                if (lane == 0) at = atomicAdd(cnt, (unsigned)__builtin_popcountll(m));
+                at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+                if (hit) s_list[at + (unsigned)__builtin_popcountll(m & below)] = cj[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0u;
+        const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)*cnt);
+        // ---- phase B: the full test of the tile's survivors against this wave's sub-tile ------------------
+        if (live) {
+            unsigned j = (unsigned)lane < n ? s_list[lane] : 0xffffffffu;
+            const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);
+            uint4 bb = dead;
+            uint2 bs = make_uint2(0u, 0u);
+            if (j != 0xffffffffu) {
+                bb = bbox[2 * (size_t)j];
+                bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)j + 1);
+            }
+            for (unsigned q = 0; q < n; q += 64u) {
+                const unsigned nq = q + 64u + (unsigned)lane;
+                const unsigned nj = nq < n ? s_list[nq] : 0xffffffffu;
+                uint4 nbb = dead;
+                uint2 nbs = make_uint2(0u, 0u);
+                if (nj != 0xffffffffu) {
+                    nbb = bbox[2 * (size_t)nj];
+                    nbs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)nj + 1);
+                }
+                const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+                const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+                bool hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
+                if (bb.y & 0x8000u) {  // per-tile-row column spans (k_bin), in 8-column units: the sub-tile covers two
+                    const unsigned t = (unsigned)(wty - ((r0 - P.row0) >> SUBY_SHIFT)) & 7u, sh = (t & 3u) * 8u;
+                    const unsigned lo = t < 4u ? bb.z : bs.x, hi = t < 4u ? bb.w : bs.y;
+                    const int txr = wtx - (c0 >> SUBX_SHIFT);
+                    hit &= (txr + 1 >= (int)((lo >> sh) & 0xffu)) & (txr <= (int)((hi >> sh) & 0xffu));
+                }
+                const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
+                const unsigned long long m0 = __ballot(hit && !needs), m1 = __ballot(hit && needs);
+                const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
+                if (n0 + n1) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (hit) {
+                        const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
+                        const float4 *src = rec + 2 * (size_t)j;
+                        stage[2 * slot] = src[0];
+                        stage[2 * slot + 1] = src[1];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    fwd_eval_lds16<false>(stage, 0, n0, px, pyA, pyB, P.dmax, acc);
+                    if (BOUNDED) fwd_eval_lds16<true>(stage, n0, n0 + n1, px, pyA, pyB, P.dmax, acc);
+                }
+                j = nj; bb = nbb; bs = nbs;
+            }
+        }
+        __syncthreads();   // the list is rewritten in the next round
+    }
+    if (live && X < P.w) {
+        fwd_store_px(P, img, X, Y, acc[0].x, acc[1].x, acc[2].x);
+        fwd_store_px(P, img, X, Y + 4, acc[0].y, acc[1].y, acc[2].y);
+        fwd_store_px(P, img, X, Y + 8, acc[3].x, acc[4].x, acc[5].x);
+        fwd_store_px(P, img, X, Y + 12, acc[3].y, acc[4].y, acc[5].y);
     }
 }
 
@@ -3311,7 +3532,12 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     const int subs_x = (dims->w + SUBX - 1) / SUBX, tiles_y = (rows + SUBY - 1) / SUBY;
     hipStream_t st = (hipStream_t)stream;
     const long nsub = (long)subs_x * tiles_y;
-    if (nsub < 4096) {
+    if (fwd_wants_wide(dims)) {
+        const int wx = (dims->w + 2 * WIDE - 1) / (2 * WIDE), wy = (rows + 2 * WIDE - 1) / (2 * WIDE);
+        const dim3 grid((unsigned)wx * (unsigned)wy), block(256);
+        if (P.bounded) hipLaunchKernelGGL(k_render_fwd16<true>, grid, block, 0, st, P, V, img, wx);
+        else hipLaunchKernelGGL(k_render_fwd16<false>, grid, block, 0, st, P, V, img, wx);
+    } else if (nsub < 4096) {
         // fewer sub-tiles than half the chip's 8192 wave slots: split each sub-tile's Gaussian list over
         // 2..16 waves so that about one full set of waves is in flight
         int nw = 2;
@@ -3326,24 +3552,23 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         // of config 5) get two waves per sub-tile (measured -13% at 4608 sub-tiles, +2..14% above 8192)
         const int tx4 = (subs_x + 3) / 4;
         const bool two = nsub < 8192;
-        // Large scale factors (from FWD_TALL_MIN HR pixels per Gaussian, single images with plenty of tiles): tiles of
-        // 32 x 64 pixels -- the per-tile search is shared by four sub-tile rows (fwd_block)
-        const bool tall = !two && dims->batch <= 1 && nsub >= 4 * 8192 && fwd_tall_env() != 0 &&
-                          (fwd_tall_env() == 1 || (double)rows * (double)dims->w >= FWD_TALL_MIN * (double)dims->s);
-        const int ty = tall ? (tiles_y + FWD_TALL_ROWS - 1) / FWD_TALL_ROWS : tiles_y;
-        const dim3 grid((unsigned)tx4 * (unsigned)ty), block(two ? 512 : 256);
+        const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
         if (P.bounded) {
-            if (two) hipLaunchKernelGGL((k_render_fwd2<true, 2, 1>), grid, block, 0, st, P, V, img, tx4);
-            else if (tall) hipLaunchKernelGGL((k_render_fwd2<true, 1, FWD_TALL_ROWS>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd2<true, 1, 1>), grid, block, 0, st, P, V, img, tx4);
+            if (two) hipLaunchKernelGGL((k_render_fwd2<true, 2>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd2<true, 1>), grid, block, 0, st, P, V, img, tx4);
         } else {
-            if (two) hipLaunchKernelGGL((k_render_fwd2<false, 2, 1>), grid, block, 0, st, P, V, img, tx4);
-            else if (tall) hipLaunchKernelGGL((k_render_fwd2<false, 1, FWD_TALL_ROWS>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd2<false, 1, 1>), grid, block, 0, st, P, V, img, tx4);
+            if (two) hipLaunchKernelGGL((k_render_fwd2<false, 2>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd2<false, 1>), grid, block, 0, st, P, V, img, tx4);
         }
     }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;
+}
+
+int gsasr_forward_subtile_width(const gsasr_dims *dims)
+{
+    if (!dims || dims->s <= 0 || dims->w <= 0 || dims->row1 < dims->row0) return fail(GSASR_ERR_ARG, "bad dims");
+    return fwd_wants_wide(dims) ? WIDE : SUBX;
 }
 
 }  // extern "C"

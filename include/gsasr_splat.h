@@ -94,6 +94,11 @@ enum gsasr_status {
                                          use it as given, the windows the data-derived tau' <= cutoff (gsasr_plan_cutoff).  For
                                          callers that must name the conservative tau themselves (the row-band exchange: the
                                          selection of halo Gaussians and the neighbour's plan have to agree on it) */
+#define GSASR_FLAG_FWD_WIDE 8192u      /* forward kernel choice (default: the library picks by scale factor and image size): 16 x 16
+                                         sub-tiles, four pixels per lane (scale factors from x5 up) ... */
+#define GSASR_FLAG_FWD_NARROW 16384u   /* ... or 8 x 16 sub-tiles, two pixels per lane.  Read by gsasr_splat_forward only (the plan
+                                         is the same); images too small for the two-level walk ignore both.  Same sums in a
+                                         different order: results agree to fp32 rounding */
 
 typedef struct gsasr_dims {
     int s;        /* number of Gaussians                                              */
@@ -296,6 +301,11 @@ GSASR_API float gsasr_resolve_cutoff(float cutoff, int s);
  * data-derived: explicit tau without GSASR_FLAG_CUTOFF_CAP, GSASR_SPLAT_ADAPT=0). */
 GSASR_API int gsasr_plan_cutoff(const gsasr_dims *dims, const void *workspace, size_t workspace_bytes, void *stream,
                                 float *tau, unsigned *k_box);
+
+/* Which forward kernel gsasr_splat_forward runs for these dims (flags included; no device work; for reports and tests):
+ * the width of a wave's sub-tile in pixels -- 16 = the wide forward (16 x 16 sub-tiles, four pixels per lane: scale factors
+ * from x5 up on single images of 2 Mpx and more, or GSASR_FLAG_FWD_WIDE), 8 = the 8 x 16 kernels.  < 0: invalid dims. */
+GSASR_API int gsasr_forward_subtile_width(const gsasr_dims *dims);
 
 #ifdef __cplusplus
 }

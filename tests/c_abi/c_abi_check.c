@@ -320,6 +320,29 @@ int main(void)
         OK(gsasr_splat_plan(d_sig, d_xy, d_col, &d, ws, bytes, st));
         OK(gsasr_plan_cutoff(&d, ws, bytes, st, &tau, &k));
         if (!(fabsf(tau - 32.f) < 1e-3f && k == 0u)) { printf("explicit cutoff not kept: %.3f %u\n", tau, k); bad = 1; }
+        /* forward kernel choice: a small x? image keeps the 8 x 16 sub-tiles, the flag forces the wide kernel, and both give
+         * the image of the plan above */
+        {
+            gsasr_dims dw = d;
+            const int w0 = gsasr_forward_subtile_width(&dw);
+            dw.flags |= GSASR_FLAG_FWD_WIDE;
+            const int w1 = gsasr_forward_subtile_width(&dw);
+            printf("forward sub-tile width: default %d, GSASR_FLAG_FWD_WIDE %d\n", w0, w1);
+            if (w0 != 8 || w1 != 16) bad = 1;
+            float *im2 = (float *)malloc(sizeof(float) * 3 * h * w);
+            for (int pass = 0; pass < 2; ++pass) {
+                gsasr_dims df = d;
+                df.flags |= GSASR_FLAG_OVERWRITE_IMAGE | (pass ? GSASR_FLAG_FWD_WIDE : GSASR_FLAG_FWD_NARROW);
+                OK(gsasr_splat_forward(&df, ws, bytes, d_img, st));
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(pass ? im2 : img, d_img, sizeof(float) * 3 * h * w, hipMemcpyDeviceToHost));
+            }
+            double e = 0;
+            for (int i = 0; i < 3 * h * w; ++i) { double dd = fabs((double)img[i] - (double)im2[i]); if (dd > e) e = dd; }
+            printf("wide vs narrow forward: max |diff| %.3g\n", e);
+            if (!(e <= 1e-5)) bad = 1;
+            free(im2);
+        }
         CK(hipFree(ws));
         /* the launchers above left their scratch behind for this stream: a second round reuses it, a release frees it,
          * and the round after that allocates again -- same image every time */

@@ -285,24 +285,25 @@ def test_config4_full_size_band_against_oracle(dev):
     assert L.gsasr_splat_workspace_bytes(ctypes.byref(whole)) > L.gsasr_splat_workspace_bytes(ctypes.byref(forced))
 
 
-def test_large_scale_forward_tall_tiles_against_oracle(dev):
-    """x32 inference shape (57x72 LR -> 1824x2304, 1024 HR pixels per Gaussian): from 200 pixels per Gaussian and 32 768
-    sub-tiles up the forward renders 32x64-px workgroup tiles (four sub-tile rows per level-1 pass; gsasr_splat_forward).
-    1824 rows = 28.5 such tiles: the last one is ragged.  Bands at the top, across a tile boundary and at the ragged
-    end, bounded and unbounded, against the oracle with every Gaussian"""
+def test_large_scale_forward_against_oracle(dev):
+    """x32 inference shape (57x72 LR -> 1824x2304, 1024 HR pixels per Gaussian, windows of ~170 px): the library renders
+    it with the wide forward (16x16 sub-tiles; gsasr_splat_forward).  1824 rows = 57 tiles of 32, 2304 columns = 72.
+    Bands at the top, across a tile boundary and at the end, bounded and unbounded, against the oracle with every
+    Gaussian -- through the default choice and through the 8x16 kernels"""
     from gsasr_amd import _cabi, synthetic
     from oracle import gs_oracle
     sig, xy, col, H, W = synthetic.kernel_inputs(57, 72, 32.0, seed=5)
-    assert (H, W) == (1824, 2304) and (W // 8) * (H // 16) >= 32768 and H * W >= 200 * sig.shape[0]
+    assert (H, W) == (1824, 2304) and (W // 8) * (H // 16) >= 16384 and H * W >= 25 * sig.shape[0]
     a, b, c = sig.to(dev), xy.to(dev), col.to(dev)
     for dmax in (0.1, None):
         plan = _cabi.plan(a, b, c, H, W, dmax, flags=_cabi.FLAG_FORWARD_ONLY)
-        img = torch.full((H, W, 3), float("nan"), device=dev)
-        _cabi.forward(plan, img, overwrite=True)
-        assert bool(torch.isfinite(img).all())
-        for rows in ((0, 16), (56, 72), (1784, 1824)):
-            ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax, rows=rows)
-            assert np.abs(img[rows[0]:rows[1]].cpu().numpy() - ref).max() <= IMG_ATOL * max(1.0, float(np.abs(ref).max()))
+        for flag in (0, _cabi.FLAG_FWD_NARROW):
+            img = torch.full((H, W, 3), float("nan"), device=dev)
+            _cabi.forward(plan, img, overwrite=True, flags=flag)
+            assert bool(torch.isfinite(img).all())
+            for rows in ((0, 16), (56, 72), (1784, 1824)):
+                ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax, rows=rows)
+                assert np.abs(img[rows[0]:rows[1]].cpu().numpy() - ref).max() <= IMG_ATOL * max(1.0, float(np.abs(ref).max()))
 
 
 @pytest.mark.parametrize("dmax", [0.1, 0.5])
