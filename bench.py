@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
+from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, pair_ceiling, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
                       exact_runs, live_hbm_traffic, flush_c_stdio, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
 
 
@@ -225,10 +225,10 @@ def main():
                     "note": "pairs = (Gaussian, pixel) terms; box = what gs_cuda_dmax sums, swept window = box ∩ support cutoff"}
             # fraction of the pair-evaluation ceiling (the roof that binds): swept pairs/s over SIMDs * clock / cycles per
             # packed trip * 128 pairs, with the instruction counts the ceiling assumes
-            valu["ceiling"] = {k: PAIR_CEILING[k] for k in kern if k in PAIR_CEILING}
+            valu["ceiling"] = {k: pair_ceiling(step, k) for k in kern if k in PAIR_CEILING}
             valu["ceiling_note"] = ("1024 SIMDs x 2.4 GHz; wave64 VALU (packed fp32 included) = 4 cycles, v_exp_f32 = 8 cycles "
                                     "(tools/valu_rate.hip); one packed trip = 128 pairs")
-            roofline["valu_frac"] = {k: swept / (kern[k]["avg_ms"] * 1e-3) / PAIR_CEILING[k]["pairs_per_s"]
+            roofline["valu_frac"] = {k: swept / (kern[k]["avg_ms"] * 1e-3) / pair_ceiling(step, k)["pairs_per_s"]
                                      for k in kern if k in PAIR_CEILING}
             if os.path.exists(pmc) and args.config == "c2" and world == 1:
                 try:
@@ -280,6 +280,7 @@ def main():
                                       "parity tolerance 1e-4, all parity tests run at this default); "
                                       "--cutoff 104 sums the reference's exact set of non-zero fp32 terms, --cutoff -1 every in-box term",
                        "launch": launch,
+                       "forward_subtile_px": None if step.batched else step.cabi.forward_subtile_width(step.plan),   # 16 = wide forward (x5 and up)
                        "parallelism": (f"data-parallel x{world} (one batch per rank, no exchange)" if step.batched and world > 1
                                        else f"row-band x{world}" if world > 1 else "single")},
             "roofline": roofline, "kernels": kern,

@@ -238,7 +238,9 @@ bool fwd_wants_wide(const gsasr_dims *d)
     if (want == 1) return true;
     const int rows = d->row1 - d->row0;
     const long nsub = (long)((d->w + SUBX - 1) / SUBX) * ((rows + SUBY - 1) / SUBY);
-    return nsub >= 2 * 8192 && (double)rows * (double)d->w >= FWD_WIDE_MIN * (double)d->s;
+    // (pixels of the WHOLE grid per Gaussian = the scale factor squared: a row band that is handed every Gaussian of the image
+    // has the image's window sizes, not those of rows * w / s)
+    return nsub >= 2 * 8192 && (double)d->h * (double)d->w >= FWD_WIDE_MIN * (double)d->s;
 }
 
 int bwd_env()

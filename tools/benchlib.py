@@ -385,12 +385,22 @@ def copy_bandwidth(dev):
 # chip: a wave64 VALU instruction -- packed fp32 included -- issues in 4 cycles per SIMD, v_exp_f32 in 8).  One packed
 # trip evaluates 128 (Gaussian, pixel) pairs:
 #   forward  : 12 VALU + 2 v_exp_f32 = 64 cycles   (fwd_eval_one in gsasr_splat.hip)
+#   forward, wide kernel (16 x 16 sub-tiles, x5 and up): a record's column part (4 VALU) serves TWO packed trips of
+#              6 VALU + 2 v_exp_f32 each: 16 VALU + 4 v_exp_f32 = 96 cycles per 256 pairs = 48 per 128 (fwd_eval_lds16)
 #   backward : 14 VALU + 2 v_exp_f32 = 72 cycles   (bwd_trip: residual, exponent, <grad, colour>, 3 moments, 3 colour sums)
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 PAIR_CEILING = {"forward": {"valu": 12, "exp": 2, "cycles_per_128_pairs": 64},
+                "forward_wide": {"valu": 8, "exp": 2, "cycles_per_128_pairs": 48},
                 "backward": {"valu": 14, "exp": 2, "cycles_per_128_pairs": 72}}
 for _k in PAIR_CEILING.values():
     _k["pairs_per_s"] = SIMDS * CLOCK_HZ / _k["cycles_per_128_pairs"] * 128.0
+
+
+def pair_ceiling(step, stage):
+    """the ceiling entry of `stage` for the kernel this step's plan actually runs (the forward has two)"""
+    if stage == "forward" and not getattr(step, "batched", False) and step.cabi.forward_subtile_width(step.plan) == 16:
+        return PAIR_CEILING["forward_wide"]
+    return PAIR_CEILING[stage]
 
 
 def flush_c_stdio():
@@ -661,7 +671,7 @@ def pair_rates(step, kern, cutoff):
     """swept (Gaussian, pixel) pairs of the step's windows and the fraction of the pair-evaluation ceiling each kernel reaches"""
     tau, _ = effective_tau(step, cutoff)
     in_box, swept = window_pairs(step.sig, step.xy, step.H, step.W, step.dmax, tau, step.rows)
-    frac = {k: swept / (kern[k]["avg_ms"] * 1e-3) / PAIR_CEILING[k]["pairs_per_s"] for k in kern if k in PAIR_CEILING}
+    frac = {k: swept / (kern[k]["avg_ms"] * 1e-3) / pair_ceiling(step, k)["pairs_per_s"] for k in kern if k in PAIR_CEILING}
     return in_box, swept, frac
 
 
@@ -693,6 +703,7 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
            "cutoff_tau": round(tau_eff, 3), "cutoff_k_box": k_box,
            "cutoff_tau_conservative": round(st.cabi.resolve_cutoff(a.cutoff, st.plan.dims.s), 3),
            "what": "fwd only" if st.fwd_only else "fwd+bwd",
+           "forward_subtile_px": st.cabi.forward_subtile_width(st.plan),    # 16 = the wide forward (x5 and up), 8 = the 8 x 16 kernels
            "steps": n, "ms_per_step": ms, "value": st.H * st.W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
            "kernels": kern,
            "roofline": {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
