@@ -686,7 +686,9 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
         setattr(a, k, v)
     st = Step(a, dev, 0, 1)
     n = steps or (20 if st.H * st.W > 4e7 else 50)
-    ms = wall_ms(st, n, dev, warm=3)
+    # (as many untimed steps as the standalone run of this config gets before its timed loop: three leave the GPU's clocks
+    # still ramping after the host-side set-up, which cost the x12 and x8 legs 5-9%)
+    ms = wall_ms(st, n, dev, warm=max(10, n // 2))
     kern = stage_times(st, dev, iters=10 if st.H * st.W > 4e7 else 20)
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
     in_box, swept, vfrac = pair_rates(st, kern, a.cutoff)
@@ -735,7 +737,7 @@ def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast"):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(2):
+    for _ in range(8):
         st()
     barrier()
     t0 = time.perf_counter()

@@ -35,7 +35,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     d = json.load(open(p))
-    for k, name in (("k_render_fwd", "k_render_fwd2<true, 1,"), ("k_render_bwd", "k_render_bwd<true")):
+    for k, name in (("k_render_fwd", "k_render_fwd2<true, 1>"), ("k_render_bwd", "k_render_bwd<true")):
         f = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch.txt"), name, "FETCH_SIZE")
         w = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_write.txt"), name, "WRITE_SIZE")
         d[k].update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes=int((2 * f + w) * 1024))
