@@ -124,3 +124,32 @@ def test_explicit_cutoffs_and_a_window_wider_than_255_columns(dev):
     wide, narrow = _both(sig, xy, col, H, W, None, dev)
     assert np.abs(wide.cpu().numpy() - ref).max() <= IMG_ATOL
     assert np.abs(narrow.cpu().numpy() - ref).max() <= IMG_ATOL
+
+
+def test_host_api_at_x8_runs_the_wide_forward_and_matches_the_oracle(dev):
+    """`generate_2D_gaussian_splatting_step` (utils/gaussian_splatting.py:158-217) at x8 on 2048^2: the fused step path (planar
+    CHW image, prologue fused into the plan) takes the wide forward; a band of the result against oracle(prologue(raw
+    parameters)), and the gradient of that band to the raw parameters against the oracle's analytic backward"""
+    from gsasr_amd import _cabi, gaussian_splatting as gsp, synthetic
+    from oracle import gs_oracle, host_ref
+    p = synthetic.gs_parameters(256, 256, seed=2)
+    H = W = 2048
+    sm = torch.tensor([8.0, 8.0])
+    d = _cabi.make_dims(p.shape[0], H, W, 0.1)
+    assert int(_cabi.lib().gsasr_forward_subtile_width(__import__("ctypes").byref(d))) == 16
+    pg = p.clone().to(dev).requires_grad_(True)
+    out = gsp.generate_2D_gaussian_splatting_step((H, W), pg, 8.0, sm.to(dev), if_dmax=True, dmax_mode="fix", dmax=0.1)
+    assert out.shape == (3, H, W)
+    sig, xy, col, dmax = host_ref.prologue(p, (H, W), sm, dmax=0.1, dmax_mode="fix")
+    rows = (1016, 1048)
+    ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax, rows=rows)
+    got = out.detach()[:, rows[0]:rows[1]].permute(1, 2, 0).cpu().numpy()
+    assert np.abs(got - ref).max() <= IMG_ATOL * max(1.0, float(np.abs(ref).max()))
+    wgt = synthetic.grad_image(rows[1] - rows[0], W, 4)
+    (out[:, rows[0]:rows[1]] * wgt.permute(2, 0, 1).to(dev)).sum().backward()
+    pr = p.clone().double().requires_grad_(True)
+    s2, x2, c2, _ = host_ref.prologue(pr, (H, W), sm.double(), dmax=0.1, dmax_mode="fix")
+    g = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), dmax, h=H, rows=rows)
+    torch.autograd.backward([s2, x2, c2], [torch.from_numpy(a) for a in g])
+    want, have = pr.grad.numpy(), pg.grad.cpu().numpy()
+    assert np.abs(have - want).max() <= 2e-4 * np.abs(want).max()
