@@ -1399,8 +1399,10 @@ __device__ __forceinline__ void fwd_eval_row(const FwdCol c, const float4 a, con
     }
 }
 
-// records [beg, end) of the stage on the lane's four pixels (row pairs pyA, pyB); acc = {rA, gA, bA, rB, gB, bB}
-template <bool TEST>
+// records [beg, end) of the stage on the lane's pixels; acc = {rA, gA, bA, rB, gB, bB}.  HALVES: which of the lane's two row
+// pairs the records of this list reach -- 1 = pair A (the sub-tile's rows 0..7), 2 = pair B (rows 8..15), 3 = both
+// (k_render_fwd16 sorts a chunk's hits by that: a window that ends in the upper half costs one row part, not two).
+template <bool TEST, int HALVES>
 __device__ __forceinline__ void fwd_eval_lds16(const float4 *__restrict__ st, int beg, int end, float px, v2f pyA, v2f pyB,
                                                float dmax, v2f (&acc)[6])
 {
@@ -1408,16 +1410,20 @@ __device__ __forceinline__ void fwd_eval_lds16(const float4 *__restrict__ st, in
     for (; i + 1 < end; i += 2) {   // two records per iteration so their dependent chains interleave
         const float4 a0 = st[2 * i], b0 = st[2 * i + 1], a1 = st[2 * i + 2], b1 = st[2 * i + 3];
         const FwdCol c0 = fwd_eval_col<TEST>(a0, px, dmax), c1 = fwd_eval_col<TEST>(a1, px, dmax);
-        fwd_eval_row<TEST>(c0, a0, b0, pyA, dmax, acc[0], acc[1], acc[2]);
-        fwd_eval_row<TEST>(c1, a1, b1, pyA, dmax, acc[0], acc[1], acc[2]);
-        fwd_eval_row<TEST>(c0, a0, b0, pyB, dmax, acc[3], acc[4], acc[5]);
-        fwd_eval_row<TEST>(c1, a1, b1, pyB, dmax, acc[3], acc[4], acc[5]);
+        if (HALVES & 1) {
+            fwd_eval_row<TEST>(c0, a0, b0, pyA, dmax, acc[0], acc[1], acc[2]);
+            fwd_eval_row<TEST>(c1, a1, b1, pyA, dmax, acc[0], acc[1], acc[2]);
+        }
+        if (HALVES & 2) {
+            fwd_eval_row<TEST>(c0, a0, b0, pyB, dmax, acc[3], acc[4], acc[5]);
+            fwd_eval_row<TEST>(c1, a1, b1, pyB, dmax, acc[3], acc[4], acc[5]);
+        }
     }
     if (i < end) {
         const float4 a = st[2 * i], b = st[2 * i + 1];
         const FwdCol c = fwd_eval_col<TEST>(a, px, dmax);
-        fwd_eval_row<TEST>(c, a, b, pyA, dmax, acc[0], acc[1], acc[2]);
-        fwd_eval_row<TEST>(c, a, b, pyB, dmax, acc[3], acc[4], acc[5]);
+        if (HALVES & 1) fwd_eval_row<TEST>(c, a, b, pyA, dmax, acc[0], acc[1], acc[2]);
+        if (HALVES & 2) fwd_eval_row<TEST>(c, a, b, pyB, dmax, acc[3], acc[4], acc[5]);
     }
 }
 
@@ -1810,7 +1816,7 @@ __device__ __forceinline__ void fwd_store_px(const Params &P, float *__restrict_
 }
 
 template <bool BOUNDED>
-__global__ __launch_bounds__(256) void k_render_fwd16(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_fwd16(Params P, PlanView V, float *__restrict__ img, int tiles_x)
 {
     const unsigned tt = xcd_swizzle(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & 63;
@@ -1925,19 +1931,28 @@ __global__ __launch_bounds__(256) void k_render_fwd16(Params P, PlanView V, floa
                     hit &= (txr + 1 >= (int)((lo >> sh) & 0xffu)) & (txr <= (int)((hi >> sh) & 0xffu));
                 }
                 const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
-                const unsigned long long m0 = __ballot(hit && !needs), m1 = __ballot(hit && needs);
-                const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
-                if (n0 + n1) {
+                // Sort the hits by the row pairs their window reaches: both, only the upper eight rows of the sub-tile (pair A),
+                // only the lower eight (pair B); windows cut by the dmax box (exact in-kernel test) stay one list on both.
+                const int cls = !hit ? 4 : needs ? 3 : r1 < sy0 + 8 ? 1 : r0 >= sy0 + 8 ? 2 : 0;
+                const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+                const unsigned long long m3 = BOUNDED ? __ballot(cls == 3) : 0ull;
+                const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1), n2 = __builtin_popcountll(m2);
+                const int n3 = __builtin_popcountll(m3);
+                if (n0 + n1 + n2 + n3) {
                     __builtin_amdgcn_wave_barrier();
                     if (hit) {
-                        const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
+                        const unsigned long long mine = cls == 0 ? m0 : cls == 1 ? m1 : cls == 2 ? m2 : m3;
+                        const int base = cls == 0 ? 0 : cls == 1 ? n0 : cls == 2 ? n0 + n1 : n0 + n1 + n2;
+                        const int slot = base + __builtin_popcountll(mine & below);
                         const float4 *src = rec + 2 * (size_t)j;
                         stage[2 * slot] = src[0];
                         stage[2 * slot + 1] = src[1];
                     }
                     __builtin_amdgcn_wave_barrier();
-                    fwd_eval_lds16<false>(stage, 0, n0, px, pyA, pyB, P.dmax, acc);
-                    if (BOUNDED) fwd_eval_lds16<true>(stage, n0, n0 + n1, px, pyA, pyB, P.dmax, acc);
+                    fwd_eval_lds16<false, 3>(stage, 0, n0, px, pyA, pyB, P.dmax, acc);
+                    fwd_eval_lds16<false, 1>(stage, n0, n0 + n1, px, pyA, pyB, P.dmax, acc);
+                    fwd_eval_lds16<false, 2>(stage, n0 + n1, n0 + n1 + n2, px, pyA, pyB, P.dmax, acc);
+                    if (BOUNDED) fwd_eval_lds16<true, 3>(stage, n0 + n1 + n2, n0 + n1 + n2 + n3, px, pyA, pyB, P.dmax, acc);
                 }
                 j = nj; bb = nbb; bs = nbs;
             }
