@@ -127,6 +127,8 @@ struct Params {
     int slot;        // rows per slot (multiple of 16)
     int nper;        // Gaussians per sample (sample-major order)
     int part_k;      // tile-stationary backward: partial-gradient slots per Gaussian (PlanView::part)
+    int bt_hlog;     // ... and log2 of its tile height: 4 (32 x 16 px) or 5 (32 x 32, from 32 HR pixels per Gaussian); the tile
+                     // kernel and the gather number a window's tiles with it (bt_tile_span)
     int grad_rows;   // rows per plane of a planar (GSASR_FLAG_CHW_GRAD) upstream gradient of a batched canvas
 };
 
@@ -277,6 +279,25 @@ bool bwd_wants_tile(const gsasr_dims *d)
     // (round 4, with the windows of the data-derived cutoff: at 2048^2 x8 the Gaussian-stationary kernel is 7% ahead, at
     // 3072^2 x6 the tile-stationary one 3%, from 5120^2 up 4..10%: the line is drawn at 8 Mpx)
     return px_per_gaussian >= 32.0 && (double)d->h * (double)d->w >= 8388608.0;
+}
+
+// Tile height of the tile-stationary backward: 32 rows from 128 whole-grid HR pixels per Gaussian (x12 and up: windows of
+// 65 px and more) on single images -- the per-tile search is shared by twice the pixels and a window meets 40% fewer tiles
+// (slots written, and read by the gather): x12 -2%, x16 -9%, x24 -17%; nothing at x8 and x6 (profiles/r04_bwd_experiments.txt
+// (6)).  16 rows below that and on the batched canvas (slots are multiples of 16 rows).
+// development switch: GSASR_SPLAT_BT_TALL=0 / 1
+bool bt_tall(const gsasr_dims *d)
+{
+    static std::atomic<int> cached{-2};
+    int v = cached.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char *e = getenv("GSASR_SPLAT_BT_TALL");
+        v = !e ? -1 : atoi(e) != 0;
+        cached.store(v, std::memory_order_relaxed);
+    }
+    if (d->batch > 1 || v == 0) return false;
+    if (v == 1) return true;
+    return (double)d->h * (double)d->w >= 128.0 * (double)(d->s > 0 ? d->s : 1);
 }
 
 int bwd_part_k(const gsasr_dims *d)
@@ -438,6 +459,7 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.slot = d->batch > 1 ? d->slot : d->h;
     P.nper = d->batch > 1 ? d->s / d->batch : d->s;
     P.part_k = L.part_k;
+    P.bt_hlog = bt_tall(d) ? 5 : 4;
     P.grad_rows = d->grad_rows > 0 ? d->grad_rows : P.slot;
     return P;
 }
@@ -2397,20 +2419,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 // in LDS and streams the Gaussians binned near it).  Measured against the Gaussian-stationary k_render_bwd above in
 // DESIGN.md 3c; the host picks between the two (gsasr_splat_backward).
 //
-//   tile      32 x 16 px = 8 "quadrants" of 8 x 8 px; one workgroup of four waves per tile, XCD-banded tile order.
+//   tile      32 x 16 px = 8 "quadrants" of 8 x 8 px, one workgroup of two waves per tile; from x12 up (bt_tall) 32 x 32 px =
+//             16 quadrants and four waves.  XCD-banded tile order.
 //   stage     the tile's gradient (HWC or planar CHW, zero outside the image / the sample / the row band) goes to LDS as
 //             packed row pairs {r_a, r_b, g_a, g_b, b_a, b_b} per (column, row pair) of each quadrant, with the px / py
 //             table entries of the tile.  Every pixel of grad_img is read once per tile that holds it -- exactly once.
 //   level 1   as in the forward (fwd_block): the four waves test the windows of the Gaussians binned within reach of
 //             the tile, 64 per wave and chunk, and append the survivors to a list in LDS.  A survivor also appends one
-//             ITEM per quadrant its window touches (1..8), survivor-major, the last one marked.
+//             ITEM per quadrant its window touches (1..8 or 16), survivor-major, the last one marked.
 //   level 2   LANE = ITEM = (Gaussian, quadrant): a lane loads its Gaussian's records once and evaluates it at the 64
 //             pixels of its quadrant -- gradients read from LDS (lanes of different quadrants hit disjoint banks), two
 //             rows per packed-fp32 operation, columns in the outer loop so that u = dx/sx is constant in the inner one
 //             and the same residual-form sums as bwd_sweep apply.  No cross-lane reduction of pixels, no masks: a pixel
 //             outside the Gaussian's window adds a term below exp(-tau), a pixel outside the image adds 0 * v.
 //             The items of one Gaussian sit in adjacent lanes (chunks are cut at the last marked lane, so a Gaussian never
-//             straddles two chunks): three shuffle steps add them up, and the first lane of each run stores the eight raw
+//             straddles two chunks): three (four) shuffle steps add them up, and the first lane of each run stores the eight raw
 //             sums into the Gaussian's slot for THIS tile (PlanView::part) -- plain 32-byte stores, no atomics, no
 //             dependence on scheduling.  (Measured on this chip: fp32 global atomics retire ~19 G cache-line requests/s
 //             chip-wide and ds_add_f32 ~3 cycles per lane; tools/atomic_rate.hip.  One atomic set per (tile, Gaussian)
@@ -2420,7 +2443,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 // A Gaussian whose window spans more tiles than it has slots (or the "large" class) adds into PlanView::sums with
 // atomics instead; the gather adds those as well.
 // ---------------------------------------------------------------------------------------------------
-constexpr int BT_W = 32, BT_H = 16;                 // tile
+constexpr int BT_W = 32;                            // tile width; its height 1 << HLOG = 16 or 32 is a template parameter (bt_tall)
 #ifndef BT_WAVES_N
 #define BT_WAVES_N 2
 #endif
@@ -2434,13 +2457,13 @@ constexpr int BT_QSTRIDE = 32 * 8 + 8;              // floats per quadrant block
                                                     // blocks of the eight quadrants start 8 banks apart
 constexpr unsigned BT_WIDE = 0xffu;                 // slot code: window spans more tiles than part_k -> atomics into sums
 
-__device__ __forceinline__ int bt_tile_span(unsigned wx, unsigned wy, int row0, int &ntx, int &tx0, int &ty0)
+__device__ __forceinline__ int bt_tile_span(unsigned wx, unsigned wy, int row0, int hlog, int &ntx, int &tx0, int &ty0)
 {
     const int c0 = (int)(wx & 0x7fffu), c1 = (int)(wx >> 16), r0 = (int)(wy & 0x7fffu), r1 = (int)(wy >> 16);
     tx0 = c0 >> 5;
-    ty0 = (r0 - row0) >> 4;
+    ty0 = (r0 - row0) >> hlog;
     ntx = (c1 >> 5) - tx0 + 1;
-    return ntx * (((r1 - row0) >> 4) - ty0 + 1);
+    return ntx * (((r1 - row0) >> hlog) - ty0 + 1);
 }
 
 // One item: Gaussian j (cell order) at the 64 pixels of one quadrant.  gq = the quadrant's block of staged gradients,
@@ -2514,16 +2537,20 @@ __device__ __forceinline__ void bt_eval(const PlanView &V, unsigned j, float dm,
     a[7] = Cb.x + Cb.y;
 }
 
-template <bool BOUNDED, int BT_CHUNKS>
-__global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_CHUNKS * BT_WAVES <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
+// (the 32-row tile runs twice the waves per workgroup with half the chunks each: the same rounds, the same waves per CU under
+// its 27 KB of LDS)
+template <bool BOUNDED, int BT_CHUNKS, int HLOG>
+__global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_waves_per_eu((BT_CHUNKS * BT_WAVES << (HLOG - 4)) <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
     Params P, PlanView V, const float *__restrict__ grad, int tiles_x, int use_atomics)
 {
-    constexpr int BT_LIST = BT_WAVES * BT_CHUNKS * 64;  // survivors per round at most (512 / 256)
-    __shared__ __attribute__((aligned(16))) float s_g[8 * BT_QSTRIDE];
+    constexpr int BT_H = 1 << HLOG, NQY = BT_H / 8, NQ = 4 * NQY;   // tile height, quadrant rows, quadrants (8 or 16)
+    constexpr int WAVES = BT_WAVES << (HLOG - 4), THREADS = 64 * WAVES;
+    constexpr int BT_LIST = WAVES * BT_CHUNKS * 64;     // survivors per round at most (512 / 256)
+    __shared__ __attribute__((aligned(16))) float s_g[NQ * BT_QSTRIDE];
     __shared__ float s_px[BT_W], s_py[BT_H];
     __shared__ unsigned s_list[BT_LIST];            // survivor: index in cell order | needs the dmax test << 31
     __shared__ unsigned char s_slot[BT_LIST];       // its slot in part[] for this tile, or BT_WIDE
-    __shared__ unsigned short s_items[BT_LIST * 8]; // item: survivor (9 bits) | quadrant << 9 | last of its survivor << 12
+    __shared__ unsigned short s_items[BT_LIST * NQ]; // item: survivor (9 bits) | quadrant << 9 | last of its survivor << 13
     __shared__ unsigned s_cnt[3];                   // survivors, items of the round; head of the item queue (level 2)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2546,7 +2573,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
             yoff = g.base;
         }
 #pragma unroll
-        for (int i = tid; i < BT_W * BT_H; i += BT_THREADS) {
+        for (int i = tid; i < BT_W * BT_H; i += THREADS) {
             const int row = i >> 5, col = i & 31, X = bx0 + col, Y = by0 + row;
             float r = 0.f, gg = 0.f, b = 0.f;
             if (X < g.w && Y < ylim) {
@@ -2598,13 +2625,13 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
     int rseg = 0;
     __syncthreads();
 
-    for (unsigned base = 0; base < nchunks; base += (unsigned)(BT_WAVES * BT_CHUNKS)) {
+    for (unsigned base = 0; base < nchunks; base += (unsigned)(WAVES * BT_CHUNKS)) {
         // ---- level 1: candidates -> survivors + items ----------------------------------------------------
         unsigned cj[BT_CHUNKS];
         uint2 cw[BT_CHUNKS];
 #pragma unroll
         for (int k = 0; k < BT_CHUNKS; ++k) {
-            const unsigned c = base + (unsigned)wv + (unsigned)(BT_WAVES * k);
+            const unsigned c = base + (unsigned)wv + (unsigned)(WAVES * k);
             cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
             cw[k] = make_uint2(0x7fffu, 0x7fffu);
             if (cj[k] != 0xffffffffu) cw[k] = V.win[cj[k]];
@@ -2624,7 +2651,9 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
             // per-8-row spans): the corners of the window are empty for every Gaussian, most of it for a correlated one
             const int qx0 = max(c0 - bx0, 0) >> 3, qx1 = min(c1 - bx0, BT_W - 1) >> 3;
             const int qy0 = max(r0 - by0, 0) >> 3, qy1 = min(r1 - by0, BT_H - 1) >> 3;
-            int xl[2] = {1, 1}, xh[2] = {0, 0};
+            int xl[NQY], xh[NQY];
+#pragma unroll
+            for (int qy = 0; qy < NQY; ++qy) { xl[qy] = 1; xh[qy] = 0; }
             if (hit) {
                 // per-8-row spans (qspan) when the window has at most eight such bands; a taller window (x12 and up) still has
                 // the forward's per-16-row spans in its window words: both quadrant rows of this tile then share one band
@@ -2640,8 +2669,8 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
                 }
                 const int cu = (c0 >> 3) - (bx0 >> 3);
 #pragma unroll
-                for (int qy = 0; qy < 2; ++qy) {
-                    const unsigned t = (unsigned)(fine ? b8 - q0 + qy : (b8 >> 1) - (q0 >> 1)) & 7u, sh = (t & 3u) * 8u;
+                for (int qy = 0; qy < NQY; ++qy) {
+                    const unsigned t = (unsigned)(fine ? b8 - q0 + qy : ((b8 + qy) >> 1) - (q0 >> 1)) & 7u, sh = (t & 3u) * 8u;
                     const int lo = (int)(((t < 4u ? qs.x : qs.z) >> sh) & 0xffu), hi = (int)(((t < 4u ? qs.y : qs.w) >> sh) & 0xffu);
                     if (qy >= qy0 && qy <= qy1) {
                         // (hi = 255 is "as far as the window goes": the default of a window k_bin computed no spans for --
@@ -2651,7 +2680,9 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
                     }
                 }
             }
-            const unsigned n_i = (unsigned)(max(xh[0] - xl[0] + 1, 0) + max(xh[1] - xl[1] + 1, 0));
+            unsigned n_i = 0u;
+#pragma unroll
+            for (int qy = 0; qy < NQY; ++qy) n_i += (unsigned)max(xh[qy] - xl[qy] + 1, 0);
             unsigned inc = n_i;
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned v = (unsigned)__shfl_up((int)inc, o);
@@ -2663,15 +2694,15 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
             if (hit) {
                 s_list[pos] = cj[k] | ((cw[k].x & 0x8000u) << 16);
                 int ntx, wtx0, wty0;
-                const int nt = bt_tile_span(cw[k].x, cw[k].y, P.row0, ntx, wtx0, wty0);
+                const int nt = bt_tile_span(cw[k].x, cw[k].y, P.row0, HLOG, ntx, wtx0, wty0);
                 const unsigned slot = nt <= P.part_k ? (unsigned)((ty - wty0) * ntx + (tx - wtx0)) : BT_WIDE;
                 s_slot[pos] = (unsigned char)slot;
                 unsigned off = ib + inc - n_i;
                 const unsigned last = off + n_i - 1u;
 #pragma unroll
-                for (int qy = 0; qy < 2; ++qy)
+                for (int qy = 0; qy < NQY; ++qy)
                     for (int qx = xl[qy]; qx <= xh[qy]; ++qx, ++off)
-                        s_items[off] = (unsigned short)((unsigned)pos | (unsigned)(qy * 4 + qx) << 9 | (off == last ? 0x1000u : 0u));
+                        s_items[off] = (unsigned short)((unsigned)pos | (unsigned)(qy * 4 + qx) << 9 | (off == last ? 0x2000u : 0u));
                 if (n_i == 0u && slot != BT_WIDE && !use_atomics) {   // the ellipse misses the tile: its slot is still read
                     float4 *o = reinterpret_cast<float4 *>(V.part + ((size_t)cj[k] * P.part_k + slot) * 8);
                     o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2695,7 +2726,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
                 if (p0 >= nitems) break;
                 const unsigned idx = p0 + (unsigned)lane;
                 it = idx < nitems ? s_items[idx] : 0u;
-                const unsigned long long tails = __ballot(idx < nitems && (it & 0x1000u));
+                const unsigned long long tails = __ballot(idx < nitems && (it & 0x2000u));
                 tlast = 63 - __builtin_clzll(tails);                  // (the list ends on a marked item: tails != 0)
                 unsigned got = 0u;
                 if (lane == 0) got = atomicCAS(&s_cnt[2], p0, p0 + (unsigned)tlast + 1u);
@@ -2703,7 +2734,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
             }
             if (p0 >= nitems) break;
             const bool valid = lane <= tlast;
-            const unsigned lidx = it & 0x1ffu, q = (it >> 9) & 7u;
+            const unsigned lidx = it & 0x1ffu, q = (it >> 9) & 15u;
             float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             unsigned j = 0u;
             unsigned e = 0u;
@@ -2717,10 +2748,10 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(BT_C
             } else {
                 if (valid) bt_eval<false>(V, j, INFINITY, s_g + q * BT_QSTRIDE, s_px + (q & 3u) * 8u, s_py + (q >> 2) * 8u, a);
             }
-            // add up the items of each Gaussian (adjacent lanes, at most 8): three shuffle steps; its first lane gets the total
+            // add up the items of each Gaussian (adjacent lanes, at most NQ): three or four shuffle steps; its first lane gets the total
             const unsigned key = valid ? lidx : 0xffffu;
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
+            for (int o = 1; o < NQ; o <<= 1) {
                 const bool same = (unsigned)__shfl_down((int)key, o) == key && lane + o < 64;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -2767,7 +2798,7 @@ __device__ __forceinline__ unsigned bwd_gather(const Params &P, const PlanView &
     const bool dead = (int)(w.x & 0x7fffu) > (int)(w.x >> 16);
     if (!dead && !use_atomics) {
         int ntx, tx0, ty0;
-        const int nt = bt_tile_span(w.x, w.y, P.row0, ntx, tx0, ty0);
+        const int nt = bt_tile_span(w.x, w.y, P.row0, P.bt_hlog, ntx, tx0, ty0);
         if (nt <= P.part_k) {
             const float4 *pp = reinterpret_cast<const float4 *>(V.part + (size_t)j * P.part_k * 8);
             for (int t = 0; t < nt; ++t) {
@@ -3665,13 +3696,16 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         // left the accumulators alone (k_bin zeroes them only where it knows they will be used)
         HIP_TRY(hipMemsetAsync(V.sums, 0, (size_t)dims->s * 32, st));
     if (rows > 0) {
-        const int tiles_x = (dims->w + BT_W - 1) / BT_W, tiles_y = (rows + BT_H - 1) / BT_H;
-        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block(BT_THREADS);
+        const int bth = 1 << P.bt_hlog;
+        const int tiles_x = (dims->w + BT_W - 1) / BT_W, tiles_y = (rows + bth - 1) / bth;
+        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block((unsigned)BT_THREADS << (P.bt_hlog - 4));
         // small rounds + five waves per SIMD from 32 HR pixels per Gaussian up (where this kernel is the default)
         const bool sparse = (double)rows * (double)dims->w >= 32.0 * (double)dims->s;
-#define GSASR_BT(B, C) hipLaunchKernelGGL((k_render_bwd_tile<B, C>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2)
-        if (P.bounded) { if (sparse) GSASR_BT(true, 4 / BT_WAVES); else GSASR_BT(true, 8 / BT_WAVES); }
-        else { if (sparse) GSASR_BT(false, 4 / BT_WAVES); else GSASR_BT(false, 8 / BT_WAVES); }
+#define GSASR_BT(B, C, H) hipLaunchKernelGGL((k_render_bwd_tile<B, C, H>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2)
+#define GSASR_BT2(B, C) do { if (P.bt_hlog == 5) GSASR_BT(B, (C) / 2, 5); else GSASR_BT(B, C, 4); } while (0)
+        if (P.bounded) { if (sparse) GSASR_BT2(true, 4 / BT_WAVES); else GSASR_BT2(true, 8 / BT_WAVES); }
+        else { if (sparse) GSASR_BT2(false, 4 / BT_WAVES); else GSASR_BT2(false, 8 / BT_WAVES); }
+#undef GSASR_BT2
 #undef GSASR_BT
         HIP_TRY(hipGetLastError());
     }
