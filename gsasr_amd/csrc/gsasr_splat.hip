@@ -281,10 +281,11 @@ bool bwd_wants_tile(const gsasr_dims *d)
     return px_per_gaussian >= 32.0 && (double)d->h * (double)d->w >= 8388608.0;
 }
 
-// Tile height of the tile-stationary backward: 32 rows from 128 whole-grid HR pixels per Gaussian (x12 and up: windows of
-// 65 px and more) on single images -- the per-tile search is shared by twice the pixels and a window meets 40% fewer tiles
-// (slots written, and read by the gather): x12 -2%, x16 -9%, x24 -17%; nothing at x8 and x6 (profiles/r04_bwd_experiments.txt
-// (6)).  16 rows below that and on the batched canvas (slots are multiples of 16 rows).
+// Tile height of the tile-stationary backward: 32 rows from 64 whole-grid HR pixels per Gaussian (x8 and up: windows of
+// 45 px and more) on single images -- the per-tile search is shared by twice the pixels and a window meets 40% fewer tiles
+// (slots written, and read by the gather): x8 -2% (the gather 94 -> 68 us, the tile kernel level; HBM traffic 1.72 -> 1.56 GB),
+// x12 -2%, x16 -9%, x24 -17%; nothing at x6 (profiles/r04_bwd_experiments.txt (6)).  16 rows below that and on the batched
+// canvas (slots are multiples of 16 rows).
 // development switch: GSASR_SPLAT_BT_TALL=0 / 1
 bool bt_tall(const gsasr_dims *d)
 {
@@ -297,7 +298,7 @@ bool bt_tall(const gsasr_dims *d)
     }
     if (d->batch > 1 || v == 0) return false;
     if (v == 1) return true;
-    return (double)d->h * (double)d->w >= 128.0 * (double)(d->s > 0 ? d->s : 1);
+    return (double)d->h * (double)d->w >= 64.0 * (double)(d->s > 0 ? d->s : 1);
 }
 
 int bwd_part_k(const gsasr_dims *d)
@@ -2419,7 +2420,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 // in LDS and streams the Gaussians binned near it).  Measured against the Gaussian-stationary k_render_bwd above in
 // DESIGN.md 3c; the host picks between the two (gsasr_splat_backward).
 //
-//   tile      32 x 16 px = 8 "quadrants" of 8 x 8 px, one workgroup of two waves per tile; from x12 up (bt_tall) 32 x 32 px =
+//   tile      32 x 16 px = 8 "quadrants" of 8 x 8 px, one workgroup of two waves per tile; from x8 up (bt_tall) 32 x 32 px =
 //             16 quadrants and four waves.  XCD-banded tile order.
 //   stage     the tile's gradient (HWC or planar CHW, zero outside the image / the sample / the row band) goes to LDS as
 //             packed row pairs {r_a, r_b, g_a, g_b, b_a, b_b} per (column, row pair) of each quadrant, with the px / py

@@ -115,7 +115,7 @@ def test_synthetic_x4_256(dmax, cutoff, dev):
 def test_ragged_sizes_scales_and_densities(case, dev):
     """non-square, H/W not multiples of the tile, fractional scale, x12 windows wider than their slots (atomic fallback
     inside the slot mode), 16 Gaussians per LR pixel (many rounds per tile; (48, 48, 4, 16) is BASELINE config 5's sample);
-    from x12 up (128 HR pixels per Gaussian) the tile is 32 x 32 px (sixteen quadrants, four waves: bt_tall)"""
+    from x8 up (64 HR pixels per Gaussian) the tile is 32 x 32 px (sixteen quadrants, four waves: bt_tall)"""
     h_lr, w_lr, scale, gpp = case
     sig, xy, col, H, W, wgt = _synth(h_lr, w_lr, scale, seed=20, gpp=gpp)
     for dmax in (None, 0.25):
@@ -147,7 +147,7 @@ def test_row_band_of_a_x16_image_with_the_32_row_tile(dev):
     """a row band that starts and ends inside 32-row tiles of the whole image's grid (the band's own tile grid starts at its
     first row), x16: the tall tile"""
     sig, xy, col, H, W, wgt = _synth(14, 12, 16.0, seed=77)
-    assert H * W >= 128 * sig.shape[0]
+    assert H * W >= 64 * sig.shape[0]
     for rows in ((0, H), (37, 171), (100, 117)):
         _check(sig, xy, col, wgt, H, W, 0.3, dev, _flags()["tile"], rows=rows)
 
