@@ -127,6 +127,8 @@ struct Params {
     int slot;        // rows per slot (multiple of 16)
     int nper;        // Gaussians per sample (sample-major order)
     int part_k;      // tile-stationary backward: partial-gradient slots per Gaussian (PlanView::part)
+    int geo_h, geo_w; // batched canvas whose samples all have ONE size (training crops): that size -- sample_geo is then arithmetic
+                      // and the plan launches no k_batch_geo; 0: per-sample sizes in PlanView::geo
     int bt_hlog;     // ... and log2 of its tile height: 4 (32 x 16 px) or 5 (32 x 32, from 32 HR pixels per Gaussian); the tile
                      // kernel and the gather number a window's tiles with it (bt_tile_span)
     int grad_rows;   // rows per plane of a planar (GSASR_FLAG_CHW_GRAD) upstream gradient of a batched canvas
@@ -174,6 +176,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 __device__ __forceinline__ Geo sample_geo(const Params &P, const PlanView &V, int b)
 {
     if (P.batch <= 1) return Geo{P.h, P.w, 0, 0};
+    if (P.geo_h) return Geo{P.geo_h, P.geo_w, b * P.slot, b * P.w};
     const int4 g = V.geo[b];
     return Geo{g.x, g.y, g.z, g.w};
 }
@@ -411,6 +414,18 @@ float resolve_cutoff(float cutoff, int s)
     return (float)(tau < 16.0 ? 16.0 : tau > (double)GSASR_SPLAT_EXACT_CUTOFF ? (double)GSASR_SPLAT_EXACT_CUTOFF : tau);
 }
 
+// batched canvas whose samples all have one size (the training crops): that size; false otherwise
+bool batch_uniform(const gsasr_dims *d, int &h, int &w)
+{
+    h = w = 0;
+    if (d->batch <= 1) return false;
+    for (int b = 1; b < d->batch; ++b)
+        if (d->sample_hw[2 * b] != d->sample_hw[0] || d->sample_hw[2 * b + 1] != d->sample_hw[1]) return false;
+    h = d->sample_hw[0];
+    w = d->sample_hw[1];
+    return true;
+}
+
 Params make_params(const gsasr_dims *d, const Layout &L)
 {
     Params P;
@@ -461,6 +476,7 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.nper = d->batch > 1 ? d->s / d->batch : d->s;
     P.part_k = L.part_k;
     P.bt_hlog = bt_tall(d) ? 5 : 4;
+    batch_uniform(d, P.geo_h, P.geo_w);
     P.grad_rows = d->grad_rows > 0 ? d->grad_rows : P.slot;
     return P;
 }
@@ -759,8 +775,8 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
         if (i < P.w) V.px[i] = (float)(2.0 * (double)i / (double)(P.w - 1) - 1.0);
         if (i < P.h) V.py[i] = (float)(2.0 * (double)i / (double)(P.h - 1) - 1.0);
     } else {  // one px table per sample, py over the canvas rows: each sample's own grid (padding continues it)
-        if (i < P.w * P.batch) V.px[i] = (float)(2.0 * (double)(i % P.w) / (double)(V.geo[i / P.w].y - 1) - 1.0);
-        if (i < P.h) V.py[i] = (float)(2.0 * (double)(i % P.slot) / (double)(V.geo[i / P.slot].x - 1) - 1.0);
+        if (i < P.w * P.batch) V.px[i] = (float)(2.0 * (double)(i % P.w) / (double)(sample_geo(P, V, i / P.w).w - 1) - 1.0);
+        if (i < P.h) V.py[i] = (float)(2.0 * (double)(i % P.slot) / (double)(sample_geo(P, V, i / P.slot).h - 1) - 1.0);
     }
     unsigned rx = 0, ry = 0, key = 0xffffffffu;
     if (i < P.s) {
@@ -3267,7 +3283,7 @@ __global__ __launch_bounds__(256) void k_prologue_fwd(const float *__restrict__ 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (geo) {  // batched canvas: sample i/nper has its own size and step size
+    if (geo && h == 0) {  // batched canvas: sample i/nper has its own size and step size (h, w given: one size for all)
         const int4 g = geo[i / nper];
         h = g.x;
         w = g.y;
@@ -3305,7 +3321,7 @@ __global__ __launch_bounds__(256) void k_prologue_bwd(const float *__restrict__ 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (geo) {
+    if (geo && h == 0) {
         const int4 g = geo[i / nper];
         h = g.x;
         w = g.y;
@@ -3327,9 +3343,9 @@ __global__ __launch_bounds__(256) void k_prologue_bwd_gather(Params P, PlanView 
     int h = P.h, w = P.w;
     float step = step_ptr[0];
     if (P.batch > 1) {
-        const int4 g = V.geo[i / (unsigned)P.nper];
-        h = g.x;
-        w = g.y;
+        const Geo g = sample_geo(P, V, (int)(i / (unsigned)P.nper));
+        h = g.h;
+        w = g.w;
         step = step_ptr[i / (unsigned)P.nper];
     }
     prologue_chain(p + (size_t)i * 9, step, h, w, o[2], o[3], o[4], o[0], o[1], o[5], o[6], o[7], gp + (size_t)i * 9);
@@ -3372,6 +3388,8 @@ __global__ __launch_bounds__(256) void k_chw_to_hwc(const float *__restrict__ sr
 int launch_batch_geo(const gsasr_dims *dims, const PlanView &V, hipStream_t st)
 {
     if (dims->batch <= 1) return GSASR_OK;
+    int uh, uw;
+    if (batch_uniform(dims, uh, uw)) return GSASR_OK;   // (one size for all samples: the kernels get it as an argument, nothing reads PlanView::geo)
     BatchSizes S;
     for (int b = 0; b < GSASR_MAX_BATCH; ++b) {
         S.h[b] = (unsigned short)(b < dims->batch ? dims->sample_hw[2 * b] : 0);
@@ -3885,7 +3903,9 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
     }
     if (dims->batch > 1) {
         const PlanView V = make_view(make_layout(dims), workspace);
-        hipLaunchKernelGGL(k_prologue_bwd, grid, block, 0, (hipStream_t)stream, gs_parameters, step_size, dims->s, 0, 0, gs, gc,
+        int uh, uw;
+        batch_uniform(dims, uh, uw);
+        hipLaunchKernelGGL(k_prologue_bwd, grid, block, 0, (hipStream_t)stream, gs_parameters, step_size, dims->s, uh, uw, gs, gc,
                            gk, g_parameters, dims->s / dims->batch, (const int4 *)V.geo);
         HIP_TRY(hipGetLastError());
         return GSASR_OK;
@@ -4064,8 +4084,10 @@ int gsasr_step_sample_backward(const float *gs_parameters, const float *step_siz
     if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
     if (dims->batch > 1) {
         const PlanView V = make_view(make_layout(dims), workspace);
+        int uh, uw;
+        batch_uniform(dims, uh, uw);
         hipLaunchKernelGGL(k_prologue_bwd, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           gs_parameters, step_size, dims->s, 0, 0, gs, gc, gk, g_parameters, dims->s / dims->batch,
+                           gs_parameters, step_size, dims->s, uh, uw, gs, gc, gk, g_parameters, dims->s / dims->batch,
                            (const int4 *)V.geo);
         HIP_TRY(hipGetLastError());
         return GSASR_OK;
