@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, pair_ceiling, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
-                      exact_runs, live_hbm_traffic, flush_c_stdio, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
+                      exact_runs, live_hbm_traffic, flush_c_stdio, published_leg, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
 
 
 def parse():
@@ -275,7 +275,8 @@ def main():
                        "cutoff_tau": round(tau_eff, 3), "cutoff_k_box": k_box,
                        "cutoff_tau_conservative": round(step.cabi.resolve_cutoff(args.cutoff, step.plan.dims.s), 3),
                        "cutoff_note": "terms with exponent < -tau are skipped; default tau = ln(K/1e-5) with K = the plan's own bound on how many "
-                                      "Gaussians' dmax boxes cover one pixel (only those contribute, gs_cuda_dmax/gs.cu:41-50; K <= N, unbounded op: K = N) "
+                                      "Gaussians can lose a non-negligible term on one pixel -- counted from the plan's cell histogram over the class' largest support, "
+                                      "and for the bounded op also over the dmax box (gs_cuda_dmax/gs.cu:41-50), the smaller count wins; K <= N -- "
                                       "bounds the image error by 1e-5 x max|colour| per pixel for any input (colours are <= 1 after the host prologue; "
                                       "parity tolerance 1e-4, all parity tests run at this default); "
                                       "--cutoff 104 sums the reference's exact set of non-zero fp32 terms, --cutoff -1 every in-box term",
@@ -306,11 +307,24 @@ def main():
             step = None             # (its buffers make room for the 8192^2 leg)
             torch.cuda.empty_cache()
             out["configs"] = {}
-            for name in ("c3", "c4", "c2x16"):
+            for name in ("c3", "c4", "c2x16", "c5"):
                 try:
                     out["configs"][name] = single_gpu_leg(args, dev, name)
                 except Exception as e:      # a leg must never take the headline line with it
                     out["configs"][name] = {"error": repr(e)}
+            # BASELINE config 5 END TO END (encoder + producer -> batched splat -> L1 -> backward -> Adam), a handful of steps
+            try:
+                import copy
+                a5 = copy.copy(args)
+                a5.config, a5.steps, a5.warmup, a5.no_cpu_baseline = "c5e2e", 5, 3, True
+                out["configs"]["c5e2e"] = run_c5e2e(a5, dev, 0, 1, as_leg=True)
+            except Exception as e:
+                out["configs"]["c5e2e"] = {"error": repr(e)}
+            # the reference's one published measurement of this path (utils/gs_cuda/profile.py:104-113, profile.log:44)
+            try:
+                out["published"] = published_leg(args, dev)
+            except Exception as e:
+                out["published"] = {"error": repr(e)}
         if c4_strong is not None:
             out["c4_strong"] = c4_strong
         if c4_strong_halo is not None:

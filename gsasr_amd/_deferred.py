@@ -115,6 +115,15 @@ def _flush_at_exit():
         import os
         import sys
         print(f"gsasr_amd: deferred check failed at exit: {e}", file=sys.stderr)
+        if os.environ.get("GSASR_AMD_DEFERRED_EXIT", "1") == "0":    # opt-out: report only, leave the exit status alone
+            return
+        # The exit status can only be changed with os._exit, which skips every handler still to run (this one was registered
+        # at import, so it runs late, but process groups, loggers and profilers registered even earlier come after it):
+        # run those first, flush, then fail the process.
+        try:
+            atexit._run_exitfuncs()
+        except Exception:
+            pass
         sys.stderr.flush()
         sys.stdout.flush()
         os._exit(1)

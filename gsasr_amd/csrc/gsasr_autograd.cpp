@@ -153,6 +153,10 @@ public:
         const auto saved = ctx->get_saved_variables();
         const at::Tensor &sigmas = saved[0], &coords = saved[1], &colors = saved[2];
         const auto st = ctx->saved_data["plan"].toCustomClass<PlanState>();
+        // (the Python Functions are @once_differentiable: a differentiable backward -- create_graph=True, gradient penalties --
+        // must raise there and here alike instead of silently dropping the second-order terms)
+        TORCH_CHECK(!torch::autograd::GradMode::is_enabled() || !grads[0].requires_grad(),
+                    "gsasr_amd: the rasterizer's backward is not differentiable (create_graph=True is not supported)");
         const at::Tensor &ws = st->ws;
         const int64_t stream = st->stream;
         at::Tensor g = grads[0];
@@ -229,12 +233,14 @@ public:
         const float *ps = nullptr;
         if (scale_modify.has_value() && scale_modify->defined()) {
             TORCH_CHECK(scale_modify->is_cuda() && scale_modify->scalar_type() == at::kFloat, "scale_modify must be a float32 CUDA tensor");
+            TORCH_CHECK(scale_modify->get_device() == gs_parameters.get_device(), "scale_modify lives on another device than gs_parameters");
             check(p_step_fwd_sm(pp, scale_modify->data_ptr<float>(), (int)sm_stride, (float)default_step, (int *)mismatch_ptr, &dp,
                                 st->ws.data_ptr(), bytes, img.data_ptr<float>(), (void *)stream),
                   "gsasr_step_forward_sm");
         } else {
             TORCH_CHECK(step.has_value() && step->defined(), "step size missing");
             ps = fptr(*step, "step_size", step->size(-1));
+            TORCH_CHECK(step->get_device() == gs_parameters.get_device(), "step_size lives on another device than gs_parameters");
             check(p_step_fwd(pp, ps, &dp, st->ws.data_ptr(), bytes, img.data_ptr<float>(), (void *)stream), "gsasr_step_forward");
         }
         ctx->save_for_backward({gs_parameters, (step.has_value() && step->defined()) ? *step : at::Tensor()});
@@ -249,6 +255,10 @@ public:
         const auto saved = ctx->get_saved_variables();
         const at::Tensor &gs_parameters = saved[0], &step = saved[1];
         const auto st = ctx->saved_data["plan"].toCustomClass<PlanState>();
+        // (the Python Functions are @once_differentiable: a differentiable backward -- create_graph=True, gradient penalties --
+        // must raise there and here alike instead of silently dropping the second-order terms)
+        TORCH_CHECK(!torch::autograd::GradMode::is_enabled() || !grads[0].requires_grad(),
+                    "gsasr_amd: the rasterizer's backward is not differentiable (create_graph=True is not supported)");
         at::Tensor g = grads[0];
         if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
         g = g.contiguous();

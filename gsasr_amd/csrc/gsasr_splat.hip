@@ -434,8 +434,9 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.dmax = P.bounded ? d->dmax : INFINITY;
     const float tau = resolve_cutoff(d->cutoff, d->s);
     P.kcut = tau > 0.f ? (float)(std::sqrt(2.0 * (double)tau) * (1.0 + 1e-6)) : 0.f;
-    // data-derived cutoff (adapt_kcut): the bounded op under the adaptive default only -- an explicit tau (per call, per
-    // process, environment) is used as given, and the unbounded op has no box to count in
+    // data-derived cutoff (adapt_kcut), under the adaptive default only -- an explicit tau (per call, per process,
+    // environment) is used as given unless GSASR_FLAG_CUTOFF_CAP says it is an upper bound.  Both ops count K from the
+    // SUPPORT (adapt_ring); the bounded op also from its dmax box (adapt_cells), the smaller count wins
     P.adapt_cells = P.adapt_cells4 = 0.f;
     P.adapt_ring = 0;
     P.count_words = (int)(L.count_bytes / 4);
@@ -4153,11 +4154,12 @@ static LauncherScratch g_scratch[LAUNCHER_SLOTS];
 static std::mutex g_scratch_mu;
 static unsigned long long g_scratch_clock = 0;
 
+// (the caller holds g_scratch_mu from here until its kernels are enqueued: a second host thread can then neither evict the entry
+// nor take the next parity before the first thread's plan sits in the stream)
 static int launcher_scratch(const gsasr_dims &d, size_t bytes, hipStream_t st, void **ws, unsigned *flags)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
     LauncherScratch *e = nullptr;
     for (LauncherScratch &c : g_scratch)
         if (c.ptr && c.dev == dev && c.st == st) { e = &c; break; }
@@ -4227,7 +4229,19 @@ static int render_common(const float *sigmas, const float *coords, const float *
     hipStream_t st = (hipStream_t)stream;
     void *ws = nullptr;
     unsigned counter_flags = 0u;
-    if (int rc = launcher_scratch(d, bytes, st, &ws, &counter_flags)) return rc;
+    // Under stream capture the cached scratch must not be touched: a pointer that came from a captured hipMallocAsync is only
+    // valid inside the graph, and a captured plan is replayed with ONE parity, so it must zero its own counters (flags = 0).
+    // The captured call therefore allocates, plans and frees stream-ordered, all three as nodes of the graph.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(st, &cap));
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    std::unique_lock<std::mutex> lk(g_scratch_mu, std::defer_lock);
+    if (capturing) {
+        HIP_TRY(hipMallocAsync(&ws, bytes, st));
+    } else {
+        lk.lock();      // held until the plan and the render are enqueued (launcher_scratch)
+        if (int rc = launcher_scratch(d, bytes, st, &ws, &counter_flags)) return rc;
+    }
     d.flags = counter_flags;
     int rc = gsasr_splat_plan(sigmas, coords, colors, &d, ws, bytes, stream);
     d.flags = 0;
@@ -4238,6 +4252,10 @@ static int render_common(const float *sigmas, const float *coords, const float *
             if (dmax < 0.f) d.flags |= GSASR_FLAG_OVERWRITE_GRADS;  // gs_cuda backward overwrites (gs.cu:169-176)
             rc = gsasr_splat_backward(sigmas, coords, colors, grads, gs, gc, gk, &d, ws, bytes, stream);
         }
+    }
+    if (capturing) {
+        const hipError_t fe = hipFreeAsync(ws, st);
+        if (rc == GSASR_OK && fe != hipSuccess) rc = hip_fail(fe, "hipFreeAsync");
     }
     return rc;
 }

@@ -46,9 +46,9 @@ if _cpp_node.load() is not None:
 
 def gaussiansplatting_render(sigmas, coords, colors, image_size, dmax=100):
     """reference: utils/gs_cuda_dmax/gswrapper.py:46-53"""
-    sigmas = sigmas.contiguous()  # (gs num, 3)
-    coords = coords.contiguous()  # (gs num, 2)
-    colors = colors.contiguous()  # (gs num, c)
+    sigmas = sigmas.contiguous()
+    coords = coords.contiguous()
+    colors = colors.contiguous()
     h, w = image_size[:2]
     c = colors.shape[-1]
     rendered_img = torch.zeros(int(h), int(w), c, device=colors.device, dtype=torch.float32)

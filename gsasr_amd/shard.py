@@ -60,7 +60,7 @@ def broadcast_gaussians(sigmas, coords, colors, src: int = 0, group=None):
 
 class HipBackend:
     """Local band rasterizer = libgsasr_splat.so through the C ABI (the product path)."""
-    CUTOFF_CAP_FLAG = 4096      # _cabi.FLAG_CUTOFF_CAP: an explicit cutoff is an upper bound for the plan's windows
+    from ._cabi import FLAG_CUTOFF_CAP as CUTOFF_CAP_FLAG      # an explicit cutoff is an upper bound for the plan's windows
 
     # ---- packed [N,8] records (BandExchange) ----
     @staticmethod

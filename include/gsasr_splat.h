@@ -97,8 +97,9 @@ enum gsasr_status {
 #define GSASR_FLAG_FWD_WIDE 8192u      /* forward kernel choice (default: the library picks by scale factor and image size): 16 x 16
                                          sub-tiles, four pixels per lane (scale factors from x5 up) ... */
 #define GSASR_FLAG_FWD_NARROW 16384u   /* ... or 8 x 16 sub-tiles, two pixels per lane.  Read by gsasr_splat_forward only (the plan
-                                         is the same); images too small for the two-level walk ignore both.  Same sums in a
-                                         different order: results agree to fp32 rounding */
+                                         is the same).  _WIDE forces the 16 x 16 kernel on ANY single image (tests, A/B runs),
+                                         a batched canvas ignores it; _NARROW leaves the choice among the 8 x 16 kernels to the
+                                         image size.  Same sums in a different order: results agree to fp32 rounding */
 
 typedef struct gsasr_dims {
     int s;        /* number of Gaussians                                              */

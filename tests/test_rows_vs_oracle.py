@@ -362,3 +362,27 @@ def test_sixteen_million_gaussians_properties(dev):
                        timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "forward additivity over two halves" in r.stdout
+
+
+def test_published_workload_bands_against_oracle(dev):
+    """The reference's one published workload (utils/gs_cuda/profile.py:104-113: unbounded op, 512 x 512 image, 262 144
+    Gaussians with sigma in [0, 1) of the grid -- 99% of them in the plan's "large" class): row bands of the image against
+    the oracle with every Gaussian, at the default cutoff and with the cull off.  A pixel sums ~1e5 terms of size <= 1, so
+    the criterion is relative to the image's largest value (fp32 accumulation), not the 1e-4 absolute of GSASR's colours."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from benchlib import published_inputs
+    from gsasr_amd import _cabi
+    from oracle import gs_oracle
+    sig, xy, col, H, W = published_inputs()
+    assert (H, W, sig.shape[0]) == (512, 512, 262144)
+    a, b, c = sig.to(dev), xy.to(dev), col.to(dev)
+    bands = ((0, 2), (255, 257), (510, 512))
+    refs = [gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, None, rows=r) for r in bands]
+    top = max(float(np.abs(r).max()) for r in refs)
+    assert top > 1e3
+    for tau in (0.0, -1.0):
+        plan = _cabi.plan(a, b, c, H, W, None, cutoff=tau, flags=_cabi.FLAG_FORWARD_ONLY)
+        img = torch.empty(H, W, 3, device=dev)
+        _cabi.forward(plan, img, overwrite=True)
+        for r, ref in zip(bands, refs):
+            assert np.abs(img[r[0]:r[1]].cpu().numpy() - ref).max() <= 2e-5 * top, (tau, r)

@@ -493,6 +493,61 @@ def dropin_run(args, dev):
                     "wall clock incl. host launch overhead, allocations and the accumulate-into (+=) image"}
 
 
+def published_inputs():
+    """the inputs of the reference's ONE committed measurement (utils/gs_cuda/profile.py:104-113): 512 x 512 x 3 image,
+    s = 262 144 Gaussians, sigmas = 0.2 * rand(s, 3) with the two sigma columns x 5 (so sigma in [0, 1) of the [-1, 1] grid:
+    image-spanning Gaussians, rho in [0, 0.2)), coords uniform on the grid, colours rand -- seeded here"""
+    g = torch.Generator().manual_seed(0)
+    s, H, W = 512 * 512, 512, 512
+    sigmas = 0.2 * torch.rand(s, 3, generator=g)
+    sigmas[:, :2] = 5 * sigmas[:, :2]
+    coords = 2 * torch.rand(s, 2, generator=g) - 1.0
+    colors = torch.rand(s, 3, generator=g)
+    return sigmas, coords, colors, H, W
+
+
+def published_leg(args, dev, calls=10):
+    """The reference's only published number of this path, run here: `gaussiansplatting_render` of the UNBOUNDED op
+    (utils/gs_cuda/gswrapper.py:41-48) under no_grad, mean wall time of 10 synchronised calls -- 1 184.5 ms per call in
+    utils/gs_cuda/profile.log:44 (hardware unstated there; the binaries are sm_80 and the README names A100).  Timed at the
+    library's default support cutoff AND with the cull off (every one of the reference's s * H * W = 6.9e10 pairs), through
+    the same drop-in function, plus the plan / forward kernels alone through the C ABI."""
+    from gsasr_amd import _cabi
+    from gsasr_amd.gs_cuda.gswrapper import gaussiansplatting_render
+    sigmas, coords, colors, H, W = published_inputs()
+    a, b, c = sigmas.to(dev), coords.to(dev), colors.to(dev)
+    ref_ms = 1184.4923
+    out = {"workload": "utils/gs_cuda/profile.py:104-113: gs_cuda (unbounded) forward, 512x512x3 image, 262144 Gaussians with sigma in [0,1) "
+                       "of the grid, no_grad, mean of 10 calls of gaussiansplatting_render incl. its torch.zeros",
+           "published_ms_per_call": ref_ms, "published_source": "utils/gs_cuda/profile.log:44 (hardware unstated; sm_80 binaries, README names A100)",
+           "pairs_reference": sigmas.shape[0] * H * W}
+    keep = _cabi.get_default_cutoff()
+    try:
+        for name, tau in (("default_cutoff", 0.0), ("nocull_every_pair", -1.0)):
+            _cabi.set_default_cutoff(tau)
+
+            def call():
+                with torch.no_grad():
+                    return gaussiansplatting_render(a, b, c, (H, W, 3))
+
+            ms = wall_ms(call, calls, dev, warm=2)
+            plan = _cabi.plan(a, b, c, H, W, None, cutoff=tau, flags=_cabi.FLAG_FORWARD_ONLY)
+            img = torch.empty(H, W, 3, device=dev)
+            fwd_avg, _ = time_stage(lambda: _cabi.forward(plan, img, overwrite=True), 5, dev)
+            tau_eff, k_box = _cabi.plan_cutoff(plan)
+            if not tau_eff > 0:
+                tau_eff = _cabi.resolve_cutoff(tau, sigmas.shape[0])
+            _, swept = window_pairs(sigmas, coords, H, W, None, tau_eff if tau >= 0 else 0.0, (0, H))
+            out[name] = {"cutoff_tau": round(float(tau_eff), 3) if tau >= 0 else -1, "ms_per_call": ms, "vs_published": ref_ms / ms,
+                         "value": H * W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s (fwd only)",
+                         "forward_kernel_ms": fwd_avg, "pairs_swept": swept, "Gpairs_per_s": swept / (fwd_avg * 1e-3) / 1e9,
+                         "valu_frac": swept / (fwd_avg * 1e-3) / PAIR_CEILING["forward"]["pairs_per_s"]}
+            del plan, img
+    finally:
+        _cabi.set_default_cutoff(keep)
+    return out
+
+
 def cpu_baseline(args):
     """The oracle's fp32 restatement of the reference kernels (OpenMP over the host cores) on a bounded
     sample of the SAME workload: a row band of config 2 (sized for ~10 s on this host) with all 65 536 Gaussians, forward + backward."""
@@ -545,7 +600,7 @@ def cpu_baseline(args):
     return out
 
 
-def run_c5e2e(args, dev, rank, world):
+def run_c5e2e(args, dev, rank, world, as_leg=False):
     """BASELINE.json config 5 end to end.  One step = reference
     `optimize_parameters` (TrainTestGSASR/basicsr/models/gsasr_model.py:175-245) with this package's batched rasterizer.
     N > 1: independent replicas (one batch per rank, no collective: the rasterizer path itself does not shard here)."""
@@ -638,6 +693,8 @@ def run_c5e2e(args, dev, rank, world):
         out["cpu_baseline"] = {"value": H * W / t1 / 1e6, "unit": "HR Mpixels/s", "cores": cores, "logical_cpus": os.cpu_count(),
                                "kind": "port", "sample": f"ONE sample of the step (encoder + producer in torch on the CPU, oracle/gs_ref.c "
                                f"fp32 restatement of gs_cuda_dmax forward + backward, autograd to the producers; no optimizer step): {t1:.2f} s"}
+    if as_leg:
+        return out
     emit(out)
 
 
@@ -691,7 +748,10 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     ms = wall_ms(st, n, dev, warm=max(10, n // 2))
     kern = stage_times(st, dev, iters=10 if st.H * st.W > 4e7 else 20)
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
-    in_box, swept, vfrac = pair_rates(st, kern, a.cutoff)
+    if st.batched:      # (pair counts need the kernel-frame tensors: the batched step keeps raw decoder parameters only)
+        in_box, swept, vfrac = None, None, {}
+    else:
+        in_box, swept, vfrac = pair_rates(st, kern, a.cutoff)
     tau_eff, k_box = effective_tau(st, a.cutoff)
     h_lr, w_lr, scale, desc = CONFIGS[config]
     traffic = None
@@ -705,7 +765,7 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
            "cutoff_tau": round(tau_eff, 3), "cutoff_k_box": k_box,
            "cutoff_tau_conservative": round(st.cabi.resolve_cutoff(a.cutoff, st.plan.dims.s), 3),
            "what": "fwd only" if st.fwd_only else "fwd+bwd",
-           "forward_subtile_px": st.cabi.forward_subtile_width(st.plan),    # 16 = the wide forward (x5 and up), 8 = the 8 x 16 kernels
+           "forward_subtile_px": None if st.batched else st.cabi.forward_subtile_width(st.plan),    # 16 = the wide forward (x5 and up), 8 = the 8 x 16 kernels
            "steps": n, "ms_per_step": ms, "value": st.H * st.W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
            "kernels": kern,
            "roofline": {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
