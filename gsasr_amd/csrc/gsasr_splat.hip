@@ -97,7 +97,9 @@ constexpr int NCH = 64;         // row chunks a large Gaussian is split into in 
                                       // 1024^2 54.0 -> 44.7 us, the config-5 canvas 35.4 -> 32.4; at 262 144 Gaussians fused 22.8 vs 24.0
                                       // (development: GSASR_SPLAT_FUSED_MAX)
 #endif
-constexpr int FUSED_CELLS_HOST = 256 * 17;   // = FUSED_CELLS (k_bin<true>): grids up to this many classes never run a scan kernel
+constexpr int FUSED_CELLS_HOST = 256 * 17;   // = FUSED_CELLS (k_bin<true, ..>): grids up to this many classes never run a scan kernel
+constexpr int TL_W = 32;         // tile lists: tile width in pixels (height 16 or 32: Params::tl_hlog)
+constexpr int TL_STRIDE = 16;    // ... words between two tiles' cursors: one per 64-byte line (atomics serialise per LINE)
 constexpr int HDR_WORDS = 64;   // plan header (uint32): [0]=max x half-extent of normals, [1]=max y, [2]=largest cell count,
                                 //   [3]=bits of sqrt(2 tau') the windows were built with, [4]=bits of tau', [5]=K (see adapt_kcut),
                                 //   [6]=largest count of a 4 x 4 block of cells (block_count_max), [7]=near-dead Gaussians (adapt_kcut (3)),
@@ -132,6 +134,10 @@ struct Params {
     int bt_hlog;     // ... and log2 of its tile height: 4 (32 x 16 px) or 5 (32 x 32, from 32 HR pixels per Gaussian); the tile
                      // kernel and the gather number a window's tiles with it (bt_tile_span)
     int grad_rows;   // rows per plane of a planar (GSASR_FLAG_CHW_GRAD) upstream gradient of a batched canvas
+    int tl_hlog;     // tile lists (PlanView::tl_entries): log2 of the tile height, 4 (32 x 16 px: the 8 x 16 forward) or 5 (32 x 32: the
+                     // wide forward); 0: this plan carries none
+    int tl_cap;      // ... entries a tile's list can hold (a tile whose cursor ends above it is rendered by the search instead)
+    int tl_ntx, tl_ntiles;   // ... tiles per row of tiles, tiles in all (over the rows [row0, row1))
 };
 
 // One sample of a batched canvas: its own pixel-grid size, its first canvas row and its px-table offset.
@@ -167,6 +173,10 @@ struct PlanView {
     uint4 *qspan;           // [s] (plans with slots only) per band of 8 rows of the window (8 bands at most): the range of 8-px
                             //       columns, counted from the window's first, that the ellipse {exponent >= -tau} reaches:
                             //       {lo[0..3], hi[0..3], lo[4..7], hi[4..7]} bytes; lo > hi = none
+    unsigned *tl_cursor;    // [tl_ntiles * TL_STRIDE] tile lists: entries appended to tile t's list so far (zeroed by k_classify,
+                            //       counted up by k_bin: wave-aggregated returning atomics); > tl_cap = overflowed
+    uint2 *tl_entries;      // [tl_ntiles * tl_cap] tile t's list: {slot in cell order | needs the dmax test << 31, mask of the
+                            //       tile's 8 x 8-px quadrants (bit 4 qy + qx) that the ellipse {exponent >= -tau'} reaches}
     float *part;            // [s * part_k * 8] tile-stationary backward: the raw sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} of
                             //       Gaussian j (cell order) over the t-th 32x16-px tile of its window, written with plain stores
 };
@@ -183,6 +193,9 @@ __device__ __forceinline__ Geo sample_geo(const Params &P, const PlanView &V, in
 
 struct Layout {
     size_t off_geo, off_hdr, off_count, off_start, off_px, off_py, off_key, off_rank, off_bmax, off_stot, off_rec, off_fin, off_sums, off_done, off_bbox, off_win, off_part, off_qspan;
+    size_t off_tlc, off_tle;     // tile lists (at the END of the workspace: every other offset is the same with and without them)
+    int tl_hlog, tl_cap, tl_ntx, tl_ntiles;
+    bool tl_ok;                  // the lists may be READ: the plan's note says it wrote them (plan_layout)
     int part_k;
     size_t count_bytes;  // one array of per-cell counters + extent groups (there are two, used alternately: GSASR_FLAG_PARITY)
     size_t ext_off_words; // where the extent groups start inside such an array
@@ -218,14 +231,26 @@ int classify_blocks(const gsasr_dims *d)
     return (n + 255) / 256;
 }
 
-// which backward kernel: explicit flag > environment GSASR_SPLAT_BWD (gaussian | tile | atomic; development A/B) > default
+// DEVELOPMENT switches (A/B runs of one build on one box; tools/collect_profiles.sh): environment variables that override a
+// kernel choice the library makes by shape.  They are read ONLY when GSASR_SPLAT_DEV=1 is set as well -- a production process
+// that happens to carry one of the names in its environment is not affected -- and each is read once.
+//   GSASR_SPLAT_FWD_WIDE=0|1   GSASR_SPLAT_BWD=gaussian|tile|atomic   GSASR_SPLAT_BT_TALL=0|1   GSASR_SPLAT_ADAPT=0
+//   GSASR_SPLAT_FUSED_MAX=<k_bin blocks>   GSASR_SPLAT_LISTS=0|1
+// (GSASR_SPLAT_CUTOFF is not one of them: it is the documented process default of the support cutoff, INTEGRATION.md.)
+const char *dev_switch(const char *name)
+{
+    static const bool on = [] { const char *e = getenv("GSASR_SPLAT_DEV"); return e && atoi(e) != 0; }();
+    return on ? getenv(name) : nullptr;
+}
+
+// which backward kernel: explicit flag > development switch GSASR_SPLAT_BWD (gaussian | tile | atomic) > default
 // development switch: GSASR_SPLAT_FWD_WIDE=0 / 1 forces the wide forward (16 x 16 sub-tiles) off / on
 int fwd_wide_env()
 {
     static std::atomic<int> cached{-2};
     int v = cached.load(std::memory_order_relaxed);
     if (v == -2) {
-        const char *e = getenv("GSASR_SPLAT_FWD_WIDE");
+        const char *e = dev_switch("GSASR_SPLAT_FWD_WIDE");
         v = !e ? -1 : atoi(e) != 0;
         cached.store(v, std::memory_order_relaxed);
     }
@@ -253,7 +278,7 @@ int bwd_env()
     static std::atomic<int> cached{-1};
     int v = cached.load(std::memory_order_relaxed);
     if (v < 0) {
-        const char *e = getenv("GSASR_SPLAT_BWD");
+        const char *e = dev_switch("GSASR_SPLAT_BWD");
         v = !e ? 0 : !strcmp(e, "gaussian") ? 1 : !strcmp(e, "tile") ? 2 : !strcmp(e, "atomic") ? 3 : 0;
         cached.store(v, std::memory_order_relaxed);
     }
@@ -295,7 +320,7 @@ bool bt_tall(const gsasr_dims *d)
     static std::atomic<int> cached{-2};
     int v = cached.load(std::memory_order_relaxed);
     if (v == -2) {
-        const char *e = getenv("GSASR_SPLAT_BT_TALL");
+        const char *e = dev_switch("GSASR_SPLAT_BT_TALL");
         v = !e ? -1 : atoi(e) != 0;
         cached.store(v, std::memory_order_relaxed);
     }
@@ -312,7 +337,56 @@ int bwd_part_k(const gsasr_dims *d)
     return px_per_gaussian >= 32.0 ? 16 : 8;
 }
 
-Layout make_layout(const gsasr_dims *d, int part_k = -1)
+// Tile lists (round 5).  The render kernels used to FIND their Gaussians: every 32 x 16-px tile walked the cells within the
+// class' largest extent of it and tested 4-5 candidates per hit (half of the forward at x4).  A plan with lists does that
+// work once per Gaussian instead: k_bin, which holds the Gaussian's window and per-band ellipse spans in registers anyway,
+// appends {slot, quadrant mask} to the list of every tile the ellipse reaches; the forward reads its tile's list and tests
+// nothing but a mask bit.  Fixed capacity per tile (the host cannot know the window sizes, they live on the device): a tile
+// whose list overflows is rendered by the search -- same results, graceful.  The "large" class (half-extent > 128 px: one
+// Gaussian would enter thousands of lists) stays a segment every tile scans.
+// development switch: GSASR_SPLAT_LISTS=0 / 1
+int lists_env()
+{
+    static std::atomic<int> cached{-2};
+    int v = cached.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char *e = dev_switch("GSASR_SPLAT_LISTS");
+        v = !e ? -1 : atoi(e) != 0;
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// log2 of the list tiles' height for a plan of these dims: 5 where the forward will be the wide kernel (32 x 32-px tiles),
+// 4 for the two-level 8 x 16 kernels (32 x 16), 0 = no lists (small images: the split kernel; list_cap < 0; no Gaussians)
+int tl_hlog_for(const gsasr_dims *d)
+{
+    if (d->list_cap < 0 || d->s <= 0 || lists_env() == 0) return 0;
+    const int rows = d->row1 - d->row0;
+    if (fwd_wants_wide(d)) return 5;
+    const long nsub = (long)((d->w + SUBX - 1) / SUBX) * ((rows + SUBY - 1) / SUBY);
+    return nsub >= 4096 ? 4 : 0;
+}
+
+// Entries per tile.  gsasr_dims.list_cap when given; else four times what a tile of GSASR-shaped Gaussians (about one LR
+// pixel in size: half-extent ~ 2.5 / sqrt(Gaussians per pixel), twice that allowed for) collects, + 64.
+int tl_cap_for(const gsasr_dims *d, int hlog)
+{
+    if (!hlog) return 0;
+    long cap = d->list_cap;
+    if (cap <= 0) {
+        const double rows = (double)(d->row1 - d->row0 > 0 ? d->row1 - d->row0 : 1);
+        // (density over the rows rendered; a row band that is handed every Gaussian of the image sees most of them dead: its
+        // tiles then have room to spare, never too little)
+        const double rho = (double)d->s / ((double)d->w * rows), e = 5.0 / std::sqrt(rho > 1e-9 ? rho : 1e-9);
+        const double want = 4.0 * rho * ((double)TL_W + e) * ((double)(1 << hlog) + e) + 64.0;
+        cap = (long)std::fmin(want, 65536.0);
+    }
+    cap = (cap + 63) / 64 * 64;
+    return (int)(cap < 128 ? 128 : cap > 65536 ? 65536 : cap);
+}
+
+Layout make_layout(const gsasr_dims *d, int part_k = -1, int tl_hlog = -1)
 {
     Layout L{};
     L.ncx = (d->w + CELL - 1) / CELL;
@@ -345,6 +419,15 @@ Layout make_layout(const gsasr_dims *d, int part_k = -1)
     L.part_k = part_k >= 0 ? part_k : bwd_part_k(d);
     L.off_part = o;   o += align_up(s * 32 * (size_t)L.part_k, 256);
     L.off_qspan = o;  o += L.part_k ? align_up(s * 16, 256) : 0;
+    // tile lists LAST: a caller whose flags differ from the plan's (GSASR_FLAG_FWD_WIDE at forward time) lays out everything
+    // else identically; whether the workspace carries lists, and of which tile height, is the plan's note (plan_layout)
+    L.tl_hlog = tl_hlog >= 0 ? tl_hlog : tl_hlog_for(d);
+    L.tl_cap = tl_cap_for(d, L.tl_hlog);
+    L.tl_ntx = (d->w + TL_W - 1) / TL_W;
+    L.tl_ntiles = L.tl_hlog ? L.tl_ntx * ((d->row1 - d->row0 + (1 << L.tl_hlog) - 1) >> L.tl_hlog) : 0;
+    L.off_tlc = o;    o += align_up((size_t)L.tl_ntiles * TL_STRIDE * 4, 256);
+    L.off_tle = o;    o += align_up((size_t)L.tl_ntiles * (size_t)L.tl_cap * 8, 256);
+    L.tl_ok = L.tl_hlog != 0;
     L.total = o;
     return L;
 }
@@ -372,6 +455,8 @@ PlanView make_view(const Layout &L, void *ws, unsigned flags = 0u)
     V.win = (uint2 *)(b + L.off_win);
     V.part = (float *)(b + L.off_part);
     V.qspan = L.part_k ? (uint4 *)(b + L.off_qspan) : nullptr;
+    V.tl_cursor = (unsigned *)(b + L.off_tlc);
+    V.tl_entries = (uint2 *)(b + L.off_tle);
     return V;
 }
 
@@ -398,7 +483,7 @@ bool adapt_env()
     static std::atomic<int> cached{-1};
     int v = cached.load(std::memory_order_relaxed);
     if (v < 0) {
-        const char *e = getenv("GSASR_SPLAT_ADAPT");
+        const char *e = dev_switch("GSASR_SPLAT_ADAPT");
         v = !e ? 1 : atoi(e) != 0;
         cached.store(v, std::memory_order_relaxed);
     }
@@ -479,6 +564,7 @@ Params make_params(const gsasr_dims *d, const Layout &L)
     P.bt_hlog = bt_tall(d) ? 5 : 4;
     batch_uniform(d, P.geo_h, P.geo_w);
     P.grad_rows = d->grad_rows > 0 ? d->grad_rows : P.slot;
+    P.tl_hlog = L.tl_hlog; P.tl_cap = L.tl_cap; P.tl_ntx = L.tl_ntx; P.tl_ntiles = L.tl_ntiles;
     return P;
 }
 
@@ -504,23 +590,32 @@ unsigned long long note_shape(const gsasr_dims *d)
     return (x >> 40) & 0xffffull;
 }
 
-void note_plan(const void *ws, const gsasr_dims *d, int part_k)
+// (payload byte: slots per Gaussian in bits 0..4, the tile lists' tile height in bits 5..6: 0 none, 1 = 16 rows, 2 = 32)
+void note_plan(const void *ws, const gsasr_dims *d, int part_k, int tl_hlog)
 {
     const unsigned long long w = ((unsigned long long)(uintptr_t)ws & 0x0000ffffffffff00ull) << 16 | note_shape(d) << 8 |
-                                 (unsigned long long)(part_k & 0xff);
+                                 (unsigned long long)((part_k & 0x1f) | (tl_hlog ? (tl_hlog - 3) << 5 : 0));
     g_notes[note_slot(ws)].store(w, std::memory_order_relaxed);
 }
 
-// layout of the plan in `ws`: from the note its plan left, else from these dims
+// layout of the plan in `ws`: from the note its plan left, else from these dims -- except the tile lists, which a call uses
+// only on the note's word (a lost note means the search, never a list nobody wrote)
 Layout plan_layout(const gsasr_dims *d, const void *ws)
 {
-    int part_k = -1;
+    int part_k = -1, tl_hlog = -1;
     if (ws) {
         const unsigned long long w = g_notes[note_slot(ws)].load(std::memory_order_relaxed);
         const unsigned long long key = ((unsigned long long)(uintptr_t)ws & 0x0000ffffffffff00ull) << 16 | note_shape(d) << 8;
-        if ((w & ~0xffull) == key) part_k = (int)(w & 0xffull);
+        if ((w & ~0xffull) == key) {
+            part_k = (int)(w & 0x1full);
+            tl_hlog = (int)((w >> 5) & 3ull) ? (int)((w >> 5) & 3ull) + 3 : 0;
+        }
     }
-    return make_layout(d, part_k);
+    // (without a note the list region is still SIZED from the dims -- the step entry points place their scratch behind the
+    // plan -- but nothing reads it)
+    Layout L = make_layout(d, part_k, tl_hlog);
+    if (tl_hlog < 0) L.tl_ok = false;
+    return L;
 }
 
 thread_local char tl_err[256] = "";
@@ -770,6 +865,8 @@ __global__ __launch_bounds__(256) void k_classify(Params P, const float *__restr
     const int lane = threadIdx.x & 63;
     // the counters of the NEXT plan on this workspace (the other parity) are zeroed on the side
     for (int k = i; k < P.count_words; k += (int)(gridDim.x * blockDim.x)) V.cell_count_next[k] = 0u;
+    // ... and the cursors of THIS plan's tile lists (k_bin, the next kernel but one at most, counts them up)
+    for (int k = i; k < P.tl_ntiles; k += (int)(gridDim.x * blockDim.x)) V.tl_cursor[(size_t)k * TL_STRIDE] = 0u;
     if (i == 0) V.hdr[2] = V.hdr[6] = V.hdr[7] = V.hdr[8] = V.hdr[9] = 0u;   // largest cell / block count: raised with atomicMax by k_scan_local / block_count_max
     // pixel-centre tables: the reference's double expression, rounded to float (gs_cuda/gs.cu:27-28)
     if (P.batch <= 1) {
@@ -1036,6 +1133,96 @@ __global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__
     if ((int)blockIdx.x == nchunks - 1 && t == 0) start[n] = off + tot[blockIdx.x];
 }
 
+// Tile lists: the quadrants (8 x 8 px; bit 4 qy + qx) of list tile (tx, ty) that Gaussian's ellipse {exponent >= -tau'}
+// reaches, from the window words k_bin has just built (bb = bbox[2j], sp = the spans of bands 4..7): exactly the
+// window-rectangle + per-16-row-band column-span test the search kernels apply per sub-tile (fwd_block phase B), refined
+// to quadrant rows by the window's own first and last row.
+template <int HLOG>
+__device__ __forceinline__ unsigned tl_mask(int tx, int ty, const uint4 bb, const uint2 sp, int row0)
+{
+    const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16), r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+    const bool spans = (bb.y & 0x8000u) != 0u;
+    const int wb0 = (r0 - row0) >> SUBY_SHIFT, cu0 = c0 >> SUBX_SHIFT;
+    constexpr int NB = 1 << (HLOG - 4);      // 16-row bands per tile
+    unsigned mask = 0u;
+#pragma unroll
+    for (int bnd = 0; bnd < NB; ++bnd) {
+        const int G = ty * NB + bnd;         // the band, counted from row0
+        const int y0 = row0 + (G << SUBY_SHIFT);
+        int lo = cu0, hi = c1 >> SUBX_SHIFT;
+        bool any = r0 <= y0 + SUBY - 1 && r1 >= y0;
+        if (spans) {
+            const unsigned t = (unsigned)(G - wb0) & 7u, sh = (t & 3u) * 8u;
+            const unsigned l = ((t < 4u ? bb.z : sp.x) >> sh) & 0xffu, h = ((t < 4u ? bb.w : sp.y) >> sh) & 0xffu;
+            lo = cu0 + (int)l;
+            hi = cu0 + (int)h;
+            any = any && l <= h;
+        }
+        const int q0 = max(lo - 4 * tx, 0), q1 = min(hi - 4 * tx, 3);
+        if (any && q0 <= q1) {
+            const unsigned bits = (2u << q1) - (1u << q0);
+            if (r0 <= y0 + 7) mask |= bits << (8 * bnd);
+            if (r1 >= y0 + 8) mask |= bits << (8 * bnd + 4);
+        }
+    }
+    return mask;
+}
+
+// Append {j | test << 31, mask} to the lists of the tiles Gaussian j's window touches, TLB tiles of every lane per round.
+// The cursors are bumped with ONE returning atomic per (wave, round slot, distinct tile), all of a slot's issued in one
+// instruction (cf. k_classify's ranks): raster-ordered decoder output puts the 64 Gaussians of a wave into a handful of tiles,
+// and atomics on one word -- on one cache LINE -- serialise at ~12 ns each whichever wave they come from.
+constexpr int TLB = 4;
+
+template <int HLOG>
+__device__ __forceinline__ void tl_emit(const Params &P, const PlanView &V, bool emit, unsigned j, const uint4 bb, const uint2 sp)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int nx = 0, ntile = 0, tX0 = 0, tY0 = 0;
+    if (emit) {
+        const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16), r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+        tX0 = c0 >> 5;
+        nx = (c1 >> 5) - tX0 + 1;
+        tY0 = (r0 - P.row0) >> HLOG;
+        ntile = nx * (((r1 - P.row0) >> HLOG) - tY0 + 1);
+    }
+    const unsigned ex = j | ((bb.x & 0x8000u) << 16);
+    int ix = 0, iy = 0;
+    for (int base = 0; __ballot(base < ntile) != 0ull; base += TLB) {
+        unsigned m[TLB], ti[TLB], pos[TLB];
+        unsigned long long mine[TLB];
+#pragma unroll
+        for (int k = 0; k < TLB; ++k) {
+            const bool v = base + k < ntile;
+            m[k] = v ? tl_mask<HLOG>(tX0 + ix, tY0 + iy, bb, sp, P.row0) : 0u;
+            ti[k] = (unsigned)((tY0 + iy) * P.tl_ntx + tX0 + ix);
+            if (v && ++ix == nx) { ix = 0; ++iy; }
+            // lanes with the same tile in this slot: one group, one atomic
+            mine[k] = 0ull;
+            unsigned long long todo = __ballot(m[k] != 0u);
+            while (todo) {
+                const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)ti[k], __builtin_ctzll(todo));
+                const unsigned long long same = __ballot(m[k] != 0u && ti[k] == t0);
+                if (m[k] != 0u && ti[k] == t0) mine[k] = same;
+                todo &= ~same;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TLB; ++k) {
+            pos[k] = 0u;
+            if (mine[k] && lane == __builtin_ctzll(mine[k]))
+                pos[k] = atomicAdd(&V.tl_cursor[(size_t)ti[k] * TL_STRIDE], (unsigned)__builtin_popcountll(mine[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < TLB; ++k) {
+            const int leader = mine[k] ? __builtin_ctzll(mine[k]) : 0;
+            const unsigned at = (unsigned)__shfl((int)pos[k], leader) + (unsigned)__builtin_popcountll(mine[k] & below);
+            if (mine[k] && at < (unsigned)P.tl_cap) V.tl_entries[(size_t)ti[k] * (size_t)P.tl_cap + at] = make_uint2(ex, m[k]);
+        }
+    }
+}
+
 // counting-sort placement (slot = cell start + rank, no atomics) fused with record packing
 // FUSED_SCAN (grids of at most FUSED_CELLS cells+2, e.g. 1024^2): every block rebuilds the exclusive scan of
 // the cell histogram in LDS itself (16 counts per thread) instead of waiting for a separate one-block scan
@@ -1043,7 +1230,7 @@ __global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__
 constexpr int FUSED_PER_THREAD = 17, FUSED_CELLS = 256 * FUSED_PER_THREAD;
 static_assert(FUSED_CELLS == FUSED_CELLS_HOST, "make_params decides with FUSED_CELLS_HOST which plans run a scan kernel");
 
-template <bool FUSED_SCAN>
+template <bool FUSED_SCAN, int TLH>
 __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__ sigmas,
                                              const float *__restrict__ coords,
                                              const float *__restrict__ colors, PlanView V, int nblk)
@@ -1330,8 +1517,9 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
             }
         }
     }
-    if (!valid) return;
-    const unsigned j = (FUSED_SCAN ? s_start[key] : V.cell_start[key]) + rnk;
+    if (!valid && TLH == 0) return;
+    const unsigned j = valid ? (FUSED_SCAN ? s_start[key] : V.cell_start[key]) + rnk : 0u;
+    if (valid) {
     // A dead Gaussian (off the image, off this row band, non-finite) is never a candidate of any tile; all that is ever read
     // of it is its (empty) window and its original index, by the backward that writes its zero gradient.  A row band of
     // a sharded image plans every Gaussian of the image: most of them are dead there, and their records are not written.
@@ -1356,6 +1544,9 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         reinterpret_cast<float4 *>(V.sums)[2 * (size_t)j + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (large) V.done[j] = 0u;
     }
+    }
+    if constexpr (TLH != 0)   // tile lists: the normal class only (the large one stays a segment every tile scans)
+        tl_emit<TLH == 0 ? 4 : TLH>(P, V, valid && key < (unsigned)P.ncells, j, bb, make_uint2(bc.x, bc.y));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3539,7 +3730,7 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
 {
     Layout L;
     if (int rc = check_ws(dims, workspace, workspace_bytes, L, true)) return rc;
-    note_plan(workspace, dims, L.part_k);
+    note_plan(workspace, dims, L.part_k, L.tl_hlog);
     if (dims->s > 0 && (!sigmas || !coords || !colors)) return fail(GSASR_ERR_ARG, "null input pointer");
     hipStream_t st = (hipStream_t)stream;
     const Params P = make_params(dims, L);
@@ -3556,10 +3747,12 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
                            SS, (float *)nullptr, (float *)nullptr, (float *)nullptr);
     const int ncls = L.ncells + 1 + NDEAD;
     const unsigned nbin = (unsigned)((dims->s + 255) / 256);
-    static const int fused_max_blocks = getenv("GSASR_SPLAT_FUSED_MAX") ? atoi(getenv("GSASR_SPLAT_FUSED_MAX")) : FUSED_MAX_BLOCKS;
+    static const int fused_max_blocks = dev_switch("GSASR_SPLAT_FUSED_MAX") ? atoi(dev_switch("GSASR_SPLAT_FUSED_MAX")) : FUSED_MAX_BLOCKS;
     if (ncls <= FUSED_CELLS && dims->s > 0 && (int)nbin <= fused_max_blocks) {
         // small grid, not too many blocks: k_bin rebuilds the scan per block (no separate scan launch)
-        hipLaunchKernelGGL(k_bin<true>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+        if (P.tl_hlog == 5) hipLaunchKernelGGL((k_bin<true, 5>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+        else if (P.tl_hlog == 4) hipLaunchKernelGGL((k_bin<true, 4>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+        else hipLaunchKernelGGL((k_bin<true, 0>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
     } else {
         if (ncls <= 2 * SCAN_CHUNK) {
             hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P, ncls, V.cell_count, V.cell_start, L.ext_groups, V.blockmax,
@@ -3571,8 +3764,11 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
             hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, P, ncls, V.cell_start, V.scan_tot, nchunks,
                                V.cell_count, V.hdr);
         }
-        if (dims->s > 0)
-            hipLaunchKernelGGL(k_bin<false>, dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+        if (dims->s > 0) {
+            if (P.tl_hlog == 5) hipLaunchKernelGGL((k_bin<false, 5>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+            else if (P.tl_hlog == 4) hipLaunchKernelGGL((k_bin<false, 4>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+            else hipLaunchKernelGGL((k_bin<false, 0>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+        }
     }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;

@@ -385,4 +385,6 @@ def test_published_workload_bands_against_oracle(dev):
         img = torch.empty(H, W, 3, device=dev)
         _cabi.forward(plan, img, overwrite=True)
         for r, ref in zip(bands, refs):
-            assert np.abs(img[r[0]:r[1]].cpu().numpy() - ref).max() <= 2e-5 * top, (tau, r)
+            # (a pixel is a sequential fp32 sum of 2.6e5 terms: sqrt(n) * 2^-24 ~ 3e-5 of the sum is its rounding noise)
+            err = float(np.abs(img[r[0]:r[1]].cpu().numpy() - ref).max())
+            assert err <= 2e-4 * top, (tau, r, err, top)

@@ -420,10 +420,18 @@ def emit(out):
     sys.stdout.flush()
 
 
-def wall_ms(fn, n, dev, warm=3):
+def wall_ms(fn, n, dev, warm=3, warm_s=0.0):
+    """mean wall time of `fn` over n calls; `warm` untimed calls first, and -- warm_s > 0 -- as many more as it takes to keep
+    the GPU busy for that long (a leg that follows host-bound work finds the clocks down: 25 steps of 0.3 ms did not bring
+    them back, and the x12 leg of one run read 0.69 ms per step for kernels that take 0.32)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize(dev)
+    t_end = time.perf_counter() + warm_s
+    while time.perf_counter() < t_end:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(n):
         fn()
@@ -745,7 +753,7 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     n = steps or (20 if st.H * st.W > 4e7 else 50)
     # (as many untimed steps as the standalone run of this config gets before its timed loop: three leave the GPU's clocks
     # still ramping after the host-side set-up, which cost the x12 and x8 legs 5-9%)
-    ms = wall_ms(st, n, dev, warm=max(10, n // 2))
+    ms = wall_ms(st, n, dev, warm=max(10, n // 2), warm_s=0.15)
     kern = stage_times(st, dev, iters=10 if st.H * st.W > 4e7 else 20)
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
     if st.batched:      # (pair counts need the kernel-frame tensors: the batched step keeps raw decoder parameters only)
