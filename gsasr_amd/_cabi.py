@@ -52,7 +52,7 @@ class Dims(ctypes.Structure):
                 ("dmax", ctypes.c_float), ("row0", ctypes.c_int), ("row1", ctypes.c_int),
                 ("cutoff", ctypes.c_float), ("flags", ctypes.c_uint),
                 ("batch", ctypes.c_int), ("slot", ctypes.c_int), ("sample_hw", ctypes.POINTER(ctypes.c_int)),
-                ("grad_rows", ctypes.c_int)]
+                ("grad_rows", ctypes.c_int), ("list_cap", ctypes.c_int)]
 
 
 _lib = None
@@ -124,7 +124,7 @@ def lib():
         L.gsasr_forward_subtile_width.argtypes = [dp]
         L.gsasr_plan_cutoff.restype = i
         L.gsasr_plan_cutoff.argtypes = [dp, vp, sz, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]
-        if L.gsasr_abi_version() != 4:
+        if L.gsasr_abi_version() != 5:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
     return _lib
@@ -256,22 +256,24 @@ class Plan:
 
 
 def make_dims(s: int, h: int, w: int, dmax: Optional[float], rows: Optional[Tuple[int, int]] = None,
-              cutoff: float = 0.0, flags: int = 0) -> Dims:
+              cutoff: float = 0.0, flags: int = 0, list_cap: int = 0) -> Dims:
     r0, r1 = (0, h) if rows is None else rows
-    return Dims(int(s), int(h), int(w), 3, -1.0 if dmax is None else float(dmax), int(r0), int(r1),
-                float(cutoff), int(flags))
+    d = Dims(int(s), int(h), int(w), 3, -1.0 if dmax is None else float(dmax), int(r0), int(r1),
+             float(cutoff), int(flags))
+    d.list_cap = int(list_cap)      # tile lists: 0 = the library's capacity estimate, > 0 entries per tile, < 0 none
+    return d
 
 
 _PLAN_DIMS = {}     # (s, h, w, dmax, rows, cutoff, flags) -> ([Dims fresh, pooled parity 0, pooled parity 1], workspace bytes)
 
 
-def _plan_dims(s: int, h: int, w: int, dmax, rows, cutoff: float, flags: int):
-    key = (s, h, w, dmax, rows, cutoff, flags)
+def _plan_dims(s: int, h: int, w: int, dmax, rows, cutoff: float, flags: int, list_cap: int = 0):
+    key = (s, h, w, dmax, rows, cutoff, flags, list_cap)
     hit = _PLAN_DIMS.get(key)
     if hit is None:      # (dims structs + workspace size per shape: built once, not per call)
         if dmax is not None and not (float(dmax) >= 0.0):
             raise RuntimeError("dmax must be >= 0")
-        variants = [make_dims(s, h, w, dmax, rows, cutoff, int(flags) | f)
+        variants = [make_dims(s, h, w, dmax, rows, cutoff, int(flags) | f, list_cap)
                     for f in (0, FLAG_COUNTERS_CLEAN, FLAG_COUNTERS_CLEAN | FLAG_PARITY)]
         nbytes = lib().gsasr_splat_workspace_bytes(ctypes.byref(variants[0]))
         if nbytes == 0:
@@ -284,14 +286,14 @@ def _plan_dims(s: int, h: int, w: int, dmax, rows, cutoff: float, flags: int):
 
 def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: int, w: int,
          dmax: Optional[float], rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0,
-         flags: int = 0) -> Plan:
+         flags: int = 0, list_cap: int = 0) -> Plan:
     ps = _ptr3(sigmas, "sigmas", 3)
     pc = _ptr3(coords, "coords", 2)
     pk = _ptr3(colors, "colors", 3)
     s = sigmas.shape[0]
     if coords.shape[0] != s or colors.shape[0] != s:
         raise RuntimeError("sigmas, coords, colors disagree on the number of Gaussians")
-    variants, nbytes = _plan_dims(s, int(h), int(w), dmax, rows, cutoff, flags)
+    variants, nbytes = _plan_dims(s, int(h), int(w), dmax, rows, cutoff, flags, list_cap)
     dev = sigmas.device
     with _on(dev):
         stream = _stream(dev)

@@ -365,7 +365,7 @@ int tl_hlog_for(const gsasr_dims *d)
     const int rows = d->row1 - d->row0;
     if (fwd_wants_wide(d)) return 5;
     const long nsub = (long)((d->w + SUBX - 1) / SUBX) * ((rows + SUBY - 1) / SUBY);
-    return nsub >= 4096 ? 4 : 0;
+    return (nsub >= 4096 || d->list_cap > 0) ? 4 : 0;      // (an explicit capacity asks for lists on any image: tests)
 }
 
 // Entries per tile.  gsasr_dims.list_cap when given; else four times what a tile of GSASR-shaped Gaussians (about one LR
@@ -383,7 +383,7 @@ int tl_cap_for(const gsasr_dims *d, int hlog)
         cap = (long)std::fmin(want, 65536.0);
     }
     cap = (cap + 63) / 64 * 64;
-    return (int)(cap < 128 ? 128 : cap > 65536 ? 65536 : cap);
+    return (int)(cap > 65536 ? 65536 : cap);
 }
 
 Layout make_layout(const gsasr_dims *d, int part_k = -1, int tl_hlog = -1)
@@ -1695,7 +1695,8 @@ __device__ __forceinline__ unsigned fwd_candidate(unsigned c, int lane, int nseg
 // One wave, one 8x16 sub-tile at (sx0, sy0): accumulate every Gaussian binned near it into ar/ag/ab
 // (lane = column sx0 + lane%8, rows sy0 + lane/8 and +8).  With nparts > 1 the 64-candidate chunks are
 // dealt round-robin to `nparts` waves and the caller adds their partial sums.
-template <bool BOUNDED>
+// LARGE_ONLY: the walk over the "large" class alone (what a list kernel still has to scan: tile lists hold the normal class).
+template <bool BOUNDED, bool LARGE_ONLY = false>
 __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int sx0, int sy0, int lane,
                                          unsigned part, unsigned nparts, float4 *stage, v2f &ar, v2f &ag, v2f &ab)
 {
@@ -1713,7 +1714,7 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
     // Segment table: lane r holds [beg,end) of cell row cy0+r restricted to the columns a normal-class
     // Gaussian can reach this sub-tile from (max half-extent from the plan header); one more lane holds
     // the large class.  One vector round trip instead of a dependent scalar load per row.
-    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
+    const int rx = LARGE_ONLY ? 0 : (int)V.hdr[8], ry = LARGE_ONLY ? 0 : (int)V.hdr[9];
     int nseg = 0;
     unsigned sbeg = 0, send = 0;
     if (rx > 0) {
@@ -2191,6 +2192,253 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         __syncthreads();   // the list is rewritten in the next round
     }
     if (live && X < P.w) {
+        fwd_store_px(P, img, X, Y, acc[0].x, acc[1].x, acc[2].x);
+        fwd_store_px(P, img, X, Y + 4, acc[0].y, acc[1].y, acc[2].y);
+        fwd_store_px(P, img, X, Y + 8, acc[3].x, acc[4].x, acc[5].x);
+        fwd_store_px(P, img, X, Y + 12, acc[3].y, acc[4].y, acc[5].y);
+    }
+}
+
+// ---- forward from the plan's tile lists (round 5) -------------------------------------------------------------
+// The tile's hit list was written by k_bin (tl_emit): nothing is searched and nothing is tested but a mask bit.  A wave streams
+// the tile's entries 64 at a time, keeps those whose quadrant mask meets its own sub-tile, gathers their 32-byte records into
+// its LDS stage and evaluates them as the search kernels do (same fwd_eval_lds: same sums in another order).  The records of
+// chunk k+1 are in flight while chunk k is evaluated.  No barriers, no shared lists: the four waves of a workgroup only share
+// the tile.  A tile whose list overflowed its capacity is rendered by the one-level search (fwd_tile); the "large" class is
+// scanned by every tile as before.
+template <bool BOUNDED, int PARTS>
+__global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+{
+    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = wv & 3;
+    const unsigned part = (unsigned)(wv >> 2);
+    __shared__ float4 s_stage[4 * PARTS][128];
+    __shared__ float s_part[PARTS > 1 ? 4 : 1][6][64];
+    float4 *stage = s_stage[wv];
+    v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
+    const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
+    const int sx0 = bx0 + sub * SUBX;
+    if (sx0 < P.w) {   // wave-uniform (image width not a multiple of 32)
+        const unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)V.tl_cursor[(size_t)t * TL_STRIDE]);
+        if (cnt > (unsigned)P.tl_cap) {
+            fwd_tile<BOUNDED, false>(P, V, sx0, by0, lane, part, (unsigned)PARTS, stage, ar, ag, ab);
+        } else {
+            const int X = sx0 + (lane & 7);
+            const float px = V.px[(P.batch > 1 ? (by0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
+            const int Y0 = by0 + (lane >> 3);
+            const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y0 + 8, P.h - 1)]};
+            const uint2 *__restrict__ ent = V.tl_entries + (size_t)t * (size_t)P.tl_cap;
+            const float4 *__restrict__ rec = V.rec;
+            const unsigned mybits = 0x11u << sub;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint2 none = make_uint2(0u, 0u);
+            // chunk k: entries -> hits, slots -> records (registers) -> stage -> evaluation; k+1's records fly under k's evaluation
+            unsigned q = part * 64u;
+            uint2 e = q + (unsigned)lane < cnt ? ent[q + lane] : none;
+            bool hit = (e.y & mybits) != 0u, needs = BOUNDED && (e.x >> 31) != 0u;
+            float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+            if (hit) {
+                const float4 *src = rec + 2 * (size_t)(e.x & 0x7fffffffu);
+                ra = src[0];
+                rb = src[1];
+            }
+            unsigned nq = q + 64u * PARTS;
+            uint2 ne = nq + (unsigned)lane < cnt ? ent[nq + lane] : none;
+            while (q < cnt) {
+                const unsigned long long m0 = __ballot(hit && !needs), m1 = __ballot(hit && needs);
+                const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
+                __builtin_amdgcn_wave_barrier();
+                if (hit) {
+                    const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
+                    stage[2 * slot] = ra;
+                    stage[2 * slot + 1] = rb;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // next chunk: hits and their record loads, then the entries of the one after
+                q = nq;
+                e = ne;
+                hit = (e.y & mybits) != 0u;
+                needs = BOUNDED && (e.x >> 31) != 0u;
+                if (hit) {
+                    const float4 *src = rec + 2 * (size_t)(e.x & 0x7fffffffu);
+                    ra = src[0];
+                    rb = src[1];
+                }
+                nq = q + 64u * PARTS;
+                ne = nq + (unsigned)lane < cnt ? ent[nq + lane] : none;
+                fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
+                if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
+            }
+            // the large class (half-extent > 128 px) is in nobody's list
+            const unsigned nlarge = V.cell_start[P.ncells + 1] - V.cell_start[P.ncells];
+            if (__builtin_amdgcn_readfirstlane((int)nlarge) != 0)
+                fwd_tile<BOUNDED, true>(P, V, sx0, by0, lane, part, (unsigned)PARTS, stage, ar, ag, ab);
+        }
+    }
+    if (PARTS > 1) {
+        if (wv >= 4) {
+            float (*o)[64] = s_part[sub];
+            o[0][lane] = ar.x; o[1][lane] = ar.y; o[2][lane] = ag.x; o[3][lane] = ag.y; o[4][lane] = ab.x; o[5][lane] = ab.y;
+        }
+        __syncthreads();
+        if (wv >= 4) return;
+        float (*o)[64] = s_part[sub];
+        ar.x += o[0][lane]; ar.y += o[1][lane]; ag.x += o[2][lane]; ag.y += o[3][lane]; ab.x += o[4][lane]; ab.y += o[5][lane];
+    }
+    if (sx0 < P.w) fwd_store(P, V, img, sx0, by0, lane, ar, ag, ab);
+}
+
+// The wide forward from tile lists: 32 x 32-px list tiles = the 2 x 2 sub-tiles of 16 x 16 px of k_render_fwd16's workgroup.
+// A wave's hits are the entries whose quadrant mask meets the four quadrants of its sub-tile; the row-pair classes of
+// k_render_fwd16 (window reaches both halves of the sub-tile / the upper eight rows only / the lower eight only) come from the
+// same mask.  An overflowed tile falls back to a one-level search over the tile's cells with the wide evaluation.
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_fwd16_list(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+{
+    const unsigned tt = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float4 s_stage[4][128];
+    float4 *stage = s_stage[wv];
+    const int bx0 = (int)(tt % (unsigned)tiles_x) * 2 * WIDE, by0 = P.row0 + (int)(tt / (unsigned)tiles_x) * 2 * WIDE;
+    const int sx0 = bx0 + (wv & 1) * WIDE, sy0 = by0 + (wv >> 1) * WIDE;
+    if (!(sx0 < P.w && sy0 < P.row1)) return;                     // wave-uniform; no barriers below
+    const int sx1 = min(sx0 + WIDE - 1, P.w - 1), sy1 = min(sy0 + WIDE - 1, P.row1 - 1);
+    const int X = sx0 + (lane & 15), Y = sy0 + (lane >> 4);
+    const float px = V.px[min(X, P.w - 1)];
+    const v2f pyA = {V.py[min(Y, P.h - 1)], V.py[min(Y + 4, P.h - 1)]};
+    const v2f pyB = {V.py[min(Y + 8, P.h - 1)], V.py[min(Y + 12, P.h - 1)]};
+    const float4 *__restrict__ rec = V.rec;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    v2f acc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = (v2f){0.f, 0.f};
+
+    // stage the hits of one chunk sorted by row-pair class (cls 0 both, 1 upper rows only, 2 lower rows only, 3 dmax-tested,
+    // 4 none) and evaluate them
+    auto stage_eval = [&](int cls, const float4 ra, const float4 rb) {
+        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+        const unsigned long long m3 = BOUNDED ? __ballot(cls == 3) : 0ull;
+        const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1), n2 = __builtin_popcountll(m2);
+        const int n3 = __builtin_popcountll(m3);
+        if (n0 + n1 + n2 + n3 == 0) return;
+        __builtin_amdgcn_wave_barrier();
+        if (cls < 4) {
+            const unsigned long long mine = cls == 0 ? m0 : cls == 1 ? m1 : cls == 2 ? m2 : m3;
+            const int base = cls == 0 ? 0 : cls == 1 ? n0 : cls == 2 ? n0 + n1 : n0 + n1 + n2;
+            const int slot = base + __builtin_popcountll(mine & below);
+            stage[2 * slot] = ra;
+            stage[2 * slot + 1] = rb;
+        }
+        __builtin_amdgcn_wave_barrier();
+        fwd_eval_lds16<false, 3>(stage, 0, n0, px, pyA, pyB, P.dmax, acc);
+        fwd_eval_lds16<false, 1>(stage, n0, n0 + n1, px, pyA, pyB, P.dmax, acc);
+        fwd_eval_lds16<false, 2>(stage, n0 + n1, n0 + n1 + n2, px, pyA, pyB, P.dmax, acc);
+        if (BOUNDED) fwd_eval_lds16<true, 3>(stage, n0 + n1 + n2, n0 + n1 + n2 + n3, px, pyA, pyB, P.dmax, acc);
+    };
+    // one-level search of this sub-tile over candidate segments (the large class; every class when the tile's list overflowed)
+    auto search = [&](bool large_only) {
+        const uint4 *__restrict__ bbox = V.bbox;
+        const unsigned *__restrict__ cs = V.cell_start;
+        const int wtx = sx0 >> SUBX_SHIFT, wty = (sy0 - P.row0) >> SUBY_SHIFT;
+        const int rx = large_only ? 0 : (int)V.hdr[8], ry = large_only ? 0 : (int)V.hdr[9];
+        int nseg = 0;
+        unsigned sbeg = 0, send = 0;
+        if (rx > 0) {
+            const int cx0 = max(sx0 - rx, 0) >> CELL_SHIFT, cx1 = min((sx1 + rx) >> CELL_SHIFT, P.ncx - 1);
+            const int cy0 = max(sy0 - ry, 0) >> CELL_SHIFT, cy1 = min((sy1 + ry) >> CELL_SHIFT, P.ncy - 1);
+            nseg = cy1 - cy0 + 1;
+            if (lane < nseg) {
+                sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+                send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
+            }
+        }
+        if (lane == nseg) {
+            sbeg = cs[P.ncells];
+            send = cs[P.ncells + 1];
+        }
+        ++nseg;
+        const unsigned len = send - sbeg;
+        unsigned pin = len;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = (unsigned)__shfl_up((int)pin, o);
+            if (lane >= o) pin += v;
+        }
+        const unsigned pex = pin - len;
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+        const unsigned nchunks = (total + 63u) >> 6;
+        int rseg = 0;
+        for (unsigned c = 0; c < nchunks; ++c) {
+            const unsigned j = fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin);
+            uint4 bb = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);
+            uint2 bs = make_uint2(0u, 0u);
+            if (j != 0xffffffffu) {
+                bb = bbox[2 * (size_t)j];
+                bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)j + 1);
+            }
+            const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+            const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+            bool hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
+            if (bb.y & 0x8000u) {
+                const unsigned t = (unsigned)(wty - ((r0 - P.row0) >> SUBY_SHIFT)) & 7u, sh = (t & 3u) * 8u;
+                const unsigned lo = t < 4u ? bb.z : bs.x, hi = t < 4u ? bb.w : bs.y;
+                const int txr = wtx - (c0 >> SUBX_SHIFT);
+                hit &= (txr + 1 >= (int)((lo >> sh) & 0xffu)) & (txr <= (int)((hi >> sh) & 0xffu));
+            }
+            const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
+            const int cls = !hit ? 4 : needs ? 3 : r1 < sy0 + 8 ? 1 : r0 >= sy0 + 8 ? 2 : 0;
+            float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+            if (hit) {
+                ra = rec[2 * (size_t)j];
+                rb = rec[2 * (size_t)j + 1];
+            }
+            stage_eval(cls, ra, rb);
+        }
+    };
+
+    const unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)V.tl_cursor[(size_t)tt * TL_STRIDE]);
+    if (cnt > (unsigned)P.tl_cap) {
+        search(false);
+    } else {
+        const uint2 *__restrict__ ent = V.tl_entries + (size_t)tt * (size_t)P.tl_cap;
+        // the sub-tile's quadrants: columns 2 sx, 2 sx + 1 of quadrant rows 2 sy (upper eight pixel rows) and 2 sy + 1 (lower)
+        const unsigned up = 0x3u << (2 * (wv & 1) + 8 * (wv >> 1)), lo = up << 4;
+        const uint2 none = make_uint2(0u, 0u);
+        auto classify = [&](const uint2 e) {
+            const bool u = (e.y & up) != 0u, l = (e.y & lo) != 0u;
+            return !(u || l) ? 4 : (BOUNDED && (e.x >> 31)) ? 3 : !l ? 1 : !u ? 2 : 0;
+        };
+        unsigned q = 0;
+        uint2 e = (unsigned)lane < cnt ? ent[lane] : none;
+        int cls = classify(e);
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+        if (cls < 4) {
+            const float4 *src = rec + 2 * (size_t)(e.x & 0x7fffffffu);
+            ra = src[0];
+            rb = src[1];
+        }
+        uint2 ne = 64u + (unsigned)lane < cnt ? ent[64 + lane] : none;
+        while (q < cnt) {
+            // (the next chunk's records are requested before this chunk is evaluated)
+            const int ncls = classify(ne);
+            float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+            if (ncls < 4) {
+                const float4 *src = rec + 2 * (size_t)(ne.x & 0x7fffffffu);
+                na = src[0];
+                nb = src[1];
+            }
+            q += 64u;
+            const uint2 nne = q + 64u + (unsigned)lane < cnt ? ent[q + 64u + lane] : none;
+            stage_eval(cls, ra, rb);
+            cls = ncls; ra = na; rb = nb; ne = nne;
+        }
+        const unsigned nlarge = V.cell_start[P.ncells + 1] - V.cell_start[P.ncells];
+        if (__builtin_amdgcn_readfirstlane((int)nlarge) != 0) search(true);
+    }
+    if (X < P.w) {
         fwd_store_px(P, img, X, Y, acc[0].x, acc[1].x, acc[2].x);
         fwd_store_px(P, img, X, Y + 4, acc[0].y, acc[1].y, acc[2].y);
         fwd_store_px(P, img, X, Y + 8, acc[3].x, acc[4].x, acc[5].x);
@@ -3799,9 +4047,12 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     if (fwd_wants_wide(dims)) {
         const int wx = (dims->w + 2 * WIDE - 1) / (2 * WIDE), wy = (rows + 2 * WIDE - 1) / (2 * WIDE);
         const dim3 grid((unsigned)wx * (unsigned)wy), block(256);
-        if (P.bounded) hipLaunchKernelGGL(k_render_fwd16<true>, grid, block, 0, st, P, V, img, wx);
+        if (L.tl_ok && L.tl_hlog == 5) {    // the plan's tile lists (32 x 32-px tiles)
+            if (P.bounded) hipLaunchKernelGGL(k_render_fwd16_list<true>, grid, block, 0, st, P, V, img, wx);
+            else hipLaunchKernelGGL(k_render_fwd16_list<false>, grid, block, 0, st, P, V, img, wx);
+        } else if (P.bounded) hipLaunchKernelGGL(k_render_fwd16<true>, grid, block, 0, st, P, V, img, wx);
         else hipLaunchKernelGGL(k_render_fwd16<false>, grid, block, 0, st, P, V, img, wx);
-    } else if (nsub < 4096) {
+    } else if (nsub < 4096 && !(L.tl_ok && L.tl_hlog == 4)) {
         // fewer sub-tiles than half the chip's 8192 wave slots: split each sub-tile's Gaussian list over
         // 2..16 waves so that about one full set of waves is in flight
         int nw = 2;
@@ -3811,6 +4062,18 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
             hipLaunchKernelGGL(k_render_fwd_split<true>, grid, block, 0, st, P, V, img, subs_x);
         else
             hipLaunchKernelGGL(k_render_fwd_split<false>, grid, block, 0, st, P, V, img, subs_x);
+    } else if (L.tl_ok && L.tl_hlog == 4) {
+        // the plan's tile lists (32 x 16-px tiles: the same workgroup tile as the two-level walk, and its two shapes)
+        const int tx4 = (subs_x + 3) / 4;
+        const bool two = nsub < 8192;
+        const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
+        if (P.bounded) {
+            if (two) hipLaunchKernelGGL((k_render_fwd_list<true, 2>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd_list<true, 1>), grid, block, 0, st, P, V, img, tx4);
+        } else {
+            if (two) hipLaunchKernelGGL((k_render_fwd_list<false, 2>), grid, block, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL((k_render_fwd_list<false, 1>), grid, block, 0, st, P, V, img, tx4);
+        }
     } else {
         // two-level walk; images with fewer sub-tiles than the chip has wave slots (4096..8191, e.g. the batched canvas
         // of config 5) get two waves per sub-tile (measured -13% at 4608 sub-tiles, +2..14% above 8192)

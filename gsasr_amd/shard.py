@@ -72,6 +72,15 @@ class HipBackend:
         return slab, plan
 
     @staticmethod
+    def forward_packed_into(records, slab, h, w, dmax, rows, cutoff=0.0, flags=0, accumulate=False):
+        """plan `records` and render them INTO `slab` (stored, or added to what is there): the two-render form of the band
+        exchange (`BandExchange(overlap=True)`: own Gaussians first, the halos on top once they have arrived)"""
+        from . import _cabi
+        plan = _cabi.plan_packed(records, h, w, dmax, rows=rows, cutoff=cutoff, flags=flags)
+        _cabi.forward(plan, slab, overwrite=not accumulate)
+        return plan
+
+    @staticmethod
     def backward_packed(state, records, grad_slab, g_records):
         from . import _cabi
         _cabi.backward_packed(state, records, grad_slab.contiguous(), g_records, overwrite=True)
@@ -319,8 +328,15 @@ class BandExchange:
 
     def __init__(self, n_local: int, cap: int, h: int, w: int, dmax: Optional[float], cutoff: float = 0.0,
                  device=None, group=None, backend=None, rank: Optional[int] = None, world: Optional[int] = None,
-                 transport: str = "alltoall"):
+                 transport: str = "alltoall", overlap: bool = False):
         self.group, self.backend = group, backend or HipBackend
+        # overlap = True: TWO renders per band instead of one plan over [own | halos] -- the own Gaussians are planned and
+        # splatted while the halos travel, the (at most 2 cap) halo records are planned when they have landed and added on
+        # top; in the backward the halo part runs first and its gradients fly home under the own part.  One more (small)
+        # plan per direction against an exchange that no kernel waits for.
+        self.overlap = bool(overlap)
+        if self.overlap and not hasattr(self.backend, "forward_packed_into"):
+            raise ValueError("BandExchange(overlap=True) needs a backend with forward_packed_into")
         # how the two neighbour swaps of a step are issued: "alltoall" = ONE `all_to_all_single` with split sizes that are
         # zero for every rank but g-1 / g+1 (RCCL turns it into the same grouped send/recv pairs, but the host pays for one
         # collective call instead of four P2P ops and a coalescing context -- the exchange sits between kernels of tens of
@@ -380,10 +396,12 @@ class BandExchange:
                            self.counts)
         return self.g_records[: self.n]
 
-    def _swap(self, key, to_above, from_above, to_below, from_below):
+    def _swap(self, key, to_above, from_above, to_below, from_below, async_op=False):
+        """one neighbour swap; async_op: returns the handles to `_wait` on (the transfer then runs beside whatever the
+        caller enqueues next: RCCL orders it behind the work already on the stream and `wait` makes the stream wait)"""
         if self.transport == "alltoall":
             if self.world <= 1:
-                return
+                return []
             hit = self._a2a.get(key) if hasattr(self, "_a2a") else None
             if hit is None:
                 c, n = self.cap, self.n
@@ -398,8 +416,8 @@ class BandExchange:
                 if not hasattr(self, "_a2a"):
                     self._a2a = {}
                 hit = self._a2a[key] = (out[lo:hi], inp[lo:hi], splits)
-            dist.all_to_all_single(hit[0], hit[1], hit[2], hit[2], group=self.group)
-            return
+            w = dist.all_to_all_single(hit[0], hit[1], hit[2], hit[2], group=self.group, async_op=async_op)
+            return [w] if async_op else []
         # the four P2POps of a direction always name the same buffers and peers: built once (this runs twice per step
         # on the host, in front of kernels that take tens of microseconds)
         ops = self._ops.get(key) if hasattr(self, "_ops") else None
@@ -414,9 +432,17 @@ class BandExchange:
             if not hasattr(self, "_ops"):
                 self._ops = {}
             self._ops[key] = ops
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if async_op:
+            return reqs
+        for r in reqs:
+            r.wait()
+        return []
+
+    @staticmethod
+    def _wait(handles) -> None:
+        for h in handles or []:
+            h.wait()
 
     def _peer(self, group_rank: int) -> int:
         return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
@@ -461,6 +487,48 @@ def _poison_if(flag: torch.Tensor, t: torch.Tensor) -> None:
     first.copy_(torch.where(flag, torch.full_like(first, float("nan")), first))
 
 
+class _BandLocalSplatOverlap(Function):
+    """`splat_band_local` with the exchange hidden behind the own Gaussians' render (BandExchange(overlap=True))"""
+
+    @staticmethod
+    def forward(ctx, packed_local, ex):
+        if packed_local.data_ptr() != ex.own.data_ptr():
+            ex.own.copy_(packed_local)
+        ex.version = getattr(ex, "version", 0) + 1
+        n, be = ex.n, ex.backend
+        ex.select()
+        flying = ex._swap("fwd", ex.send_up, ex.from_above, ex.send_down, ex.from_below, async_op=True)
+        slab = torch.empty(ex.rows[1] - ex.rows[0], ex.w, 3, device=ex.records.device, dtype=torch.float32)
+        # own part under the transfer (windows from the data-derived cutoff below the exchange's conservative tau) ...
+        own = be.forward_packed_into(ex.records[:n], slab, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff, ex.plan_flags, False)
+        ex._wait(flying)
+        # ... the halos on top (a few thousand records: the conservative tau as given)
+        halo = be.forward_packed_into(ex.records[n:], slab, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff, 0, True)
+        ctx.ex, ctx.own, ctx.halo, ctx.version = ex, own, halo, ex.version
+        if slab.numel():
+            _poison_if(ex.incomplete(), slab)
+        return slab
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_slab):
+        ex = ctx.ex
+        if ex.version != ctx.version:
+            raise RuntimeError("BandExchange was used by another splat_band_local forward before this backward ran; "
+                               "use one BandExchange per forward that is in flight (e.g. per accumulation micro-step)")
+        n, c, be = ex.n, ex.cap, ex.backend
+        grad_slab = grad_slab.contiguous()
+        # the halo part first: its gradients travel home while the own part is differentiated
+        be.backward_packed(ctx.halo, ex.records[n:], grad_slab, ex.g_records[n:])
+        flying = ex._swap("bwd", ex.g_records[n:n + c], ex.ret_up, ex.g_records[n + c:], ex.ret_down, async_op=True)
+        be.backward_packed(ctx.own, ex.records[:n], grad_slab, ex.g_records[:n])
+        ex._wait(flying)
+        g = ex.merge().clone()
+        if g.numel():
+            _poison_if(ex.incomplete(), g)
+        return g, None
+
+
 class _BandLocalSplat(Function):
     @staticmethod
     def forward(ctx, packed_local, ex):
@@ -495,4 +563,4 @@ def splat_band_local(packed_local: torch.Tensor, ex: BandExchange) -> torch.Tens
     """Render this rank's row band from the Gaussians it produced (`[n_local,8]` records) plus the
     neighbours' halos; differentiable w.r.t. `packed_local`, whose gradient includes what the
     neighbouring bands contribute.  Returns `[r1-r0, w, 3]`."""
-    return _BandLocalSplat.apply(packed_local, ex)
+    return (_BandLocalSplatOverlap if ex.overlap else _BandLocalSplat).apply(packed_local, ex)

@@ -44,7 +44,7 @@ extern "C" {
 #define GSASR_API
 #endif
 
-#define GSASR_SPLAT_ABI_VERSION 4 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags; 4: the _sm step entry points, step_size = NULL in the step backwards */
+#define GSASR_SPLAT_ABI_VERSION 5 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags; 4: the _sm step entry points, step_size = NULL in the step backwards; 5: gsasr_dims.list_cap (tile lists) */
 
 enum gsasr_status {
     GSASR_OK = 0,
@@ -125,6 +125,13 @@ typedef struct gsasr_dims {
     const int *sample_hw; /* HOST array [2*batch]: (h_b, w_b) per sample, read during the call */
     int grad_rows;        /* batched canvas + GSASR_FLAG_CHW_GRAD: rows per plane of grad_img [B, 3, grad_rows, w]
                              (>= every h_b; 0 = slot), so that the [B,3,Hmax,Wmax] gradient autograd returns is read in place */
+    int list_cap;         /* tile lists (ABI 5): the plan appends every Gaussian of the normal class to the hit list of each
+                             32 x 16-px (wide forward: 32 x 32) tile its ellipse reaches, and the forward renders from those
+                             lists instead of searching the cells around each tile.  Entries per tile: 0 = the library's
+                             estimate from the Gaussian density (four times what GSASR-shaped Gaussians fill), > 0 = this
+                             many (rounded up to 64), < 0 = no lists (the search kernels of rounds 1-4).  A tile whose list
+                             overflows is rendered by the search: same image, only slower.  Part of the workspace layout:
+                             pass the same value to every call on a plan */
 } gsasr_dims;
 
 #define GSASR_MAX_BATCH 64

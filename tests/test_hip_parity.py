@@ -667,6 +667,30 @@ def test_band_exchange_emulated_on_one_gpu(world, dev):
         want = gfull[ex.lr[0]: ex.lr[1]]
         for cols in (slice(0, 3), slice(3, 5), slice(5, 8)):
             assert float((g[:, cols] - want[:, cols]).abs().max()) <= 2e-4 * float(gfull[:, cols].abs().max())
+    # The two-render form (BandExchange(overlap=True): what _BandLocalSplatOverlap enqueues): the own Gaussians planned and
+    # stored, the halo records planned separately and ADDED on top; backward halo part first, then the own part.
+    be = shard.HipBackend
+    for ex in exs:
+        n = ex.n
+        ex.g_records.fill_(float("nan"))
+        slab = torch.full((ex.rows[1] - ex.rows[0], W, 3), float("nan"), device=dev)
+        own = be.forward_packed_into(ex.records[:n], slab, H, W, dmax, ex.rows, ex.cutoff, ex.plan_flags, False)
+        halo = be.forward_packed_into(ex.records[n:], slab, H, W, dmax, ex.rows, ex.cutoff, 0, True)
+        assert float((slab - full[ex.rows[0]: ex.rows[1]]).abs().max()) <= 1e-5
+        gs = wgt[ex.rows[0]: ex.rows[1]].contiguous()
+        be.backward_packed(halo, ex.records[n:], gs, ex.g_records[n:])
+        be.backward_packed(own, ex.records[:n], gs, ex.g_records[:n])
+    for r, ex in enumerate(exs):
+        c = ex.cap
+        if r > 0:
+            ex.ret_up.copy_(exs[r - 1].g_records[exs[r - 1].n + c:])
+        if r < world - 1:
+            ex.ret_down.copy_(exs[r + 1].g_records[exs[r + 1].n: exs[r + 1].n + c])
+    for ex in exs:
+        g = ex.merge()
+        want = gfull[ex.lr[0]: ex.lr[1]]
+        for cols in (slice(0, 3), slice(3, 5), slice(5, 8)):
+            assert float((g[:, cols] - want[:, cols]).abs().max()) <= 2e-4 * float(gfull[:, cols].abs().max())
 
 
 def test_band_select_flags_overflow_and_far(dev):

@@ -206,6 +206,12 @@ class OraclePackedBackend(OracleBackend):
         return slab, (h, w, dmax, rows, live)
 
     @classmethod
+    def forward_packed_into(cls, records, slab, h, w, dmax, rows, cutoff=0.0, flags=0, accumulate=False):
+        part, state = cls.forward_packed(records, h, w, dmax, rows, cutoff)
+        slab.copy_(slab + part if accumulate else part)
+        return state
+
+    @classmethod
     def backward_packed(cls, state, records, grad_slab, g_records):
         h, w, dmax, rows, live = state
         s, c, k = shard.unpack(records[live])
@@ -243,7 +249,7 @@ class OraclePackedBackend(OracleBackend):
 H_LR, W_LR, SCALE, DMAX_X = 12, 10, 3.0, 0.2
 
 
-def _exchange_worker(rank, world, port, cap, out, transport="alltoall"):
+def _exchange_worker(rank, world, port, cap, out, transport="alltoall", overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -251,7 +257,7 @@ def _exchange_worker(rank, world, port, cap, out, transport="alltoall"):
         sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
         lr0, lr1 = shard.row_band(H_LR, rank, world)           # this rank "decodes" its own LR rows
         mine = shard.pack(sig, xy, col)[lr0 * W_LR: lr1 * W_LR]
-        ex = shard.BandExchange(mine.shape[0], cap, H, W, DMAX_X, backend=OraclePackedBackend, transport=transport)
+        ex = shard.BandExchange(mine.shape[0], cap, H, W, DMAX_X, backend=OraclePackedBackend, transport=transport, overlap=overlap)
         p = mine.clone().requires_grad_(True)
         slab = shard.splat_band_local(p, ex)
         err = None
@@ -267,14 +273,17 @@ def _exchange_worker(rank, world, port, cap, out, transport="alltoall"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,transport", [(2, "alltoall"), (3, "alltoall"), (4, "alltoall"), (2, "p2p"), (3, "p2p")])
-def test_band_exchange_matches_single_process(world, transport):
+@pytest.mark.parametrize("world,transport,overlap", [(2, "alltoall", False), (3, "alltoall", False), (4, "alltoall", False),
+                                                     (2, "p2p", False), (3, "p2p", False),
+                                                     (2, "alltoall", True), (3, "alltoall", True), (3, "p2p", True)])
+def test_band_exchange_matches_single_process(world, transport, overlap):
     """both ways of issuing the two neighbour swaps of a step: ONE all_to_all_single whose split sizes are zero for every
-    rank but g-1 / g+1 (default), and batched isend / irecv"""
+    rank but g-1 / g+1 (default), and batched isend / irecv; overlap: the two-render form (own Gaussians rendered while the
+    halos travel, the halo render added on top; halo gradients sent home under the own part's backward)"""
     from oracle import gs_oracle
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_exchange_worker, args=(world, _free_port(), 64, out, transport), nprocs=world, join=True)
+    mp.spawn(_exchange_worker, args=(world, _free_port(), 64, out, transport, overlap), nprocs=world, join=True)
     sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
     wgt = synthetic.grad_image(H, W, 6)
     ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, DMAX_X)
