@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, pair_ceiling, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
+from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, band8_leg, pair_ceiling, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
                       exact_runs, live_hbm_traffic, flush_c_stdio, published_leg, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
 
 
@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--exchange", default="halo", choices=["halo", "broadcast"],
                     help="multi-rank data path: neighbour halo swap (default) or broadcast + reduce_scatter")
+    ap.add_argument("--overlap", action="store_true",
+                    help="halo exchange as TWO renders per band: own Gaussians under the swap, halos added on top (shard.BandExchange(overlap=True))")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even at world size 1 (self-test)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl (= RCCL over xGMI, the measured configuration) or gloo -- a functional "
@@ -240,7 +242,7 @@ def main():
                     pass
             roofline["valu"] = valu
 
-    c4_strong = c4_strong_halo = None
+    c4_strong = c4_strong_halo = c4_strong_halo_overlap = None
     if (world > 1 or args.force_dist) and args.config in ("c2", "c4") and not step.batched:
         # BASELINE config 4's own pattern -- strong-scaled 8192^2, packed broadcast + in-place reduce-scatter -- as a leg of
         # EVERY multi-rank line, whatever exchange the headline used
@@ -254,6 +256,11 @@ def main():
             c4_strong_halo = strong_c4_leg(args, dev, rank, world, exchange="halo")
         except Exception as e:
             c4_strong_halo = {"error": repr(e)}
+        # ... and with the swap hidden behind the own Gaussians' render (two renders per band)
+        try:
+            c4_strong_halo_overlap = strong_c4_leg(args, dev, rank, world, exchange="halo", overlap=True)
+        except Exception as e:
+            c4_strong_halo_overlap = {"error": repr(e)}
     if world > 1:      # every rank's C-stdio output (RCCL banner) is out before rank 0 prints the line
         import torch.distributed as dist
         flush_c_stdio()
@@ -320,6 +327,12 @@ def main():
                 out["configs"]["c5e2e"] = run_c5e2e(a5, dev, 0, 1, as_leg=True)
             except Exception as e:
                 out["configs"]["c5e2e"] = {"error": repr(e)}
+            # one of eight ranks' share of config 4, alone on this GPU: the strong-scaling ceiling before hardware exists
+            try:
+                t_full = out["configs"].get("c4", {}).get("ms_per_step")
+                out["c4_band8"] = band8_leg(args, dev, t_full)
+            except Exception as e:
+                out["c4_band8"] = {"error": repr(e)}
             # the reference's one published measurement of this path (utils/gs_cuda/profile.py:104-113, profile.log:44)
             try:
                 out["published"] = published_leg(args, dev)
@@ -329,6 +342,8 @@ def main():
             out["c4_strong"] = c4_strong
         if c4_strong_halo is not None:
             out["c4_strong_halo"] = c4_strong_halo
+        if c4_strong_halo_overlap is not None:
+            out["c4_strong_halo_overlap"] = c4_strong_halo_overlap
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         emit(out)

@@ -357,11 +357,23 @@ int lists_env()
     return v;
 }
 
+// dense plan: at least one Gaussian per four pixels of the rows rendered (GSASR's 16 per LR pixel at x4 and below).  The 64
+// Gaussians of a k_bin wave then share a handful of tiles, so their cursor atomics aggregate (tl_emit) and the lists cost less
+// than the search they replace: 16 Gaussians per LR pixel at 1024^2 -5.8% per step, the config-5 canvas -5.2%.  At one
+// Gaussian per LR pixel the atomics outweigh the search: config 2 +5%, config 3 +20% (profiles/r05_lists_ab.txt).
+bool tl_dense(const gsasr_dims *d)
+{
+    const double rows = (double)(d->row1 - d->row0 > 0 ? d->row1 - d->row0 : 1);
+    return 4.0 * (double)d->s >= (double)d->w * rows;
+}
+
 // log2 of the list tiles' height for a plan of these dims: 5 where the forward will be the wide kernel (32 x 32-px tiles),
 // 4 for the two-level 8 x 16 kernels (32 x 16), 0 = no lists (small images: the split kernel; list_cap < 0; no Gaussians)
 int tl_hlog_for(const gsasr_dims *d)
 {
     if (d->list_cap < 0 || d->s <= 0 || lists_env() == 0) return 0;
+    // by default for dense plans only (tl_dense); an explicit capacity (or the development switch) asks for them anywhere
+    if (d->list_cap == 0 && lists_env() != 1 && !tl_dense(d)) return 0;
     const int rows = d->row1 - d->row0;
     if (fwd_wants_wide(d)) return 5;
     const long nsub = (long)((d->w + SUBX - 1) / SUBX) * ((rows + SUBY - 1) / SUBY);
@@ -1172,6 +1184,8 @@ __device__ __forceinline__ unsigned tl_mask(int tx, int ty, const uint4 bb, cons
 // The cursors are bumped with ONE returning atomic per (wave, round slot, distinct tile), all of a slot's issued in one
 // instruction (cf. k_classify's ranks): raster-ordered decoder output puts the 64 Gaussians of a wave into a handful of tiles,
 // and atomics on one word -- on one cache LINE -- serialise at ~12 ns each whichever wave they come from.
+// (Measured and dropped, profiles/r05_lists_ab.txt run r05d: per-lane atomics without the match-any loops, six tiles per round --
+// config 2's k_bin +10.5 us instead of +6, config 4's plan +165 us instead of +81: the atomics, not the loops, are what costs.)
 constexpr int TLB = 4;
 
 template <int HLOG>
@@ -1230,6 +1244,7 @@ __device__ __forceinline__ void tl_emit(const Params &P, const PlanView &V, bool
 constexpr int FUSED_PER_THREAD = 17, FUSED_CELLS = 256 * FUSED_PER_THREAD;
 static_assert(FUSED_CELLS == FUSED_CELLS_HOST, "make_params decides with FUSED_CELLS_HOST which plans run a scan kernel");
 
+// TLH: the plan's tile lists -- 0 none, else log2 of the tile height (4 / 5)
 template <bool FUSED_SCAN, int TLH>
 __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__ sigmas,
                                              const float *__restrict__ coords,
@@ -1671,6 +1686,106 @@ __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int 
     if (i < end) fwd_eval_one<TEST>(st[2 * i], st[2 * i + 1], px, py, dmax, ar, ag, ab);
 }
 
+// RECORD-PAIR evaluation (round 5).  fwd_eval_one packs the two PIXELS of a lane: of its instructions per record the four
+// that depend on the column alone (dx, U, -U^2, NR U) have nothing to pack with.  Packed over two RECORDS instead -- the stage
+// holds pairs interleaved {x0,x1, y0,y1, IX0,IX1, NR0,NR1 | IY0,IY1, r0,r1, g0,g1, b0,b1} -- every instruction is packed:
+// 4 (column) + 2 rows x 6 = 16 packed + 4 v_exp_f32 per record PAIR and 128 pixels = 96 cycles against 2 x 64.  The sums of
+// the even and the odd records of a list are kept apart (two accumulators per channel and row) and added at the end; a list
+// of odd length ends in a zero record (colour 0).
+#ifndef FWD_PAIR
+#define FWD_PAIR 1
+#endif
+constexpr int STAGE_F4 = 136;    // float4 per wave's stage: 64 records + a zero record behind each of the two lists (pairs)
+
+__device__ __forceinline__ void stage_put_pair(float4 *stage, int slot, const float4 a, const float4 b)
+{
+    float *p = reinterpret_cast<float *>(stage) + (slot >> 1) * 16 + (slot & 1);
+    p[0] = a.x; p[2] = a.y; p[4] = a.z; p[6] = a.w; p[8] = b.x; p[10] = b.y; p[12] = b.z; p[14] = b.w;
+}
+
+template <bool TEST>
+__device__ __forceinline__ void fwd_eval_pair(const float4 q0, const float4 q1, const float4 q2, const float4 q3, float px, v2f py,
+                                              float dmax, v2f (&acc)[6])
+{
+    // q0 = {x0,x1,y0,y1}, q1 = {IX0,IX1,NR0,NR1}, q2 = {IY0,IY1,r0,r1}, q3 = {g0,g1,b0,b1}; acc = {rA, gA, bA, rB, gB, bB} (row A / B)
+    const v2f x = {q0.x, q0.y}, y = {q0.z, q0.w}, ix = {q1.x, q1.y}, nr = {q1.z, q1.w}, iy = {q2.x, q2.y};
+    const v2f cr = {q2.z, q2.w}, cg = {q3.x, q3.y}, cb = {q3.z, q3.w};
+    const v2f dx = px - x;
+    const v2f u = ix * dx;
+    const v2f k0 = -u * u, ru = nr * u;
+    const v2f dyA = py.x - y, dyB = py.y - y;
+    const v2f bqA = iy * dyA + ru, bqB = iy * dyB + ru;
+    const v2f pwA = k0 - bqA * bqA, pwB = k0 - bqB * bqB;
+    v2f vA = {__builtin_amdgcn_exp2f(pwA.x), __builtin_amdgcn_exp2f(pwA.y)};
+    v2f vB = {__builtin_amdgcn_exp2f(pwB.x), __builtin_amdgcn_exp2f(pwB.y)};
+    if (TEST) {
+        const bool in0 = fabsf(dx.x) <= dmax, in1 = fabsf(dx.y) <= dmax;
+        vA.x = (in0 && fabsf(dyA.x) <= dmax) ? vA.x : 0.f;
+        vA.y = (in1 && fabsf(dyA.y) <= dmax) ? vA.y : 0.f;
+        vB.x = (in0 && fabsf(dyB.x) <= dmax) ? vB.x : 0.f;
+        vB.y = (in1 && fabsf(dyB.y) <= dmax) ? vB.y : 0.f;
+    }
+    acc[0] += vA * cr; acc[1] += vA * cg; acc[2] += vA * cb;
+    acc[3] += vB * cr; acc[4] += vB * cg; acc[5] += vB * cb;
+}
+
+// pairs [beg, end) of the stage
+template <bool TEST>
+__device__ __forceinline__ void fwd_eval_lds_pairs(const float4 *__restrict__ st, int beg, int end, float px, v2f py, float dmax,
+                                                   v2f (&acc)[6])
+{
+    int i = beg;
+    for (; i + 1 < end; i += 2) {   // two pairs per iteration so their dependent chains interleave
+        const float4 a0 = st[4 * i], a1 = st[4 * i + 1], a2 = st[4 * i + 2], a3 = st[4 * i + 3];
+        const float4 b0 = st[4 * i + 4], b1 = st[4 * i + 5], b2 = st[4 * i + 6], b3 = st[4 * i + 7];
+        fwd_eval_pair<TEST>(a0, a1, a2, a3, px, py, dmax, acc);
+        fwd_eval_pair<TEST>(b0, b1, b2, b3, px, py, dmax, acc);
+    }
+    if (i < end) fwd_eval_pair<TEST>(st[4 * i], st[4 * i + 1], st[4 * i + 2], st[4 * i + 3], px, py, dmax, acc);
+}
+
+// One chunk of a wave's walk: compact the hits' records (ra, rb of the hit lanes; those that need the dmax test behind the
+// others) into the wave's LDS stage and evaluate them on the lane's two pixels from broadcast LDS reads.
+template <bool BOUNDED>
+__device__ __forceinline__ void fwd_stage_eval(float4 *stage, bool hit, bool needs, const float4 ra, const float4 rb, int lane, float px,
+                                               v2f py, float dmax, v2f &ar, v2f &ag, v2f &ab)
+{
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long m0 = __ballot(hit && !needs), m1 = BOUNDED ? __ballot(hit && needs) : 0ull;
+    const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
+    if (n0 + n1 == 0) return;
+#if FWD_PAIR
+    const int b1 = (n0 + 1) & ~1;     // first slot of the tested list (the lists are padded to whole pairs)
+    __builtin_amdgcn_wave_barrier();
+    if (hit) {
+        const int r = needs ? __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
+        const int slot = needs ? b1 + r : r;
+        stage_put_pair(stage, slot, ra, rb);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (((needs ? n1 : n0) & 1) && r == (needs ? n1 : n0) - 1) stage_put_pair(stage, slot + 1, z, z);   // the odd list's zero record
+    }
+    __builtin_amdgcn_wave_barrier();
+    v2f acc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = (v2f){0.f, 0.f};
+    fwd_eval_lds_pairs<false>(stage, 0, (n0 + 1) >> 1, px, py, dmax, acc);
+    if (BOUNDED) fwd_eval_lds_pairs<true>(stage, b1 >> 1, (b1 + n1 + 1) >> 1, px, py, dmax, acc);
+    ar += (v2f){acc[0].x + acc[0].y, acc[3].x + acc[3].y};
+    ag += (v2f){acc[1].x + acc[1].y, acc[4].x + acc[4].y};
+    ab += (v2f){acc[2].x + acc[2].y, acc[5].x + acc[5].y};
+#else
+    __builtin_amdgcn_wave_barrier();
+    if (hit) {
+        const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
+        stage[2 * slot] = ra;
+        stage[2 * slot + 1] = rb;
+    }
+    __builtin_amdgcn_wave_barrier();
+    fwd_eval_lds<false>(stage, 0, n0, px, py, dmax, ar, ag, ab);
+    if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, dmax, ar, ag, ab);
+#endif
+}
+
 // Candidate index of this lane in flat chunk `c` of the concatenated segments.  The segment table lives in
 // lanes (lane r: start `sbeg`, exclusive/inclusive prefix of the lengths `pex`/`pin`); `r` is the first
 // segment that reaches into the chunk (wave-uniform, advanced monotonically).  Returns 0xffffffff for
@@ -1776,21 +1891,13 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
         const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
         // Compact the hits' records into this wave's LDS stage (untested ones first), then every lane
         // evaluates all of them from broadcast LDS reads.
-        const unsigned long long m0 = __ballot(hit && !needs), m1 = __ballot(hit && needs);
-        const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
-        if (n0 + n1) {
-            __builtin_amdgcn_wave_barrier();
-            if (hit) {
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
-                const float4 *src = rec + 2 * (size_t)j;
-                stage[2 * slot] = src[0];
-                stage[2 * slot + 1] = src[1];
-            }
-            __builtin_amdgcn_wave_barrier();
-            fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
-            if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+        if (hit) {
+            const float4 *src = rec + 2 * (size_t)j;
+            ra = src[0];
+            rb = src[1];
         }
+        fwd_stage_eval<BOUNDED>(stage, hit, needs, ra, rb, lane, px, py, P.dmax, ar, ag, ab);
         c = nc; j = nj; bb = nbb; bs = nbs;
     }
 }
@@ -1916,20 +2023,13 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
                     hit &= (txr >= (int)((lo >> sh) & 0xffu)) & (txr <= (int)((hi >> sh) & 0xffu));
                 }
                 const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
-                const unsigned long long m0 = __ballot(hit && !needs), m1 = __ballot(hit && needs);
-                const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
-                if (n0 + n1) {
-                    __builtin_amdgcn_wave_barrier();
-                    if (hit) {
-                        const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
-                        const float4 *src = rec + 2 * (size_t)j;
-                        stage[2 * slot] = src[0];
-                        stage[2 * slot + 1] = src[1];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
-                    if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
+                float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+                if (hit) {
+                    const float4 *src = rec + 2 * (size_t)j;
+                    ra = src[0];
+                    rb = src[1];
                 }
+                fwd_stage_eval<BOUNDED>(stage, hit, needs, ra, rb, lane, px, py, P.dmax, ar, ag, ab);
                 j = nj; bb = nbb; bs = nbs;
             }
         }
@@ -1999,7 +2099,7 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView 
     const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ float4 s_stage[4 * PARTS][128];
+    __shared__ float4 s_stage[4 * PARTS][STAGE_F4];
     __shared__ unsigned s_list[COARSE_LIST * PARTS];
     __shared__ unsigned s_cnt[2];
     __shared__ float s_part[PARTS > 1 ? 4 : 1][6][64];
@@ -2215,13 +2315,18 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanV
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = wv & 3;
     const unsigned part = (unsigned)(wv >> 2);
-    __shared__ float4 s_stage[4 * PARTS][128];
+    __shared__ float4 s_stage[4 * PARTS][STAGE_F4];
     __shared__ float s_part[PARTS > 1 ? 4 : 1][6][64];
     float4 *stage = s_stage[wv];
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
     const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
     const int sx0 = bx0 + sub * SUBX;
     if (sx0 < P.w) {   // wave-uniform (image width not a multiple of 32)
+        // (the first 64 entries are requested together with the cursor that says how many of them are real: one dependent
+        // round trip less in a wave whose whole life is three or four of them)
+        const uint2 *__restrict__ ent = V.tl_entries + (size_t)t * (size_t)P.tl_cap;
+        const unsigned q_first = part * 64u;
+        uint2 e_first = q_first + (unsigned)lane < (unsigned)P.tl_cap ? ent[q_first + lane] : make_uint2(0u, 0u);
         const unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)V.tl_cursor[(size_t)t * TL_STRIDE]);
         if (cnt > (unsigned)P.tl_cap) {
             fwd_tile<BOUNDED, false>(P, V, sx0, by0, lane, part, (unsigned)PARTS, stage, ar, ag, ab);
@@ -2230,14 +2335,12 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanV
             const float px = V.px[(P.batch > 1 ? (by0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
             const int Y0 = by0 + (lane >> 3);
             const v2f py = {V.py[min(Y0, P.h - 1)], V.py[min(Y0 + 8, P.h - 1)]};
-            const uint2 *__restrict__ ent = V.tl_entries + (size_t)t * (size_t)P.tl_cap;
             const float4 *__restrict__ rec = V.rec;
             const unsigned mybits = 0x11u << sub;
-            const unsigned long long below = (1ull << lane) - 1ull;
             const uint2 none = make_uint2(0u, 0u);
             // chunk k: entries -> hits, slots -> records (registers) -> stage -> evaluation; k+1's records fly under k's evaluation
-            unsigned q = part * 64u;
-            uint2 e = q + (unsigned)lane < cnt ? ent[q + lane] : none;
+            unsigned q = q_first;
+            uint2 e = q + (unsigned)lane < cnt ? e_first : none;
             bool hit = (e.y & mybits) != 0u, needs = BOUNDED && (e.x >> 31) != 0u;
             float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
             if (hit) {
@@ -2248,16 +2351,10 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanV
             unsigned nq = q + 64u * PARTS;
             uint2 ne = nq + (unsigned)lane < cnt ? ent[nq + lane] : none;
             while (q < cnt) {
-                const unsigned long long m0 = __ballot(hit && !needs), m1 = __ballot(hit && needs);
-                const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
-                __builtin_amdgcn_wave_barrier();
-                if (hit) {
-                    const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
-                    stage[2 * slot] = ra;
-                    stage[2 * slot + 1] = rb;
-                }
-                __builtin_amdgcn_wave_barrier();
-                // next chunk: hits and their record loads, then the entries of the one after
+                // next chunk: hits and their record loads, then the entries of the one after -- requested before this
+                // chunk is evaluated
+                const bool chit = hit, cneeds = needs;
+                const float4 ca = ra, cb = rb;
                 q = nq;
                 e = ne;
                 hit = (e.y & mybits) != 0u;
@@ -2269,8 +2366,7 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanV
                 }
                 nq = q + 64u * PARTS;
                 ne = nq + (unsigned)lane < cnt ? ent[nq + lane] : none;
-                fwd_eval_lds<false>(stage, 0, n0, px, py, P.dmax, ar, ag, ab);
-                if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, P.dmax, ar, ag, ab);
+                fwd_stage_eval<BOUNDED>(stage, chit, cneeds, ca, cb, lane, px, py, P.dmax, ar, ag, ab);
             }
             // the large class (half-extent > 128 px) is in nobody's list
             const unsigned nlarge = V.cell_start[P.ncells + 1] - V.cell_start[P.ncells];
@@ -2453,7 +2549,7 @@ template <bool BOUNDED>
 __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V, float *__restrict__ img, int subs_x)
 {
     __shared__ float s_part[16][6][64];
-    __shared__ float4 s_stage[16][128];
+    __shared__ float4 s_stage[16][STAGE_F4];
     const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
     const int sx0 = (int)(t % (unsigned)subs_x) * SUBX, sy0 = P.row0 + (int)(t / (unsigned)subs_x) * SUBY;
     const int lane = threadIdx.x & 63;
@@ -3998,9 +4094,12 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
     static const int fused_max_blocks = dev_switch("GSASR_SPLAT_FUSED_MAX") ? atoi(dev_switch("GSASR_SPLAT_FUSED_MAX")) : FUSED_MAX_BLOCKS;
     if (ncls <= FUSED_CELLS && dims->s > 0 && (int)nbin <= fused_max_blocks) {
         // small grid, not too many blocks: k_bin rebuilds the scan per block (no separate scan launch)
-        if (P.tl_hlog == 5) hipLaunchKernelGGL((k_bin<true, 5>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
-        else if (P.tl_hlog == 4) hipLaunchKernelGGL((k_bin<true, 4>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
-        else hipLaunchKernelGGL((k_bin<true, 0>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
+#define GSASR_BIN(F) do { \
+        const int tlh = P.tl_hlog; \
+        if (tlh == 5) hipLaunchKernelGGL((k_bin<F, 5>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups); \
+        else if (tlh == 4) hipLaunchKernelGGL((k_bin<F, 4>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups); \
+        else hipLaunchKernelGGL((k_bin<F, 0>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups); } while (0)
+        GSASR_BIN(true);
     } else {
         if (ncls <= 2 * SCAN_CHUNK) {
             hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, P, ncls, V.cell_count, V.cell_start, L.ext_groups, V.blockmax,
@@ -4012,11 +4111,8 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
             hipLaunchKernelGGL(k_scan_fix, dim3(nchunks), dim3(1024), 0, st, P, ncls, V.cell_start, V.scan_tot, nchunks,
                                V.cell_count, V.hdr);
         }
-        if (dims->s > 0) {
-            if (P.tl_hlog == 5) hipLaunchKernelGGL((k_bin<false, 5>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
-            else if (P.tl_hlog == 4) hipLaunchKernelGGL((k_bin<false, 4>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
-            else hipLaunchKernelGGL((k_bin<false, 0>), dim3(nbin), dim3(256), 0, st, P, sigmas, coords, colors, V, L.ext_groups);
-        }
+        if (dims->s > 0) GSASR_BIN(false);
+#undef GSASR_BIN
     }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;

@@ -127,11 +127,13 @@ typedef struct gsasr_dims {
                              (>= every h_b; 0 = slot), so that the [B,3,Hmax,Wmax] gradient autograd returns is read in place */
     int list_cap;         /* tile lists (ABI 5): the plan appends every Gaussian of the normal class to the hit list of each
                              32 x 16-px (wide forward: 32 x 32) tile its ellipse reaches, and the forward renders from those
-                             lists instead of searching the cells around each tile.  Entries per tile: 0 = the library's
-                             estimate from the Gaussian density (four times what GSASR-shaped Gaussians fill), > 0 = this
-                             many (rounded up to 64), < 0 = no lists (the search kernels of rounds 1-4).  A tile whose list
-                             overflows is rendered by the search: same image, only slower.  Part of the workspace layout:
-                             pass the same value to every call on a plan */
+                             lists instead of searching the cells around each tile.  0 = the library decides: lists for
+                             DENSE plans (at least one Gaussian per four pixels -- GSASR's 16 per LR pixel up to x8 -- where
+                             they save ~5% of a step), sized four times what GSASR-shaped Gaussians fill, and the search
+                             kernels elsewhere (at one Gaussian per LR pixel the plan's list atomics cost more than the
+                             search); > 0 = lists with this many entries per tile (rounded up to 64) on any image; < 0 = no
+                             lists.  A tile whose list overflows is rendered by the search: same image, only slower.  Part of
+                             the workspace layout: pass the same value to every call on a plan */
 } gsasr_dims;
 
 #define GSASR_MAX_BATCH 64

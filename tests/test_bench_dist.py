@@ -49,3 +49,7 @@ def test_bench_two_ranks_functional(launcher, extra):
     assert halo["gaussians_per_rank"] == 1048576 // 2
     assert 0 < halo["rccl"]["bytes_sent_per_rank_per_step"] < 64 * 1048576 // 8
     assert halo["rccl"]["halo_records_max_per_edge"] <= halo["rccl"]["capacity"]
+    # ... and with the swap hidden behind the own Gaussians' render (BandExchange(overlap=True)'s sequence), same transport
+    ov = d["c4_strong_halo_overlap"]
+    assert "error" not in ov and "note" not in ov, ov
+    assert ov["overlap"] is True and ov["transport"] == halo["transport"] and ov["value"] > 0 and ov["rows_per_rank"] == 4096

@@ -89,11 +89,14 @@ def test_workspace_bytes_and_bad_dims_no_gpu():
     d = _cabi.make_dims(65536, 1024, 1024, 0.1, list_cap=-1)
     n = _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(d))
     assert 65536 * 120 <= n <= 65536 * 160      # 136 B/Gaussian of scratch + per-cell tables
-    # + the tile lists (default: on at this size): 2 048 tiles of 32 x 16 px, a 64-byte cursor line and `cap` 8-byte entries each
+    # the tile lists are the default for DENSE plans only (>= 1 Gaussian per 4 pixels): none at one Gaussian per 16 pixels ...
     d = _cabi.make_dims(65536, 1024, 1024, 0.1)
-    nl = _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(d))
-    cap = (nl - n - 2048 * 64) // (2048 * 8)
-    assert nl > n and 256 <= cap <= 1024 and cap % 64 == 0
+    assert _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(d)) == n
+    # ... 2 048 tiles of 32 x 16 px, a 64-byte cursor line and `cap` 8-byte entries each, at 16 Gaussians per LR pixel
+    dd = [_cabi.make_dims(1048576, 1024, 1024, 0.1, list_cap=c) for c in (-1, 0)]
+    n16, nl = (_cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(x)) for x in dd)
+    cap = (nl - n16 - 2048 * 64) // (2048 * 8)
+    assert nl > n16 and 2048 <= cap <= 8192 and cap % 64 == 0
     d = _cabi.make_dims(65536, 1024, 1024, 0.1, list_cap=100)       # explicit capacity: rounded up to 64 entries
     assert _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(d)) == n + 2048 * 64 + 2048 * 128 * 8
     bad = _cabi.make_dims(10, 1, 8, 0.1)        # h < 2: the grid 2*i/(h-1)-1 is undefined

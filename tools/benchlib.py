@@ -64,6 +64,7 @@ class Step:
         self.img = torch.zeros(nrows, W, 3, device=dev)
         self.dist = world > 1 or args.force_dist
         self.halo = self.dist and args.exchange == "halo"
+        self.overlap = bool(getattr(args, "overlap", False))
         self.ex = None
         if self.halo:
             # sharded producer: this rank holds the Gaussians of its own LR rows (raster order => one slice)
@@ -247,6 +248,26 @@ class Step:
             self.batched_forward()               # prologue + plan + forward of all 16 samples
             if not self.fwd_only:
                 self.batched_backward()          # splat backward + prologue backward
+            return
+        if self.halo and getattr(self, "overlap", False):
+            # the two-render form (shard.BandExchange(overlap=True)): own Gaussians planned and splatted while the halos
+            # travel, the halo records added on top; backward halo part first, its gradients fly home under the own part
+            ex, c = self.ex, self.cabi
+            n, H, W = ex.n, self.H, self.W
+            tile = c.FLAG_BWD_TILE if (self.strong and not self.fwd_only) else 0
+            ex.select()
+            fly = ex._swap("fwd", ex.send_up, ex.from_above, ex.send_down, ex.from_below, async_op=True)
+            po = c.plan_packed(ex.records[:n], H, W, self.dmax, rows=self.rows, cutoff=ex.cutoff, flags=tile | ex.plan_flags)
+            c.forward(po, self.img, overwrite=True)
+            ex._wait(fly)
+            ph = c.plan_packed(ex.records[n:], H, W, self.dmax, rows=self.rows, cutoff=ex.cutoff, flags=tile)
+            c.forward(ph, self.img, overwrite=False)
+            if not self.fwd_only:
+                c.backward_packed(ph, ex.records[n:], self.grad_img, ex.g_records[n:], overwrite=True)
+                fly = ex._swap("bwd", ex.g_records[n:n + ex.cap], ex.ret_up, ex.g_records[n + ex.cap:], ex.ret_down, async_op=True)
+                c.backward_packed(po, ex.records[:n], self.grad_img, ex.g_records[:n], overwrite=True)
+                ex._wait(fly)
+                ex.merge()
             return
         if self.halo:
             self.ex.exchange_forward()          # Gaussians crossing a band edge -> neighbours (P2P)
@@ -556,6 +577,73 @@ def published_leg(args, dev, calls=10):
     return out
 
 
+def band8_leg(args, dev, t_full_ms=None, world=8, rank=3):
+    """BASELINE config 4's strong scaling, priced on ONE GPU: the work of one of eight ranks (rows [3072, 4096) of the 8192^2
+    image) timed alone, three ways -- (a) sharded producer, ONE plan over [own | halos] (BandExchange); (b) the same as TWO
+    renders (BandExchange(overlap=True): own Gaussians planned and splatted while the halos would travel, the halo records
+    added on top; backward halo part first) -- the kernels the overlap form enqueues, back to back; (c) replicated set: the
+    band is handed all 1 048 576 Gaussians (broadcast + reduce-scatter pattern).  With T_full the single-GPU step of the
+    whole image, T_full / (8 T_band) is the ceiling of the 8-GPU strong-scaling efficiency before any byte moves."""
+    from gsasr_amd import _cabi, shard, synthetic
+    h_lr, w_lr, scale, _ = CONFIGS["c4"]
+    sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, w_lr, scale, seed=0, device="cpu")
+    rec = shard.pack(sig, xy, col).to(dev)
+    dmax = None if args.dmax < 0 else args.dmax
+    rows = shard.row_band(H, rank, world)
+    nrows = rows[1] - rows[0]
+    grad = synthetic.grad_image(H, W, 1)[rows[0]:rows[1]].contiguous().to(dev)
+    slab = torch.empty(nrows, W, 3, device=dev)
+    exs = {}
+    for r in (rank - 1, rank, rank + 1):
+        lr0, lr1 = shard.row_band(h_lr, r, world)
+        ex = shard.BandExchange((lr1 - lr0) * w_lr, 16384, H, W, dmax, args.cutoff, device=dev, rank=r, world=world)
+        ex.own.copy_(rec[lr0 * w_lr: lr1 * w_lr])
+        ex.select()
+        exs[r] = ex
+    ex = exs[rank]
+    n_up, n_down = ex.check()
+    ex.from_above.copy_(exs[rank - 1].send_down)
+    ex.from_below.copy_(exs[rank + 1].send_up)
+    ex.ret.zero_()
+    n, tile = ex.n, _cabi.FLAG_BWD_TILE
+
+    def one_plan():
+        ex.select()
+        p = _cabi.plan_packed(ex.records, H, W, dmax, rows=rows, cutoff=ex.cutoff, flags=tile | ex.plan_flags)
+        _cabi.forward(p, slab, overwrite=True)
+        _cabi.backward_packed(p, ex.records, grad, ex.g_records, overwrite=True)
+        ex.merge()
+
+    def two_renders():
+        ex.select()
+        po = _cabi.plan_packed(ex.records[:n], H, W, dmax, rows=rows, cutoff=ex.cutoff, flags=tile | ex.plan_flags)
+        _cabi.forward(po, slab, overwrite=True)
+        ph = _cabi.plan_packed(ex.records[n:], H, W, dmax, rows=rows, cutoff=ex.cutoff, flags=tile)
+        _cabi.forward(ph, slab, overwrite=False)
+        _cabi.backward_packed(ph, ex.records[n:], grad, ex.g_records[n:], overwrite=True)
+        _cabi.backward_packed(po, ex.records[:n], grad, ex.g_records[:n], overwrite=True)
+        ex.merge()
+
+    gall = torch.empty_like(rec)
+
+    def replicated():
+        p = _cabi.plan_packed(rec, H, W, dmax, rows=rows, cutoff=args.cutoff, flags=tile)
+        _cabi.forward(p, slab, overwrite=True)
+        _cabi.backward_packed(p, rec, grad, gall, overwrite=True)
+
+    out = {"workload": f"one of {world} row bands of config 4 (rank {rank}: HR rows [{rows[0]},{rows[1]}) of 8192^2, fwd+bwd) on this one GPU",
+           "gaussians_own": n, "halo_records": [n_up, n_down], "gaussians_image": int(rec.shape[0])}
+    for name, fn in (("sharded_one_plan", one_plan), ("sharded_two_renders_overlap_form", two_renders), ("replicated_all_gaussians", replicated)):
+        ms = wall_ms(fn, 20, dev, warm=5, warm_s=0.1)
+        out[name] = {"ms_per_step": ms, "value_if_8_ranks": H * W / (ms * 1e-3) / 1e6}
+        if t_full_ms:
+            out[name]["strong_scaling_ceiling_8"] = t_full_ms / (world * ms)
+    out["t_full_ms"] = t_full_ms
+    out["note"] = ("no byte moves here: selection, plan(s), forward, backward, merge of ONE rank; the exchange itself is "
+                   f"2 x {n_up + n_down} records of 32 B per step (sharded) or 2 x 32 MiB (replicated)")
+    return out
+
+
 def cpu_baseline(args):
     """The oracle's fp32 restatement of the reference kernels (OpenMP over the host cores) on a bounded
     sample of the SAME workload: a row band of config 2 (sized for ~10 s on this host) with all 65 536 Gaussians, forward + backward."""
@@ -787,7 +875,7 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     return out
 
 
-def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast"):
+def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast", overlap=False):
     """BASELINE config 4 on whatever group this run has: the 8192^2 image strong-scaled over the ranks' row bands.
     exchange = "broadcast": as the north star states it -- Gaussians broadcast once per step as ONE packed [N,8] buffer,
     per-Gaussian gradients reduce-scattered in place (64 MB per rank and step over xGMI whatever the band height);
@@ -797,7 +885,7 @@ def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast"):
     import copy
     import torch.distributed as dist
     a = copy.copy(args)
-    a.config, a.exchange, a.fwd_only, a.force_dist = "c4", exchange, False, True
+    a.config, a.exchange, a.fwd_only, a.force_dist, a.overlap = "c4", exchange, False, True, overlap
     st = Step(a, dev, rank, world)
 
     def barrier():
@@ -818,8 +906,8 @@ def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast"):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / steps * 1e3
-    kern = stage_times(st, dev, iters=5)
-    out = {"workload": CONFIGS["c4"][3], "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": ms,
+    kern = stage_times(st, dev, iters=5) if not (st.halo and overlap) else {}
+    out = {"workload": CONFIGS["c4"][3], "scaling": "strong", "overlap": bool(st.halo and overlap), "transport": (st.ex.transport if st.halo else "collectives"), "n_gpus": world, "steps": steps, "ms_per_step": ms,
            "value": st.H * st.W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s", "rows_per_rank": st.rows[1] - st.rows[0],
            "kernels_rank0": kern,
            "rccl": {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
