@@ -13,12 +13,15 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = os.path.join(PKG, "csrc", "gsasr_splat.hip")
+CSRC = os.path.join(PKG, "csrc")
+# the translation units of the library (csrc/gsasr_splat.hip is the same code as ONE unit: the micro-benchmark tools/mb.hip builds that)
+PARTS = ["splat_api", "splat_plan", "splat_forward", "splat_backward", "splat_step", "splat_sampled", "splat_shard"]
 INC = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libgsasr_splat.so")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-fvisibility=hidden",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-fvisibility=hidden",
                "-Wall", "-Wno-unused-function"]
 
 
@@ -29,23 +32,45 @@ def hipcc() -> str:
     return exe
 
 
+def _deps():
+    return [os.path.join(CSRC, p + ".hip") for p in PARTS] + [os.path.join(CSRC, "splat_common.h"), os.path.join(INC, "gsasr_splat.h")]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [SRC, os.path.join(INC, "gsasr_splat.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB) -> str:
+    """compile the translation units in parallel (hipcc, gfx950) and link them into one shared library"""
+    if not force and out == LIB and not needs_build():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), *HIPCC_FLAGS, "-I", INC, SRC, "-o", LIB]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = hipcc()
+    common = os.path.getmtime(os.path.join(CSRC, "splat_common.h"))
+    header = os.path.getmtime(os.path.join(INC, "gsasr_splat.h"))
+    tag = "" if out == LIB else "_" + os.path.splitext(os.path.basename(out))[0]
+
+    def one(part):
+        src, obj = os.path.join(CSRC, part + ".hip"), os.path.join(OBJ_DIR, part + tag + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), common, header):
+            return obj
+        cmd = [cc, *HIPCC_FLAGS, *extra_flags, "-I", INC, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(PARTS)) as ex:
+        objs = list(ex.map(one, PARTS))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 AUTOGRAD_SRC = os.path.join(PKG, "csrc", "gsasr_autograd.cpp")

@@ -1,0 +1,1031 @@
+// splat_backward.hip -- backward kernels (Gaussian-stationary, tile-stationary + gather) and gsasr_splat_backward
+// (one translation unit of libgsasr_splat.so; gsasr_splat.hip has the overview of the whole pipeline)
+#include "splat_common.h"
+
+using namespace gsasr_detail;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// backward: one wave64 per Gaussian (cell order, so neighbouring waves read neighbouring pixels)
+// ---------------------------------------------------------------------------------------------------
+// Sweep the pixel window [c0,c0+bw) x [r0,r1] of one Gaussian with a wave.  Lanes are laid LX = 16/32/64
+// wide (the narrowest that covers bw, a template parameter so all the lane geometry is constant) and
+// 64/LX rows deep; a lane keeps ONE column (u = dx/sx is a lane constant) and handles TWO rows per trip, so
+// the per-pixel arithmetic is 2-wide packed fp32.  Because u is constant per lane only three sums over
+// rows are accumulated per pixel column,
+//     M0 = sum q,  N1 = sum q*B,  N2 = sum q*B^2,      q = v * <grad, colour>,  B = dy/sy - rho u,
+// and expanded at the end of the column (see below).
+// The dy/sy values of a 64-row block are staged in LDS (256 B per wave); full trips carry no masks or
+// address clamps, the ragged last trip is peeled.
+// acc[] = {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} (per lane, summed over the wave by the caller).
+struct BwdRow {
+    v2f m1, m2, k01;         // moments N1, N2 (row pair); colour sums r, g of the first row
+    float ka2, kb0, kb1, kb2;  // colour sums: b of the first row, r g b of the second
+};
+
+struct Grad6 {  // the three gradient channels of the two pixels (rows Y, Y+RPI) a lane owns in one trip
+    float a0, a1, a2, b0, b1, b2;
+};
+
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
+
+// Two 12-byte pixels through a raw buffer resource: address = base(SGPR x4) + per-lane byte offset (one VGPR per
+// row of the pair, constant over the sweep) + ONE running row offset (SGPR), so a trip spends no VALU instruction and
+// a single scalar add on addressing, and reads past the end of the slab return 0 instead of faulting.  (An instruction
+// added to a trip of ANY kind, scalar or vector, costs 0.35 us at config 2: the trips are the wave's dependent chain, and
+// that chain at seven waves per SIMD is the run time -- DESIGN.md 3c (c), (d).)
+__device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int voff_b, int soff_a)
+{
+    const int soff_b = soff_a;
+#ifdef BWD_EXP_NOLOAD   // what-if build (tools/whatif.sh): synthetic gradient values instead of the two loads of a trip
+    Grad6 s;
+    s.a0 = __int_as_float(voff | 0x3f000000); s.a1 = __int_as_float(soff_a | 0x3f000000); s.a2 = 0.25f;
+    s.b0 = __int_as_float(voff_b | 0x3f000000); s.b1 = 0.5f; s.b2 = __int_as_float(soff_b | 0x3e000000);
+    return s;
+#endif
+    const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
+    const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff_b, soff_b, 0);
+    Grad6 g;
+    g.a0 = __uint_as_float(a.x); g.a1 = __uint_as_float(a.y); g.a2 = __uint_as_float(a.z);
+    g.b0 = __uint_as_float(b.x); g.b1 = __uint_as_float(b.y); g.b2 = __uint_as_float(b.z);
+    return g;
+}
+
+template <bool TEST, bool TAIL>
+__device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f dyraw, bool ok1, bool ok2, float K0,
+                                         float nK1, float rho_u, float cr, float cg, float cb, float dmax)
+{
+#ifdef BWD_EXP_NOMATH   // what-if build (tools/whatif.sh): the loads are consumed by six adds, the trip's arithmetic is gone
+    R.k01 += (v2f){g.a0 + g.b0, g.a1 + g.b1};
+    R.ka2 += g.a2 + g.b2 + dyn.x;
+    return;
+#endif
+    // With u = dx/sx, v = dy/sy and B = v - rho u (the residual of v about its conditional mean given u) the
+    // quadratic form completes to  u^2 - 2 rho u v + v^2 = (1-rho^2) u^2 + B^2,  so the exponent is
+    //   log2(e) w1 (...) = K0 - K1 B^2,   K0 = -log2(e)/2 u^2 (lane constant),  K1 = log2(e)/2 / (1-rho^2),
+    // and the same B feeds the gradient moments: nothing here cancels as |rho| -> 1.
+    const v2f Bv = dyn - rho_u;
+    const v2f pw = (Bv * nK1) * Bv + K0;
+    v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+    if (TEST || TAIL) {
+        v.x = ((!TAIL || ok1) && (!TEST || fabsf(dyraw.x) <= dmax)) ? v.x : 0.f;
+        v.y = ((!TAIL || ok2) && (!TEST || fabsf(dyraw.y) <= dmax)) ? v.y : 0.f;
+    }
+    // six consecutive-in-memory floats per pixel pair are used as they land: no register shuffling
+    const v2f gp = {fmaf(g.a2, cb, fmaf(g.a1, cg, g.a0 * cr)), fmaf(g.b2, cb, fmaf(g.b1, cg, g.b0 * cr))};  // gs.cu:150
+    const v2f q = gp * v, qB = q * Bv;
+    // (M0 = sum q is not accumulated: it is <colour, colour sums>, formed once per column strip)
+    R.m1 += qB;
+    R.m2 += qB * Bv;
+    // Only {a0, a1} is an aligned register pair as the two 12-byte loads land; the other four take scalar FMAs
+    // (pairing them up costs five v_mov per trip -- more than the two packed operations save).
+    R.k01 += (v2f){g.a0, g.a1} * v.x;
+    R.ka2 = fmaf(g.a2, v.x, R.ka2);
+    R.kb0 = fmaf(g.b0, v.y, R.kb0);
+    R.kb1 = fmaf(g.b1, v.y, R.kb1);
+    R.kb2 = fmaf(g.b2, v.y, R.kb2);
+}
+
+template <bool TEST, int LXLOG, bool UNROLL>
+__device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int lane, const Params &P,
+                                          const float *__restrict__ pxt, const float *__restrict__ pyt,
+                                          const float *__restrict__ grad, float x, float y, float cr, float cg,
+                                          float cb, float cinv, float rho, float kappa, float isx, float isy,
+                                          float *spy, float (&acc)[8])
+{
+    constexpr int LX = 1 << LXLOG, RPI = 64 >> LXLOG;
+    constexpr float HALF_LOG2E = 0.72134752044448170368f;
+    const int col = lane & (LX - 1), rsub = lane >> LXLOG;
+    const unsigned pitchb = (unsigned)P.w * 12u;   // bytes per gradient row (< 2^19); all offsets below are unsigned 32 x 32 -> 64
+    const float nK1 = -HALF_LOG2E * cinv;
+    // issued together with the px load below: one round trip for both tables instead of two dependent ones
+    const float py_first = pyt[min(r0 + lane, r1)];
+    for (int strip = 0; strip < bw; strip += 64) {
+        const int cc = strip + col;
+        const int X = c0 + min(cc, bw - 1);
+        const float dx = pxt[X] - x;
+        // lanes outside the window (or, with TEST, outside the dmax box in x) are switched off through K0:
+        // the exponent becomes -inf, v = 0 exactly, and every product with it is 0
+        const bool inx = cc < bw && (!TEST || fabsf(dx) <= P.dmax);
+        const float u = dx * isx, rho_u = rho * u;
+        const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;
+        BwdRow R;
+        R.m1 = R.m2 = R.k01 = (v2f){0.f, 0.f};
+        R.ka2 = R.kb0 = R.kb1 = R.kb2 = 0.f;
+        const int voff = (int)((unsigned)X * 12u + (unsigned)rsub * pitchb);
+        const int halfb = (int)((unsigned)RPI * pitchb);
+        for (int rb = r0; rb <= r1; rb += 64) {
+            const int rend = min(r1, rb + 63);
+            __builtin_amdgcn_wave_barrier();
+            {   // per-row values of the block in LDS: v = dy/sy, and (TEST only) the raw dy for the exact box test
+                const float dyr = (rb == r0 ? py_first : pyt[min(rb + lane, r1)]) - y;
+                spy[lane] = dyr * isy;
+                if (TEST) spy[64 + lane] = dyr;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float *sp = spy + rsub;
+            // buffer resource over the slab from row `rb` on (offsets stay far below 2^31 within a 64-row block)
+            const char *blk = reinterpret_cast<const char *>(grad) + (unsigned long long)(unsigned)(rb - P.row0) * pitchb;
+            const unsigned long long left = (unsigned long long)(unsigned)(P.row1 - rb) * pitchb;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
+            int soff = 0;
+            // trip counts up front: the loops below count down (one scalar add + compare + branch per iteration)
+            constexpr int TRIP_SHIFT = 7 - LXLOG;                 // log2(rows per trip) = log2(2 RPI)
+            const int nrows = rend - rb + 1, ntrip = nrows >> TRIP_SHIFT;
+            const int voff_b = voff + halfb;
+            // Lanes outside the window sit the trips out (exec mask): the backward is co-limited by the CU's
+            // vector-memory pipe (two 768-byte loads per trip and wave, four SIMDs behind one L1), and idle
+            // lanes would fetch gradient pixels only to multiply them by zero.
+            if (inx) {
+            // UNROLL: two trips per iteration, four gradient loads in flight before the first is consumed.  Pays
+            // for windows of many trips (x8 and up); costs 18 VGPRs = two waves per SIMD, which small windows
+            // (x4, 6 trips) need more: the host picks the instantiation (gsasr_splat_backward).
+            int t = ntrip;
+            for (; UNROLL && t >= 2; t -= 2, soff += 4 * halfb, sp += 4 * RPI) {
+                const Grad6 g0 = bwd_load(rsrc, voff, voff_b, soff);
+                const Grad6 g1 = bwd_load(rsrc, voff, voff_b, soff + 2 * halfb);
+                const v2f n0 = {sp[0], sp[RPI]}, n1 = {sp[2 * RPI], sp[3 * RPI]};
+                const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0, w1 = TEST ? (v2f){sp[64 + 2 * RPI], sp[64 + 3 * RPI]} : n1;
+                bwd_trip<TEST, false>(R, g0, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
+                bwd_trip<TEST, false>(R, g1, n1, w1, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax);
+            }
+            if (!UNROLL && t > 0) {
+                // The plain loop runs ONE TRIP AHEAD: the two loads of trip k+1 are in flight while trip k is summed (two
+                // register sets used alternately: no copies).  Left to the compiler every trip was a dependent round trip
+                // -- issue, wait, sum -- and a wave's life at x4 is six of them: -5% at config 2, -4% on the config-5 crops,
+                // at 71 VGPRs (seven waves per SIMD kept).  Two trips ahead spills (72-VGPR budget): +8%; the same rotation
+                // in the unrolled instantiation: no gain (profiles/r03_bwd_experiments.txt).
+#define GSASR_TRIP(G) { const v2f n0 = {sp[0], sp[RPI]}; const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0; \
+                        bwd_trip<TEST, false>(R, G, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax); sp += 2 * RPI; }
+                Grad6 ga = bwd_load(rsrc, voff, voff_b, soff);
+                soff += 2 * halfb;
+                for (; t >= 3; t -= 2) {
+                    const Grad6 gb = bwd_load(rsrc, voff, voff_b, soff);
+                    soff += 2 * halfb;
+                    GSASR_TRIP(ga)
+                    ga = bwd_load(rsrc, voff, voff_b, soff);
+                    soff += 2 * halfb;
+                    GSASR_TRIP(gb)
+                }
+                if (t == 2) {
+                    const Grad6 gb = bwd_load(rsrc, voff, voff_b, soff);
+                    soff += 2 * halfb;
+                    GSASR_TRIP(ga)
+                    GSASR_TRIP(gb)
+                } else {
+                    GSASR_TRIP(ga)
+                }
+#undef GSASR_TRIP
+                t = 0;
+            }
+            for (; t > 0; --t, soff += 2 * halfb, sp += 2 * RPI) {   // (odd trip of the unrolled instantiation)
+                const v2f n0 = {sp[0], sp[RPI]};
+                const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0;
+                bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr,
+                                      cg, cb, P.dmax);
+            }
+            if (nrows & ((1 << TRIP_SHIFT) - 1)) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
+                const int Yb = rb + (ntrip << TRIP_SHIFT);
+                const int Ya = Yb + rsub, Yc = Ya + RPI;
+                const int ia = min(Ya, rend) - rb, ic = min(Yc, rend) - rb;
+                const v2f n0 = {spy[ia], spy[ic]};
+                const v2f w0 = TEST ? (v2f){spy[64 + ia], spy[64 + ic]} : n0;
+                bwd_trip<TEST, true>(R, bwd_load(rsrc, voff, voff_b, soff), n0, w0, Ya <= rend, Yc <= rend, K0, nK1,
+                                     rho_u, cr, cg, cb, P.dmax);
+            }
+            }
+        }
+        // Expand the column's three sums M0 = sum q, N1 = sum q B, N2 = sum q B^2 (u = dx/sx is a lane constant,
+        // A = u - rho v = u kappa - rho B, v = B + rho u):  sum qA, sum qB, sum q u A, sum q v B, sum q A B.
+        // Every difference is formed between quantities of its own size, so nothing cancels as |rho| -> 1
+        // (the plain monomial moments sum q dx^2, q dx dy, q dy^2 lose 1/(1-rho) digits there).
+        const float Kr = R.k01.x + R.kb0, Kg = R.k01.y + R.kb1, Kb = R.ka2 + R.kb2;
+        const float M0 = fmaf(Kb, cb, fmaf(Kg, cg, Kr * cr)), N1 = R.m1.x + R.m1.y, N2 = R.m2.x + R.m2.y;
+        // (switched-off lanes have M0 = N1 = N2 = 0, but their u is meaningless: use 0)
+        const float ue = inx ? u : 0.f, uk = ue * kappa;
+        const float sA = uk * M0 - rho * N1;
+        const float e[8] = {sA, N1, ue * sA, N2 + rho * ue * N1, uk * N1 - rho * N2,
+                            Kr, Kg, Kb};
+        // the first (usually only) 64-column strip assigns, so acc[] is not live during its sweep
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = strip == 0 ? e[k] : acc[k] + e[k];
+    }
+}
+
+// Sum eight per-lane values over the wave through LDS: lanes park their 8 partials ([8][64] floats per wave),
+// lane l then adds the 8 consecutive partials {l&7} of value {l>>3} (two ds_read_b128) and three butterfly
+// steps (DPP) finish inside each 8-lane group.  Afterwards lane 8k holds the total of value k.  ~14 VALU
+// instructions instead of ~45 for a register-only exchange network; the LDS pipe is otherwise idle here.
+__device__ __forceinline__ float wave_sum8(const float (&a)[8], int lane, float *red)
+{
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k * 64 + lane] = a[k];
+    __builtin_amdgcn_wave_barrier();
+    const float4 u = *reinterpret_cast<const float4 *>(red + lane * 8);
+    const float4 v = *reinterpret_cast<const float4 *>(red + lane * 8 + 4);
+    float d = ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
+    // lane 8k += lanes 8k+4, then +2, then +1, as DPP row shifts folded into the adds (a __shfl_xor is a
+    // ds_bpermute round trip plus five address instructions each)
+    d += dpp_row_shl<4>(d);
+    d += dpp_row_shl<2>(d);
+    d += dpp_row_shl<1>(d);
+    return d;   // valid in lanes 8k only
+}
+
+__device__ __forceinline__ void bwd_write(float v, int lane, const Params &P, unsigned i, float *__restrict__ g_sigmas,
+                                          float *__restrict__ g_coords, float *__restrict__ g_colors)
+{
+    if (lane & 7) return;
+    const int k = lane >> 3;
+    // one store (or atomic) through a per-lane pointer: the three arrays' bases are wave-uniform, pre-biased so that each
+    // is indexed by k, and selected per lane -- three exec-masked branches cost twice the instructions
+    float *pc = g_coords + (size_t)i * stride2(P), *ps = g_sigmas + (size_t)i * stride3(P) - 2,
+          *pk = g_colors + (size_t)i * stride3(P) - 5;
+    float *dst = (k < 2 ? pc : (k < 5 ? ps : pk)) + k;
+    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) *dst = v;
+    else atomicAdd(dst, v);   // fire-and-forget: the wave must not end on a load-add-store round trip
+}
+
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u8v __attribute__((ext_vector_type(8)));
+
+// Everything the sweep needs about Gaussian j, fetched by the SCALAR unit in one batch (one round trip).
+// Left to the compiler these are vector loads + v_readfirstlane (the kernel also stores to the workspace, so
+// it will not use the non-coherent scalar cache) issued as three dependent round trips, which was most of a
+// wave's life.  The plan was written by an earlier kernel, so the scalar cache is coherent for it.
+struct BwdRec {
+    u8v bb;    // both bbox words: {c0|test|c1, r0|r1, spans.. | spans.., padded rows r0|r1 of the sweep, -}
+    u8v rec;   // {x, y, IX, NR | IY, r, g, b}
+    u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, px-table offset, sample, index}
+};
+
+__device__ __forceinline__ void bwd_fetch(const PlanView &V, unsigned j, BwdRec &R)
+{
+    const uint4 *pb = V.bbox + 2 * (size_t)j;
+    const float4 *pr = V.rec + 2 * (size_t)j, *pf = V.fin + 2 * (size_t)j;
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\t"
+                 "s_load_dwordx8 %1, %4, 0x0\n\t"
+                 "s_load_dwordx8 %2, %5, 0x0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(R.bb), "=&s"(R.rec), "=&s"(R.fin)
+                 : "s"(pb), "s"(pr), "s"(pf)
+                 : "memory");
+}
+
+// the same plus the two class boundaries cell_start[ncells], cell_start[ncells+1]
+__device__ __forceinline__ void bwd_fetch_first(const PlanView &V, const unsigned *bounds, unsigned j, BwdRec &R, u2v &lim)
+{
+    const uint4 *pb = V.bbox + 2 * (size_t)j;
+    const float4 *pr = V.rec + 2 * (size_t)j, *pf = V.fin + 2 * (size_t)j;
+    asm volatile("s_load_dwordx2 %3, %7, 0x0\n\t"
+                 "s_load_dwordx8 %0, %4, 0x0\n\t"
+                 "s_load_dwordx8 %1, %5, 0x0\n\t"
+                 "s_load_dwordx8 %2, %6, 0x0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(R.bb), "=&s"(R.rec), "=&s"(R.fin), "=&s"(lim)
+                 : "s"(pb), "s"(pr), "s"(pf), "s"(bounds)
+                 : "memory");
+}
+
+template <bool BOUNDED, bool UNROLL>
+__device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk, bool atomic, int lane, const Params &P,
+                                         const PlanView &V, const float *__restrict__ grad, float *spy, float *red,
+                                         float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                         float *__restrict__ g_colors)
+{
+    const unsigned bbx = G.bb[0];
+    const int c0 = (int)(bbx & 0x7fffu), c1 = (int)(bbx >> 16);
+    if (c0 > c1) return;  // dead class (handled by the caller)
+    int r0, r1;
+    bool empty = false;
+    if (chunk >= 0) {  // (row chunks of a large Gaussian must not overlap: they split the window's own rows)
+        r0 = (int)(G.bb[1] & 0x7fffu);
+        r1 = (int)(G.bb[1] >> 16);
+        const int rpc = (r1 - r0 + NCH) / NCH;
+        r0 = r0 + chunk * rpc;
+        r1 = min(r1, r0 + rpc - 1);
+        empty = r0 > r1;   // still counted as a finished chunk below
+    } else {           // the plan's padded row range (whole trips; k_bin)
+        r0 = (int)(G.bb[6] & 0xffffu);
+        r1 = (int)(G.bb[6] >> 16);
+    }
+    const float x = __uint_as_float(G.rec[0]), y = __uint_as_float(G.rec[1]);
+    const float cr = __uint_as_float(G.rec[5]), cg = __uint_as_float(G.rec[6]), cb = __uint_as_float(G.rec[7]);
+    const float4 fa = make_float4(__uint_as_float(G.fin[0]), __uint_as_float(G.fin[1]), __uint_as_float(G.fin[2]),
+                                  __uint_as_float(G.fin[3]));   // {c, kappa, rho, 1/sx}
+    const float4 fb = make_float4(__uint_as_float(G.fin[4]), 0.f, 0.f, 0.f);   // {1/sy, ..}
+    float a[8];
+    const int bw = c1 - c0 + 1;
+    const bool test = BOUNDED && (bbx & 0x8000u);
+    float d = 0.f;
+    if (!empty) {
+#define GSASR_SWEEP(T, L) \
+    bwd_sweep<T, L, UNROLL>(c0, bw, r0, r1, lane, P, V.px + G.fin[5], V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
+        if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
+        else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
+        else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
+#undef GSASR_SWEEP
+        bwd_scale(a, fa.x, fa.w, fb.x);
+        d = wave_sum8(a, lane, red);   // lane 8k now holds gradient component k
+    }
+    if (atomic) {
+        // Large class: the row chunks add into sums[] and count themselves; the wave that finishes the
+        // last chunk takes the totals (re-arming the accumulators for the next backward) and writes the
+        // gradient, so no separate finalize pass exists.
+        if (!empty && (lane & 7) == 0) atomicAdd(V.sums + 8 * (size_t)j + (lane >> 3), d);
+        __threadfence();
+        unsigned prev = 0;
+        if (lane == 0) prev = atomicAdd(&V.done[j], 1u);
+        prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+        if (prev != (unsigned)(NCH - 1)) return;
+        __threadfence();
+        if ((lane & 7) == 0) d = atomicExch(V.sums + 8 * (size_t)j + (lane >> 3), 0.f);
+        if (lane == 0) V.done[j] = 0u;
+    }
+    bwd_write(d, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
+}
+
+// (occupancy targets: the unrolled sweep fits 6 waves per SIMD at the price of five spilled dwords, -2.7% at config 4;
+// forcing the plain sweep to 8 costs more in spills than it gains)
+template <bool BOUNDED, bool UNROLL>
+__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(UNROLL ? BWD_UNROLL_OCC : BWD_OCC))) void k_render_bwd(Params P, PlanView V, const float *__restrict__ grad,
+                                                    float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                                    float *__restrict__ g_colors)
+{
+    const int lane = threadIdx.x & 63;
+    // XCD-aware order (block b runs on XCD b%8): each XCD sweeps a contiguous run of the cell-ordered
+    // Gaussians, i.e. one band of the image, so the grad_img rows it re-reads stay in ITS 4 MiB L2
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u;
+    const unsigned t = xcd * q + min(xcd, r) + (b >> 3);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned gw = t * (unsigned)BWD_WAVES + (unsigned)wv;
+    const unsigned nwaves = nb * (unsigned)BWD_WAVES;
+    __shared__ float s_py[BWD_WAVES][128];  // per wave: v = dy/sy of a 64-row block, then (TEST) the raw dy
+    __shared__ __attribute__((aligned(16))) float s_red[BWD_WAVES][512];
+    float *spy = s_py[wv], *red = s_red[wv];
+    // one Gaussian per wave, dispatched by the hardware (a persistent-workgroup variant with a static
+    // partition was measured 13% slower at config 2 and 60% slower at config 3: load imbalance)
+    // (two or four Gaussians per wave, one after the other, measured the same: wave launch is not the cost)
+    BwdRec G;
+    u2v lim;
+    bwd_fetch_first(V, V.cell_start + P.ncells, min(gw, (unsigned)P.s - 1u), G, lim);  // speculative: class checked below
+    const unsigned large_beg = lim.x, large_end = lim.y;
+    if (gw < large_beg)
+        bwd_item<BOUNDED, UNROLL>(gw, G, -1, false, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+    else if (gw < large_end)
+        bwd_item<BOUNDED, UNROLL>(gw, G, 0, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+    else if (gw < (unsigned)P.s && (P.flags & GSASR_FLAG_OVERWRITE_GRADS))   // dead class: the gradient is zero
+        bwd_write(0.f, lane, P, G.fin[7], g_sigmas, g_coords, g_colors);
+    // remaining row chunks of the large class, spread over all waves
+    const unsigned extra = (large_end - large_beg) * (unsigned)(NCH - 1);
+    for (unsigned it = gw; it < extra; it += nwaves) {
+        const unsigned j = large_beg + it / (unsigned)(NCH - 1);
+        const int chunk = 1 + (int)(it % (unsigned)(NCH - 1));
+        bwd_fetch(V, j, G);
+        bwd_item<BOUNDED, UNROLL>(j, G, chunk, true, lane, P, V, grad, spy, red, g_sigmas, g_coords, g_colors);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// backward, Gaussian-stationary with EIGHT Gaussians per wave (round 5).  k_render_bwd spends a wave per Gaussian: at GSASR's
+// x4 a window is ~20 x 20 px, i.e. six trips of 21 VALU instructions under ~80 instructions of per-wave fixed work (record
+// fetch, tables, expansion, wave reduction, write) with 20 of the 32 lanes of a row in use.  Here a Gaussian gets the 8 lanes
+// of one DPP half-row: lane = one column of an 8-column strip, two rows per trip (packed fp32), strips and row pairs in
+// per-lane loops (the wave runs until its tallest Gaussian is done; cell-ordered neighbours have like windows).  The fixed
+// work is shared by eight Gaussians, 20 of 24 lanes of a strip are in use, a gradient load instruction serves eight windows
+// (7.5 wave-loads per Gaussian instead of 13 on the CU's vector-memory pipe), and the reduction is three DPP steps inside
+// the half-row.  The sums are bwd_sweep's (residual form: nothing cancels as |rho| -> 1).  The sample-point backward
+// (k_sample_bwd) has had this shape since round 2; the full-image one got it when the per-Gaussian cost, not latency, turned
+// out to bound GSASR's real density (1 M waves at 16 Gaussians per LR pixel).
+// The "large" class (split into row chunks over all waves, atomics) keeps the wave-per-item code: bwd_item below.
+// ---------------------------------------------------------------------------------------------------
+constexpr int B8_ROWS = 32;    // rows whose dy values a Gaussian's lanes stage in LDS at a time (4 per lane)
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(256) void k_render_bwd8(Params P, PlanView V, const float *__restrict__ grad,
+                                                     float *__restrict__ g_sigmas, float *__restrict__ g_coords,
+                                                     float *__restrict__ g_colors)
+{
+    constexpr float HALF_LOG2E = 0.72134752044448170368f;
+    __shared__ __attribute__((aligned(16))) float s_dy[4][8][2][B8_ROWS];   // per wave and Gaussian: dy / sy, raw dy of a row block
+    __shared__ float s_py[4][128];                                          // (large class: bwd_item's scratch)
+    __shared__ __attribute__((aligned(16))) float s_red[4][512];
+    const int lane = threadIdx.x & 63, sl = lane & 7, grp = lane >> 3;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const unsigned j = (t * 256u + threadIdx.x) >> 3;          // this lane's Gaussian (cell order)
+    const unsigned large_beg = V.cell_start[P.ncells], large_end = V.cell_start[P.ncells + 1];
+    const bool valid = j < (unsigned)P.s;
+    const size_t jj = valid ? j : (size_t)P.s - 1;
+    const bool normal = valid && j < large_beg;
+    uint2 bb = make_uint2(0x7fffu, 0x7fffu);
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb4 = ra, fa = ra;
+    const float4 fb = V.fin[2 * jj + 1];     // {1/sy, px-table offset, sample, original index}: written for every slot
+    if (normal) {
+        bb = *reinterpret_cast<const uint2 *>(V.bbox + 2 * jj);
+        ra = V.rec[2 * jj];
+        rb4 = V.rec[2 * jj + 1];
+        fa = V.fin[2 * jj];
+    }
+    const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+    const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+    const bool live = normal && c0 <= c1;
+    const float x = ra.x, y = ra.y, cr = rb4.y, cg = rb4.z, cb = rb4.w;
+    const float cinv = fa.x, kappa = fa.y, rho = fa.z, isx = fa.w, isy = fb.x;
+    const float nK1 = -HALF_LOG2E * cinv;
+    const bool test = BOUNDED && (bb.x & 0x8000u) != 0u;
+    const float dmax = test ? P.dmax : INFINITY;
+    // (the exact dmax test costs two instructions per trip: a wave pays them only if one of its Gaussians needs it -- the others
+    // then test against +inf)
+    const bool anytest = BOUNDED && __ballot(test) != 0ull;
+    const float *__restrict__ pxt = V.px + __float_as_uint(fb.y);
+    const float *__restrict__ pyt = V.py;
+    const unsigned pitchb = (unsigned)P.w * 12u;
+    // one buffer resource over the whole slab: per-lane byte offsets (the host takes this kernel for slabs below 4 GiB only);
+    // reads past the end return 0
+    const unsigned long long slab = (unsigned long long)(unsigned)(P.row1 - P.row0) * pitchb;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad), 0, (int)(unsigned)(slab < 0xffffffffull ? slab : 0xffffffffull), 0x00020000);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float *dyn = s_dy[wv][grp][0], *dyr = s_dy[wv][grp][1];
+    const int bw = c1 - c0 + 1;
+    for (int rb = r0; live && rb <= r1; rb += B8_ROWS) {
+        const int nrow = min(r1 - rb + 1, B8_ROWS);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {      // the block's row values: dy / sy for the exponent, raw dy for the exact dmax test
+            const float d = pyt[min(rb + 4 * sl + k, r1)] - y;
+            dyn[4 * sl + k] = d * isy;
+            dyr[4 * sl + k] = d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int strip = 0; strip < bw; strip += 8) {
+            const int X = c0 + min(strip + sl, bw - 1);
+            const float dx = pxt[X] - x;
+            const bool inx = strip + sl < bw && fabsf(dx) <= dmax;
+            const float u = dx * isx, rho_u = rho * u;
+            const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;     // a column outside the window (or the box): v = 0 exactly
+            BwdRow R;
+            R.m1 = R.m2 = R.k01 = (v2f){0.f, 0.f};
+            R.ka2 = R.kb0 = R.kb1 = R.kb2 = 0.f;
+            int voff = (int)((unsigned)(rb - P.row0) * pitchb + (unsigned)X * 12u);
+            int rr = 0;
+            for (; rr + 1 < nrow; rr += 2, voff += (int)(2u * pitchb)) {
+                const u3v ga = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, 0, 0);
+                const u3v gb = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, (int)pitchb, 0);
+                Grad6 g;
+                g.a0 = __uint_as_float(ga.x); g.a1 = __uint_as_float(ga.y); g.a2 = __uint_as_float(ga.z);
+                g.b0 = __uint_as_float(gb.x); g.b1 = __uint_as_float(gb.y); g.b2 = __uint_as_float(gb.z);
+                const v2f n0 = *reinterpret_cast<const v2f *>(dyn + rr);
+                const v2f w0 = BOUNDED ? *reinterpret_cast<const v2f *>(dyr + rr) : n0;
+                if (BOUNDED && anytest) bwd_trip<true, false>(R, g, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, dmax);
+                else bwd_trip<false, false>(R, g, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, dmax);
+            }
+            if (rr < nrow) {     // odd last row: the second pixel of the pair is switched off (and reads the same, valid row)
+                const u3v ga = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, 0, 0);
+                Grad6 g;
+                g.a0 = g.b0 = __uint_as_float(ga.x); g.a1 = g.b1 = __uint_as_float(ga.y); g.a2 = g.b2 = __uint_as_float(ga.z);
+                const v2f n0 = {dyn[rr], dyn[rr]};
+                const v2f w0 = {dyr[rr], dyr[rr]};
+                if (BOUNDED && anytest) bwd_trip<true, true>(R, g, n0, w0, true, false, K0, nK1, rho_u, cr, cg, cb, dmax);
+                else bwd_trip<false, true>(R, g, n0, w0, true, false, K0, nK1, rho_u, cr, cg, cb, dmax);
+            }
+            // the column's three sums expanded to the five gradient sums (bwd_sweep)
+            const float Kr = R.k01.x + R.kb0, Kg = R.k01.y + R.kb1, Kb = R.ka2 + R.kb2;
+            const float M0 = fmaf(Kb, cb, fmaf(Kg, cg, Kr * cr)), N1 = R.m1.x + R.m1.y, N2 = R.m2.x + R.m2.y;
+            const float ue = inx ? u : 0.f, uk = ue * kappa;
+            const float sA = uk * M0 - rho * N1;
+            a[0] += sA; a[1] += N1; a[2] += ue * sA; a[3] += N2 + rho * ue * N1; a[4] += uk * N1 - rho * N2;
+            a[5] += Kr; a[6] += Kg; a[7] += Kb;
+        }
+    }
+    if (live) bwd_scale(a, cinv, isx, isy);
+    // sum over the Gaussian's 8 lanes (half a DPP row): its first lane gets the totals
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = a[k];
+        v += dpp_row_shl<4>(v);
+        v += dpp_row_shl<2>(v);
+        v += dpp_row_shl<1>(v);
+        a[k] = v;
+    }
+    // normal class: its gradient; dead class (behind the large one in cell order): zero when gradients are stored
+    const bool dead_slot = valid && j >= large_end;
+    if (sl == 0 && (normal || dead_slot)) {
+        const unsigned orig = __float_as_uint(fb.w);
+        const bool store = (P.flags & GSASR_FLAG_OVERWRITE_GRADS) != 0u;
+        float *pc = g_coords + (size_t)orig * stride2(P), *ps = g_sigmas + (size_t)orig * stride3(P),
+              *pk = g_colors + (size_t)orig * stride3(P);
+        if (store) {
+            pc[0] = a[0]; pc[1] = a[1]; ps[0] = a[2]; ps[1] = a[3]; ps[2] = a[4]; pk[0] = a[5]; pk[1] = a[6]; pk[2] = a[7];
+        } else if (live) {
+            atomicAdd(pc, a[0]); atomicAdd(pc + 1, a[1]); atomicAdd(ps, a[2]); atomicAdd(ps + 1, a[3]); atomicAdd(ps + 2, a[4]);
+            atomicAdd(pk, a[5]); atomicAdd(pk + 1, a[6]); atomicAdd(pk + 2, a[7]);
+        }
+    }
+    // the large class: NCH row chunks per Gaussian, dealt to all waves of the launch, one wave per chunk (k_render_bwd's code)
+    const unsigned nitems = (large_end - large_beg) * (unsigned)NCH;
+    if (nitems) {
+        const unsigned nwaves = gridDim.x * 4u, gw = t * 4u + (unsigned)wv;
+        BwdRec G;
+        for (unsigned it = gw; it < nitems; it += nwaves) {
+            const unsigned jl = large_beg + it / (unsigned)NCH;
+            bwd_fetch(V, jl, G);
+            bwd_item<BOUNDED, false>(jl, G, (int)(it % (unsigned)NCH), true, lane, P, V, grad, s_py[wv], s_red[wv], g_sigmas, g_coords, g_colors);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// backward, TILE-stationary (BASELINE.json north_star's shape: a workgroup owns an HR tile, stages its grad_img ONCE
+// in LDS and streams the Gaussians binned near it).  Measured against the Gaussian-stationary k_render_bwd above in
+// DESIGN.md 3c; the host picks between the two (gsasr_splat_backward).
+//
+//   tile      32 x 16 px = 8 "quadrants" of 8 x 8 px, one workgroup of two waves per tile; from x8 up (bt_tall) 32 x 32 px =
+//             16 quadrants and four waves.  XCD-banded tile order.
+//   stage     the tile's gradient (HWC or planar CHW, zero outside the image / the sample / the row band) goes to LDS as
+//             packed row pairs {r_a, r_b, g_a, g_b, b_a, b_b} per (column, row pair) of each quadrant, with the px / py
+//             table entries of the tile.  Every pixel of grad_img is read once per tile that holds it -- exactly once.
+//   level 1   as in the forward (fwd_block): the four waves test the windows of the Gaussians binned within reach of
+//             the tile, 64 per wave and chunk, and append the survivors to a list in LDS.  A survivor also appends one
+//             ITEM per quadrant its window touches (1..8 or 16), survivor-major, the last one marked.
+//   level 2   LANE = ITEM = (Gaussian, quadrant): a lane loads its Gaussian's records once and evaluates it at the 64
+//             pixels of its quadrant -- gradients read from LDS (lanes of different quadrants hit disjoint banks), two
+//             rows per packed-fp32 operation, columns in the outer loop so that u = dx/sx is constant in the inner one
+//             and the same residual-form sums as bwd_sweep apply.  No cross-lane reduction of pixels, no masks: a pixel
+//             outside the Gaussian's window adds a term below exp(-tau), a pixel outside the image adds 0 * v.
+//             The items of one Gaussian sit in adjacent lanes (chunks are cut at the last marked lane, so a Gaussian never
+//             straddles two chunks): three (four) shuffle steps add them up, and the first lane of each run stores the eight raw
+//             sums into the Gaussian's slot for THIS tile (PlanView::part) -- plain 32-byte stores, no atomics, no
+//             dependence on scheduling.  (Measured on this chip: fp32 global atomics retire ~19 G cache-line requests/s
+//             chip-wide and ds_add_f32 ~3 cycles per lane; tools/atomic_rate.hip.  One atomic set per (tile, Gaussian)
+//             would be 14 us of atomic traffic at config 2.)
+//   gather    k_bwd_gather (or the fused k_prologue_bwd_gather of the step entry points): one thread per Gaussian adds
+//             the slots of its window's tiles in order, applies the Gaussian's constants and writes the gradient.
+// A Gaussian whose window spans more tiles than it has slots (or the "large" class) adds into PlanView::sums with
+// atomics instead; the gather adds those as well.
+// ---------------------------------------------------------------------------------------------------
+// One item: Gaussian j (cell order) at the 64 pixels of one quadrant.  gq = the quadrant's block of staged gradients,
+// pxq / pyq = its 8 column / row coordinates.  a[] = raw sums {qA, qB, quA, qvB, qAB, Cr, Cg, Cb} (cf. bwd_sweep).
+template <bool TEST>
+__device__ __forceinline__ void bt_eval(const PlanView &V, unsigned j, float dm, const float *gq, const float *pxq,
+                                        const float *pyq, float (&a)[8])
+{
+    constexpr float HALF_LOG2E = 0.72134752044448170368f;
+    const float4 ra = V.rec[2 * (size_t)j], rb = V.rec[2 * (size_t)j + 1];
+    const float4 fa = V.fin[2 * (size_t)j];
+    const float isy = V.fin[2 * (size_t)j + 1].x;
+    const float x = ra.x, y = ra.y, cr = rb.y, cg = rb.z, cb = rb.w;
+    const float cinv = fa.x, kappa = fa.y, rho = fa.z, isx = fa.w;
+    // exponent (log2) = -h u^2 - h c B^2 with u = dx/sx, B = dy/sy - rho u, c = 1/(1-rho^2) (bwd_trip); B is carried
+    // pre-scaled by sB = sqrt(h c), so that the exponent is K0(u) - B'^2
+    const float sB = __builtin_amdgcn_sqrtf(HALF_LOG2E * cinv), inv_sB = __builtin_amdgcn_rcpf(sB);
+    const float isyB = isy * sB, rsB = rho * sB;
+    v2f vp[4], rt[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const v2f dy = (v2f){pyq[2 * p], pyq[2 * p + 1]} - y;
+        vp[p] = dy * isyB;
+        if (TEST) rt[p] = (v2f){fabsf(dy.x) <= dm ? 0.f : -INFINITY, fabsf(dy.y) <= dm ? 0.f : -INFINITY};
+    }
+    float s_uM = 0.f, s_uuM = 0.f, s_N1 = 0.f, s_uN1 = 0.f, s_N2 = 0.f;
+    v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
+    for (int c = 0; c < 8; ++c) {
+        const float dx = pxq[c] - x;
+        const float u = dx * isx, ru = rsB * u;
+        float K0 = -HALF_LOG2E * u * u;
+        if (TEST) K0 = fabsf(dx) <= dm ? K0 : -INFINITY;   // exponent -inf: v = 0 exactly, every product with it is 0
+        v2f M0 = {0.f, 0.f}, N1 = {0.f, 0.f}, N2 = {0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 d0 = *reinterpret_cast<const float4 *>(gq + (c * 4 + p) * 8);
+            const float2 d1 = *reinterpret_cast<const float2 *>(gq + (c * 4 + p) * 8 + 4);
+            const v2f Bv = vp[p] - ru;
+            v2f pw = K0 - Bv * Bv;
+            if (TEST) pw += rt[p];
+            const v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+            const v2f gr = {d0.x, d0.y}, gn = {d0.z, d0.w}, gb = {d1.x, d1.y};
+            const v2f gp = gb * cb + (gn * cg + gr * cr);   // gs.cu:150
+            const v2f qq = gp * v, qB = qq * Bv;
+            M0 += qq;
+            N1 += qB;
+            N2 += qB * Bv;
+            Cr += v * gr;
+            Cg += v * gn;
+            Cb += v * gb;
+        }
+        // the column's sums, as polynomials in its u (expanded after the last column)
+        const float m0 = M0.x + M0.y, n1 = N1.x + N1.y, n2 = N2.x + N2.y;
+        const float um = u * m0;
+        s_uM += um;
+        s_uuM = fmaf(u, um, s_uuM);
+        s_N1 += n1;
+        s_uN1 = fmaf(u, n1, s_uN1);
+        s_N2 += n2;
+    }
+    // undo the scale of B, then  sum qA = kappa sum(u M0) - rho sum N1  etc.: bwd_sweep's per-column expansion summed
+    // over the columns (A = kappa u - rho B, v = B + rho u)
+    const float N1t = s_N1 * inv_sB, uN1t = s_uN1 * inv_sB, N2t = s_N2 * inv_sB * inv_sB;
+    a[0] = kappa * s_uM - rho * N1t;
+    a[1] = N1t;
+    a[2] = kappa * s_uuM - rho * uN1t;
+    a[3] = N2t + rho * uN1t;
+    a[4] = kappa * uN1t - rho * N2t;
+    a[5] = Cr.x + Cr.y;
+    a[6] = Cg.x + Cg.y;
+    a[7] = Cb.x + Cb.y;
+}
+
+// (the 32-row tile runs twice the waves per workgroup with half the chunks each: the same rounds, the same waves per CU under
+// its 27 KB of LDS)
+template <bool BOUNDED, int BT_CHUNKS, int HLOG>
+__global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_waves_per_eu((BT_CHUNKS * BT_WAVES << (HLOG - 4)) <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
+    Params P, PlanView V, const float *__restrict__ grad, int tiles_x, int use_atomics)
+{
+    constexpr int BT_H = 1 << HLOG, NQY = BT_H / 8, NQ = 4 * NQY;   // tile height, quadrant rows, quadrants (8 or 16)
+    constexpr int WAVES = BT_WAVES << (HLOG - 4), THREADS = 64 * WAVES;
+    constexpr int BT_LIST = WAVES * BT_CHUNKS * 64;     // survivors per round at most (512 / 256)
+    __shared__ __attribute__((aligned(16))) float s_g[NQ * BT_QSTRIDE];
+    __shared__ float s_px[BT_W], s_py[BT_H];
+    __shared__ unsigned s_list[BT_LIST];            // survivor: index in cell order | needs the dmax test << 31
+    __shared__ unsigned char s_slot[BT_LIST];       // its slot in part[] for this tile, or BT_WIDE
+    __shared__ unsigned short s_items[BT_LIST * NQ]; // item: survivor (9 bits) | quadrant << 9 | last of its survivor << 13
+    __shared__ unsigned s_cnt[3];                   // survivors, items of the round; head of the item queue (level 2)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tt = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = (int)(tt % (unsigned)tiles_x), ty = (int)(tt / (unsigned)tiles_x);
+    const int bx0 = tx * BT_W, by0 = P.row0 + ty * BT_H;
+    const int bx1 = min(bx0 + BT_W - 1, P.w - 1), by1 = min(by0 + BT_H - 1, P.row1 - 1);
+    const int smp = P.batch > 1 ? by0 / P.slot : 0;
+    const Geo g = sample_geo(P, V, smp);
+
+    // ---- stage the tile ---------------------------------------------------------------------------------
+    {
+        const int ylim = min(P.row1, g.base + g.h);
+        const bool chw = (P.flags & GSASR_FLAG_CHW_GRAD) != 0u;
+        size_t plane = (size_t)(P.row1 - P.row0) * P.w, org = 0;     // planar: [3, rows, w]; batched [B, 3, grad_rows, w]
+        int yoff = P.row0;
+        if (chw && P.batch > 1) {
+            plane = (size_t)P.grad_rows * P.w;
+            org = (size_t)smp * 3 * plane;
+            yoff = g.base;
+        }
+#pragma unroll
+        for (int i = tid; i < BT_W * BT_H; i += THREADS) {
+            const int row = i >> 5, col = i & 31, X = bx0 + col, Y = by0 + row;
+            float r = 0.f, gg = 0.f, b = 0.f;
+            if (X < g.w && Y < ylim) {
+                if (chw) {
+                    const float *q = grad + org + (size_t)(Y - yoff) * P.w + X;
+                    r = q[0]; gg = q[plane]; b = q[2 * plane];
+                } else {
+                    const float *q = grad + ((size_t)(Y - P.row0) * P.w + X) * 3;
+                    r = q[0]; gg = q[1]; b = q[2];
+                }
+            }
+            float *e = s_g + ((row >> 3) * 4 + (col >> 3)) * BT_QSTRIDE + (((col & 7) * 4 + ((row & 7) >> 1)) * 8) + (row & 1);
+            e[0] = r; e[2] = gg; e[4] = b;
+        }
+        if (tid < BT_W) s_px[tid] = V.px[g.pxo + min(bx0 + tid, P.w - 1)];
+        else if (tid < BT_W + BT_H) s_py[tid - BT_W] = V.py[min(by0 + tid - BT_W, P.h - 1)];
+        if (tid < 3) s_cnt[tid] = 0u;
+    }
+
+    // ---- segment table of the tile (every wave builds the same one; cf. fwd_block) ------------------------
+    const unsigned *__restrict__ cs = V.cell_start;
+    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
+    int nseg = 0;
+    unsigned sbeg = 0, send = 0;
+    if (rx > 0) {
+        const int cx0 = max(bx0 - rx, 0) >> CELL_SHIFT, cx1 = min((bx1 + rx) >> CELL_SHIFT, P.ncx - 1);
+        const int cy0 = max(by0 - ry, 0) >> CELL_SHIFT, cy1 = min((by1 + ry) >> CELL_SHIFT, P.ncy - 1);
+        nseg = cy1 - cy0 + 1;
+        if (lane < nseg) {
+            sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+            send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
+        }
+    }
+    if (lane == nseg) {
+        sbeg = cs[P.ncells];
+        send = cs[P.ncells + 1];
+    }
+    ++nseg;
+    const unsigned len = send - sbeg;
+    unsigned pin = len;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)pin, o);
+        if (lane >= o) pin += v;
+    }
+    const unsigned pex = pin - len;
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+    const unsigned nchunks = (total + 63u) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rseg = 0;
+    __syncthreads();
+
+    for (unsigned base = 0; base < nchunks; base += (unsigned)(WAVES * BT_CHUNKS)) {
+        // ---- level 1: candidates -> survivors + items ----------------------------------------------------
+        unsigned cj[BT_CHUNKS];
+        uint2 cw[BT_CHUNKS];
+#pragma unroll
+        for (int k = 0; k < BT_CHUNKS; ++k) {
+            const unsigned c = base + (unsigned)wv + (unsigned)(WAVES * k);
+            cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
+            cw[k] = make_uint2(0x7fffu, 0x7fffu);
+            if (cj[k] != 0xffffffffu) cw[k] = V.win[cj[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < BT_CHUNKS; ++k) {
+            const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
+            const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
+            const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) continue;
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&s_cnt[0], (unsigned)__builtin_popcountll(m));
+            at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+            const unsigned pos = at + (unsigned)__builtin_popcountll(m & below);
+            // quadrants of the tile the window touches, row by row trimmed to the columns the ellipse reaches (k_bin's
+            // per-8-row spans): the corners of the window are empty for every Gaussian, most of it for a correlated one
+            const int qx0 = max(c0 - bx0, 0) >> 3, qx1 = min(c1 - bx0, BT_W - 1) >> 3;
+            const int qy0 = max(r0 - by0, 0) >> 3, qy1 = min(r1 - by0, BT_H - 1) >> 3;
+            int xl[NQY], xh[NQY];
+#pragma unroll
+            for (int qy = 0; qy < NQY; ++qy) { xl[qy] = 1; xh[qy] = 0; }
+            if (hit) {
+                // per-8-row spans (qspan) when the window has at most eight such bands; a taller window (x12 and up) still has
+                // the forward's per-16-row spans in its window words: both quadrant rows of this tile then share one band
+                uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);
+                const int q0 = (r0 - P.row0) >> 3, b8 = (by0 - P.row0) >> 3;
+                const bool fine = ((r1 - P.row0) >> 3) - q0 < 8;
+                if (fine) {
+                    if (V.qspan) qs = V.qspan[cj[k]];
+                } else if (cw[k].y & 0x8000u) {
+                    const uint2 *sp = reinterpret_cast<const uint2 *>(V.bbox + 2 * (size_t)cj[k]);
+                    const uint2 s0 = sp[1], s1 = sp[2];
+                    qs = make_uint4(s0.x, s0.y, s1.x, s1.y);
+                }
+                const int cu = (c0 >> 3) - (bx0 >> 3);
+#pragma unroll
+                for (int qy = 0; qy < NQY; ++qy) {
+                    const unsigned t = (unsigned)(fine ? b8 - q0 + qy : ((b8 + qy) >> 1) - (q0 >> 1)) & 7u, sh = (t & 3u) * 8u;
+                    const int lo = (int)(((t < 4u ? qs.x : qs.z) >> sh) & 0xffu), hi = (int)(((t < 4u ? qs.y : qs.w) >> sh) & 0xffu);
+                    if (qy >= qy0 && qy <= qy1) {
+                        // (hi = 255 is "as far as the window goes": the default of a window k_bin computed no spans for --
+                        // one wider than 255 columns of 8 px among them, whose far tiles would otherwise lose their quadrants)
+                        xl[qy] = max(qx0, cu + lo);
+                        xh[qy] = hi == 255 ? qx1 : min(qx1, cu + hi);
+                    }
+                }
+            }
+            unsigned n_i = 0u;
+#pragma unroll
+            for (int qy = 0; qy < NQY; ++qy) n_i += (unsigned)max(xh[qy] - xl[qy] + 1, 0);
+            unsigned inc = n_i;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = (unsigned)__shfl_up((int)inc, o);
+                if (lane >= o) inc += v;
+            }
+            unsigned ib = 0;
+            if (lane == 63) ib = atomicAdd(&s_cnt[1], inc);
+            ib = (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
+            if (hit) {
+                s_list[pos] = cj[k] | ((cw[k].x & 0x8000u) << 16);
+                int ntx, wtx0, wty0;
+                const int nt = bt_tile_span(cw[k].x, cw[k].y, P.row0, HLOG, ntx, wtx0, wty0);
+                const unsigned slot = nt <= P.part_k ? (unsigned)((ty - wty0) * ntx + (tx - wtx0)) : BT_WIDE;
+                s_slot[pos] = (unsigned char)slot;
+                unsigned off = ib + inc - n_i;
+                const unsigned last = off + n_i - 1u;
+#pragma unroll
+                for (int qy = 0; qy < NQY; ++qy)
+                    for (int qx = xl[qy]; qx <= xh[qy]; ++qx, ++off)
+                        s_items[off] = (unsigned short)((unsigned)pos | (unsigned)(qy * 4 + qx) << 9 | (off == last ? 0x2000u : 0u));
+                if (n_i == 0u && slot != BT_WIDE && !use_atomics) {   // the ellipse misses the tile: its slot is still read
+                    float4 *o = reinterpret_cast<float4 *>(V.part + ((size_t)cj[k] * P.part_k + slot) * 8);
+                    o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned nsurv = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[0]);
+        const unsigned nitems = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cnt[1]);
+        (void)nsurv;
+        // ---- level 2: chunks of <= 64 items, cut where a Gaussian's items end, CLAIMED by the waves from one queue ----
+        // (a static split of the item list between the waves leaves every wave a ragged last chunk: with ~150 items per wave
+        // that is 3-3.5 chunk iterations for 2.4 chunks of work, the largest single loss of this kernel.  A chunk's end
+        // depends on its items, so a wave reads the queue head, finds its cut and claims [head, cut] with a compare-and-swap.)
+        for (;;) {
+            unsigned p0, it = 0u;
+            int tlast = 0;
+            for (;;) {
+                p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned *)&s_cnt[2]);
+                if (p0 >= nitems) break;
+                const unsigned idx = p0 + (unsigned)lane;
+                it = idx < nitems ? s_items[idx] : 0u;
+                const unsigned long long tails = __ballot(idx < nitems && (it & 0x2000u));
+                tlast = 63 - __builtin_clzll(tails);                  // (the list ends on a marked item: tails != 0)
+                unsigned got = 0u;
+                if (lane == 0) got = atomicCAS(&s_cnt[2], p0, p0 + (unsigned)tlast + 1u);
+                if ((unsigned)__builtin_amdgcn_readfirstlane((int)got) == p0) break;
+            }
+            if (p0 >= nitems) break;
+            const bool valid = lane <= tlast;
+            const unsigned lidx = it & 0x1ffu, q = (it >> 9) & 15u;
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            unsigned j = 0u;
+            unsigned e = 0u;
+            if (valid) {
+                e = s_list[lidx];
+                j = e & 0x7fffffffu;
+            }
+            // (the dmax test costs an instruction per pixel pair: only chunks holding a Gaussian that needs it pay)
+            if (BOUNDED && __ballot(valid && (e >> 31)) != 0ull) {
+                if (valid) bt_eval<true>(V, j, (e >> 31) ? P.dmax : INFINITY, s_g + q * BT_QSTRIDE, s_px + (q & 3u) * 8u, s_py + (q >> 2) * 8u, a);
+            } else {
+                if (valid) bt_eval<false>(V, j, INFINITY, s_g + q * BT_QSTRIDE, s_px + (q & 3u) * 8u, s_py + (q >> 2) * 8u, a);
+            }
+            // add up the items of each Gaussian (adjacent lanes, at most NQ): three or four shuffle steps; its first lane gets the total
+            const unsigned key = valid ? lidx : 0xffffu;
+#pragma unroll
+            for (int o = 1; o < NQ; o <<= 1) {
+                const bool same = (unsigned)__shfl_down((int)key, o) == key && lane + o < 64;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float other = __shfl_down(a[k], o);
+                    a[k] += same ? other : 0.f;
+                }
+            }
+            // (the shuffle must run with every lane enabled: a lane that has been switched off by a short-circuit
+            // supplies 0 to its neighbour)
+            const unsigned prev = (unsigned)__shfl_up((int)key, 1);
+            const bool head = valid && (lane == 0 || prev != key);
+            if (head) {
+                const unsigned slot = s_slot[lidx];
+                if (slot != BT_WIDE && !use_atomics) {
+                    float4 *o = reinterpret_cast<float4 *>(V.part + ((size_t)j * P.part_k + slot) * 8);
+                    o[0] = make_float4(a[0], a[1], a[2], a[3]);
+                    o[1] = make_float4(a[4], a[5], a[6], a[7]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) atomicAdd(V.sums + 8 * (size_t)j + k, a[k]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 3) s_cnt[tid] = 0u;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_gather(Params P, PlanView V, int use_atomics, float *__restrict__ g_sigmas,
+                                                    float *__restrict__ g_coords, float *__restrict__ g_colors)
+{
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= (unsigned)P.s) return;
+    float o[8];
+    const unsigned i = bwd_gather(P, V, j, use_atomics != 0, o);
+    float *pc = g_coords + (size_t)i * stride2(P), *ps = g_sigmas + (size_t)i * stride3(P), *pk = g_colors + (size_t)i * stride3(P);
+    if (P.flags & GSASR_FLAG_OVERWRITE_GRADS) {
+        pc[0] = o[0]; pc[1] = o[1]; ps[0] = o[2]; ps[1] = o[3]; ps[2] = o[4]; pk[0] = o[5]; pk[1] = o[6]; pk[2] = o[7];
+    } else {   // (one thread per Gaussian: a plain read-modify-write)
+        pc[0] += o[0]; pc[1] += o[1]; ps[0] += o[2]; ps[1] += o[3]; ps[2] += o[4]; pk[0] += o[5]; pk[1] += o[6]; pk[2] += o[7];
+    }
+}
+
+}  // namespace
+
+namespace gsasr_detail {
+
+// mode: 0 = Gaussian-stationary, 1 = tile-stationary with slots, 2 = tile-stationary with atomics
+int bwd_mode(const gsasr_dims *dims, const Layout &L)
+{
+    // Default: whatever the plan was made for (bwd_wants_tile).  Measured on MI355X the two kernels are
+    // within ~10% of each other at every scale -- both are bound by VALU issue: Gaussian-stationary ahead for GSASR's
+    // LR-pixel sized Gaussians at x4 (38.4 vs 38.8 + 5.0 us gather at config 2), tile-stationary ahead from x8 up
+    // (config 4: 1.67 vs 1.79 ms); the tile-stationary one is deterministic and reads the planar gradient autograd returns.
+    const unsigned f = dims->flags;
+    int mode = L.part_k > 0 ? 1 : 0;      // a plan with slots was made for the tile-stationary kernel (bwd_wants_tile)
+    if (f & GSASR_FLAG_BWD_GAUSSIAN) mode = 0;
+    else if (f & GSASR_FLAG_BWD_ATOMIC) mode = 2;
+    else if (f & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_CHW_GRAD)) mode = 1;
+    else if (bwd_env()) mode = bwd_env() - 1;
+    if (L.part_k == 0 && mode == 1) mode = (f & GSASR_FLAG_CHW_GRAD) ? 2 : 0;   // a forward-only plan has no slots
+    return mode;
+}
+
+// Backward of the splat.  With `gather` the kernel-frame gradients are written (or added) to g_*; without it a
+// tile-stationary run stops after the tile kernel and the caller fuses the gather into its next kernel
+// (k_prologue_bwd_gather) -- *mode_out tells which kernel ran.
+int splat_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_img, float *g_sigmas,
+                   float *g_coords, float *g_colors, const gsasr_dims *dims, const void *workspace, size_t workspace_bytes,
+                   void *stream, bool gather, int *mode_out)
+{
+    Layout L;
+    if (int rc = check_ws(dims, workspace, workspace_bytes, L)) return rc;
+    const int mode = bwd_mode(dims, L);
+    if (mode_out) *mode_out = mode;
+    if (dims->flags & GSASR_FLAG_FORWARD_ONLY) return fail(GSASR_ERR_PLAN, "the plan was made with GSASR_FLAG_FORWARD_ONLY: it holds no backward records");
+    if (dims->s == 0) return GSASR_OK;
+    if (gather && (!g_sigmas || !g_coords || !g_colors)) return fail(GSASR_ERR_ARG, "null pointer");
+    if (mode == 0 && (dims->flags & GSASR_FLAG_CHW_GRAD))
+        return fail(GSASR_ERR_ARG, "GSASR_FLAG_CHW_GRAD needs the tile-stationary backward");
+    hipStream_t st = (hipStream_t)stream;
+    const Params P = make_params(dims, L);
+    const PlanView V = make_view(L, const_cast<void *>(workspace));
+    const int rows = dims->row1 - dims->row0;
+    if (rows > 0 && !grad_img) return fail(GSASR_ERR_ARG, "null pointer");
+    if (mode == 0) {
+        if (!sigmas || !coords || !colors || !g_sigmas || !g_coords || !g_colors) return fail(GSASR_ERR_ARG, "null pointer");
+        if (rows == 0) {  // empty band: the gradient is zero
+            if (dims->flags & GSASR_FLAG_OVERWRITE_GRADS) {
+                const size_t e3 = (dims->flags & GSASR_FLAG_STRIDE8) ? 0 : sizeof(float) * 3 * (size_t)dims->s;
+                if (!e3) {
+                    HIP_TRY(hipMemsetAsync(g_sigmas, 0, sizeof(float) * 8 * (size_t)dims->s, st));   // one packed [s,8] array
+                } else {
+                    HIP_TRY(hipMemsetAsync(g_sigmas, 0, e3, st));
+                    HIP_TRY(hipMemsetAsync(g_coords, 0, sizeof(float) * 2 * (size_t)dims->s, st));
+                    HIP_TRY(hipMemsetAsync(g_colors, 0, e3, st));
+                }
+            }
+            return GSASR_OK;
+        }
+        // Eight Gaussians per wave (k_render_bwd8) where windows are small -- below 32 HR pixels per Gaussian: GSASR at x4 and
+        // below, any density -- and the slab's byte offsets fit 32 bits; one wave per Gaussian otherwise, and on request
+        // (development switch GSASR_SPLAT_BWD8=0 / 1).
+        static const int bwd8_env = dev_switch("GSASR_SPLAT_BWD8") ? atoi(dev_switch("GSASR_SPLAT_BWD8")) : -1;
+        const bool small_windows = (double)rows * (double)dims->w < BWD_UNROLL_MIN * (double)dims->s;
+        const bool fits32 = (double)rows * (double)dims->w * 12.0 < 4294967295.0;
+        if (fits32 && (bwd8_env == 1 || (bwd8_env != 0 && small_windows))) {
+            const dim3 grid8((unsigned)(((size_t)dims->s * 8 + 255) / 256)), block8(256);
+            if (P.bounded) hipLaunchKernelGGL(k_render_bwd8<true>, grid8, block8, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
+            else hipLaunchKernelGGL(k_render_bwd8<false>, grid8, block8, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
+            HIP_TRY(hipGetLastError());
+            return GSASR_OK;
+        }
+        const dim3 grid((unsigned)((dims->s + BWD_WAVES - 1) / BWD_WAVES)), block(64 * BWD_WAVES);
+        // Two instantiations of the same sweep (identical results): with the two-trip unrolled loop (88 VGPRs, 5 waves
+        // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
+        // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
+        const bool unroll = (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
+        // (Measured dead ends, git history: two Gaussians per wave one after the other, side by side in half waves, and --
+        // round 3 -- sharing every gradient load over the union of their windows: 44-50 us against 37 us at config 2; rows
+        // or a cell's window staged in LDS; a planar-gradient sweep.  A wave's life is its chain of dependent round trips:
+        // what helped was running the sweep one trip ahead)
+#define GSASR_BWD(B, U) hipLaunchKernelGGL((k_render_bwd<B, U>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors)
+        if (P.bounded) { if (unroll) GSASR_BWD(true, true); else GSASR_BWD(true, false); }
+        else { if (unroll) GSASR_BWD(false, true); else GSASR_BWD(false, false); }
+#undef GSASR_BWD
+        HIP_TRY(hipGetLastError());
+        return GSASR_OK;
+    }
+    if (L.part_k == 0)
+        // the atomic variant, or a tile-stationary backward asked of a plan that was not made for it: the plan may have
+        // left the accumulators alone (k_bin zeroes them only where it knows they will be used)
+        HIP_TRY(hipMemsetAsync(V.sums, 0, (size_t)dims->s * 32, st));
+    if (rows > 0) {
+        const int bth = 1 << P.bt_hlog;
+        const int tiles_x = (dims->w + BT_W - 1) / BT_W, tiles_y = (rows + bth - 1) / bth;
+        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block((unsigned)BT_THREADS << (P.bt_hlog - 4));
+        // small rounds + five waves per SIMD from 32 HR pixels per Gaussian up (where this kernel is the default)
+        const bool sparse = (double)rows * (double)dims->w >= 32.0 * (double)dims->s;
+#define GSASR_BT(B, C, H) hipLaunchKernelGGL((k_render_bwd_tile<B, C, H>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2)
+#define GSASR_BT2(B, C) do { if (P.bt_hlog == 5) GSASR_BT(B, (C) / 2, 5); else GSASR_BT(B, C, 4); } while (0)
+        if (P.bounded) { if (sparse) GSASR_BT2(true, 4 / BT_WAVES); else GSASR_BT2(true, 8 / BT_WAVES); }
+        else { if (sparse) GSASR_BT2(false, 4 / BT_WAVES); else GSASR_BT2(false, 8 / BT_WAVES); }
+#undef GSASR_BT2
+#undef GSASR_BT
+        HIP_TRY(hipGetLastError());
+    }
+    if (gather) {
+        // (an empty band left no slots behind: the gather then only sees the zero accumulators)
+        Params Pg = P;
+        if (rows == 0) Pg.part_k = 0;
+        hipLaunchKernelGGL(k_bwd_gather, dim3((unsigned)((dims->s + 255) / 256)), dim3(256), 0, st, Pg, V,
+                           (int)(mode == 2 || rows == 0), g_sigmas, g_coords, g_colors);
+        HIP_TRY(hipGetLastError());
+    }
+    return GSASR_OK;
+}
+
+}  // namespace gsasr_detail
+
+extern "C" {
+
+int gsasr_splat_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_img,
+                         float *g_sigmas, float *g_coords, float *g_colors, const gsasr_dims *dims,
+                         const void *workspace, size_t workspace_bytes, void *stream)
+{
+    return splat_backward(sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_colors, dims, workspace, workspace_bytes,
+                          stream, true, nullptr);
+}
+
+}  // extern "C"

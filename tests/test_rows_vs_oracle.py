@@ -352,6 +352,21 @@ def test_cross_fuzz_large_and_thin_images(dev):
     assert "60 cases ok" in r.stdout
 
 
+@pytest.mark.parametrize("bwd8", ["0", "1"], ids=["wave-per-gaussian-everywhere", "eight-per-wave-everywhere"])
+def test_cross_fuzz_both_gaussian_stationary_backwards(bwd8, dev):
+    """the Gaussian-stationary backward has two kernels since round 5 -- one wave per Gaussian (k_render_bwd) and eight
+    Gaussians per wave (k_render_bwd8, the default below 32 HR pixels per Gaussian): the same fuzz with each of them forced
+    on EVERY case (development switch GSASR_SPLAT_BWD8 under GSASR_SPLAT_DEV=1), windows of hundreds of pixels included"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSASR_SPLAT_DEV="1", GSASR_SPLAT_BWD8=bwd8)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_cross.py"), "40", "23"], capture_output=True, text=True,
+                       timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "40 cases ok" in r.stdout
+
+
 def test_sixteen_million_gaussians_properties(dev):
     """tools/big_n_check.py at 1024^2 LR x 16 Gaussians per LR pixel x4 (16 777 216 Gaussians on 4096^2): per-Gaussian
     gradients independent of the other Gaussians (both backward kernels), forward additive over a split"""

@@ -850,7 +850,7 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
         in_box, swept, vfrac = pair_rates(st, kern, a.cutoff)
     tau_eff, k_box = effective_tau(st, a.cutoff)
     h_lr, w_lr, scale, desc = CONFIGS[config]
-    traffic = None
+    traffic, pmc = None, {}
     try:   # HBM bytes per launch of the dominant stage's kernels, replayed from the committed counter passes of this config
         import json
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")))
@@ -867,8 +867,9 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
            "roofline": {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
                         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
                         "traffic": traffic,
-                        "traffic_source": ("profiles/pmc_latest.json (REPLAYED from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                           "this config, all kernels of the stage; not counted in this run)" if traffic is not None else None),
+                        "traffic_source": (f"profiles/pmc_latest.json (REPLAYED from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                           f"{pmc.get('_tag', '?')} of this config, collected on build {pmc.get('_build', '?')}, all kernels of the "
+                                           "stage; not counted in this run)" if traffic is not None else None),
                         "valu_frac": vfrac, "pairs_in_swept_window": swept, "pairs_in_dmax_box": in_box}}
     del st
     torch.cuda.empty_cache()

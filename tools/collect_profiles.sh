@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export GSASR_SPLAT_DEV=1   # the GSASR_SPLAT_* A/B switches below are read only with it
 BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extras"
 sq="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU"
 pass() {   # pass <name> "<counters>" <command...>: one counters-only run -> $OUT/<name>.txt
@@ -57,6 +58,7 @@ python $R/tools/rocpd_summary.py /tmp/kt216_$TAG/kt_results.db --skip 1 > $OUT/k
 for cfg in c3 c4 c2x16; do
   pass pmc_fetch_$cfg "FETCH_SIZE" $BENCH --config $cfg --steps 5 --warmup 2
   pass pmc_write_$cfg "WRITE_SIZE" $BENCH --config $cfg --steps 5 --warmup 2
+  pass pmc_sq_$cfg "$sq" $BENCH --config $cfg --steps 5 --warmup 2
 done
 # 4. the plain bench line (with exact / dropin / cpu_baseline / the x12, x8 and 16-per-LR-pixel legs)
 cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
@@ -92,3 +94,27 @@ python tools/autograd_floor.py > $OUT/autograd_floor.txt 2>&1
 python tools/rho_conditioning.py > $OUT/rho_conditioning.txt 2>&1
 python bench.py --no-cpu-baseline --config c2x16 > $OUT/bench_c2x16.json 2>> $OUT/bench.err
 cat $OUT/dropin_profile.txt $OUT/autograd_floor.txt | grep -v amdgpu.ids
+
+# 9. round 5: the reference's published workload, the tile lists against the search, what-if builds, hipGraph replay against eager
+cd /tmp
+for c in 0 -1; do
+  rocprofv3 --kernel-trace --stats -d /tmp/pub${c}_$TAG -o kt -- python $R/tools/published_run.py --cutoff $c 2> /dev/null | grep "ms per plan" > $OUT/published_run_$c.txt
+  python $R/tools/rocpd_summary.py /tmp/pub${c}_$TAG/kt_results.db --skip 2 > $OUT/kernel_stats_published_$c.txt
+done
+pass pmc_sq_published "$sq" python $R/tools/published_run.py --cutoff 0 --calls 3
+cd $R
+for cfg in c2 c2x16 c5; do
+  python bench.py --no-cpu-baseline --no-extras --no-live-pmc --no-graph --config $cfg > $OUT/bench_${cfg}_default.json 2>> $OUT/bench.err
+  GSASR_SPLAT_LISTS=0 python bench.py --no-cpu-baseline --no-extras --no-live-pmc --no-graph --config $cfg > $OUT/bench_${cfg}_search.json 2>> $OUT/bench.err
+  GSASR_SPLAT_LISTS=1 python bench.py --no-cpu-baseline --no-extras --no-live-pmc --no-graph --config $cfg > $OUT/bench_${cfg}_lists.json 2>> $OUT/bench.err
+done
+for f in $OUT/bench_c*_default.json $OUT/bench_c*_search.json $OUT/bench_c*_lists.json; do echo -n "$(basename $f) "; python -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],4), {k:round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items()})"; done > $OUT/lists_ab.txt
+cat $OUT/lists_ab.txt
+bash tools/whatif.sh > $OUT/whatif.txt 2>&1; cat $OUT/whatif.txt
+hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_exp.hip -o /tmp/mfma_exp && /tmp/mfma_exp > $OUT/mfma_exp.txt 2>&1
+# hipGraph replay against eager launches of the same five-kernel step: per-kernel durations and the idle gaps in front of them
+cd /tmp
+rocprofv3 --kernel-trace -d /tmp/tl_eager_$TAG -o kt -- python $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extras --no-live-pmc --no-graph > /dev/null 2>&1
+rocprofv3 --kernel-trace -d /tmp/tl_graph_$TAG -o kt -- python $R/tools/graph_replay.py > /dev/null 2>&1
+(echo "== eager launches"; python $R/tools/timeline.py /tmp/tl_eager_$TAG/kt_results.db; echo "== hipGraph replay of the same step"; python $R/tools/timeline.py /tmp/tl_graph_$TAG/kt_results.db) > $OUT/graph_vs_eager_timeline.txt 2>&1
+cat $OUT/graph_vs_eager_timeline.txt

@@ -35,7 +35,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     d = json.load(open(p))
-    for k, name in (("k_render_fwd", "k_render_fwd2<true, 1>"), ("k_render_bwd", "k_render_bwd<true")):
+    for k, name in (("k_render_fwd", "k_render_fwd"), ("k_render_bwd", "k_render_bwd<true")):
         f = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch.txt"), name, "FETCH_SIZE")
         w = grab(os.path.join(ROOT, "profiles", f"{tag}_pmc_write.txt"), name, "WRITE_SIZE")
         d[k].update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes=int((2 * f + w) * 1024))
@@ -46,7 +46,12 @@ def main():
             act = grab_any(sq, name, "SQ_ACTIVE_INST_VALU")
             busy = grab_any(sq, name, "SQ_BUSY_CYCLES")
             insts = grab_any(sq, name, "SQ_INSTS_VALU")
-            d[k].update(valu_busy=round(4.0 * act / (32.0 * busy), 4), valu_insts=int(insts * 32))
+            # VALU issue occupancy (the ACTIVE_INST formula read above 1 on the wide / tile kernels): every
+            # wave-level VALU instruction holds its SIMD's issue port for at least 4 cycles (tools/valu_rate.hip: v_fma_f32 4.4,
+            # v_pk_fma_f32 4.7, v_exp_f32 8.1), so  insts x 4 / (1024 SIMDs x busy cycles)  is a LOWER bound of the busy
+            # fraction and cannot exceed 1; the old figure stays beside it as valu_active_quadcycles
+            d[k].update(valu_busy=round(insts * 32.0 * 4.0 / (1024.0 * busy), 4), valu_insts=int(insts * 32),
+                        valu_active_quadcycles=round(4.0 * act / (32.0 * busy), 4))
     # the x12, x8 and 16-per-LR-pixel legs of the bench line (same passes at those configs, when collected): HBM bytes per
     # launch of every kernel of the stage, {forward: .., backward: ..}; the tile-stationary backward counts its gather
     legs = {}
@@ -79,9 +84,16 @@ def main():
         d["configs"] = legs
         d["_configs_source"] = f"profiles/{tag}_pmc_fetch_<config>.txt + {tag}_pmc_write_<config>.txt, same method; backward = render kernel + gather"
     d["_source"] = re.sub(r"r\d\d_", tag + "_", d["_source"])
-    d["_valu_method"] = ("valu_busy = 4 * SQ_ACTIVE_INST_VALU / (32 * SQ_BUSY_CYCLES), both per shader-engine averages from "
-                         f"profiles/{tag}_pmc_sq.txt (quad-cycle units; 32 SIMDs per SE); valu_insts = wave-level VALU "
-                         "instructions per launch (SQ_INSTS_VALU x 32 SE instances)")
+    d["_valu_method"] = ("valu_busy = SQ_INSTS_VALU x 32 (SE instances) x 4 cycles / (1024 SIMDs x SQ_BUSY_CYCLES): a lower bound of the "
+                         f"VALU issue occupancy that cannot exceed 1 (profiles/{tag}_pmc_sq.txt); valu_active_quadcycles = the rounds 1-4 "
+                         "figure 4 * SQ_ACTIVE_INST_VALU / (32 * SQ_BUSY_CYCLES), uncalibrated (reads > 1 on some kernels); valu_insts = "
+                         "wave-level VALU instructions per launch")
+    try:
+        import subprocess
+        d["_build"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, text=True).strip()
+    except Exception:
+        pass
+    d["_tag"] = tag
     json.dump(d, open(p, "w"), indent=1)
     print(json.dumps(d, indent=1))
 
