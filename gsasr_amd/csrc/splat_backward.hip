@@ -958,13 +958,14 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
             }
             return GSASR_OK;
         }
-        // Eight Gaussians per wave (k_render_bwd8) where windows are small -- below 32 HR pixels per Gaussian: GSASR at x4 and
-        // below, any density -- and the slab's byte offsets fit 32 bits; one wave per Gaussian otherwise, and on request
-        // (development switch GSASR_SPLAT_BWD8=0 / 1).
+        // Eight Gaussians per wave (k_render_bwd8): built in round 5, parity-green, and SLOWER than one wave per Gaussian --
+        // config 2 39.4 vs 30.7 us, 16 Gaussians per LR pixel 475 vs 401, the config-5 canvas 271 vs 235
+        // (profiles/r05_bwd8.txt): the eight windows of a wave differ (a wave runs max strips x max row pairs: 52 trips for a
+        // mean of 30) and its trips are dependent round trips.  Kept behind the development switch GSASR_SPLAT_BWD8=1 (slabs
+        // whose byte offsets fit 32 bits), exercised by tests/test_rows_vs_oracle.py.
         static const int bwd8_env = dev_switch("GSASR_SPLAT_BWD8") ? atoi(dev_switch("GSASR_SPLAT_BWD8")) : -1;
-        const bool small_windows = (double)rows * (double)dims->w < BWD_UNROLL_MIN * (double)dims->s;
         const bool fits32 = (double)rows * (double)dims->w * 12.0 < 4294967295.0;
-        if (fits32 && (bwd8_env == 1 || (bwd8_env != 0 && small_windows))) {
+        if (fits32 && bwd8_env == 1) {
             const dim3 grid8((unsigned)(((size_t)dims->s * 8 + 255) / 256)), block8(256);
             if (P.bounded) hipLaunchKernelGGL(k_render_bwd8<true>, grid8, block8, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);
             else hipLaunchKernelGGL(k_render_bwd8<false>, grid8, block8, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors);

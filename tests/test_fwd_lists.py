@@ -39,7 +39,7 @@ def test_lists_equal_search_and_oracle(gpp, scale, dmax, dev):
     ref = imgs[(_cabi.FLAG_FWD_NARROW, -1)]
     assert bool(torch.isfinite(ref).all())
     for k, v in imgs.items():
-        assert float((v - ref).abs().max()) <= 3e-6 * max(1.0, float(ref.abs().max())), k
+        assert float((v - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), k
     rows = (H // 2 - 3, H // 2 + 5)
     want = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, dmax, rows=rows)
     for k, v in imgs.items():

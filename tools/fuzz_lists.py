@@ -78,7 +78,7 @@ for case in range(cases):
     assert bool(torch.isfinite(ref).all()), what
     for k, v in imgs.items():
         e = float((v - ref).abs().max()) / top
-        assert np.isfinite(e) and e <= 3e-6, (what, k, e)
+        assert np.isfinite(e) and e <= 1e-5, (what, k, e)       # (same terms in another order: fp32 summation noise of ~100 terms per pixel)
         worst["lists_vs_search"] = max(worst["lists_vs_search"], e)
     # ... and the oracle on up to three rows of the band
     pick = sorted(set(int(x) for x in rng.integers(rows[0], rows[1], 3)))
