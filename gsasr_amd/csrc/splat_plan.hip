@@ -408,9 +408,12 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     const bool valid = i < P.s;
     unsigned c[FUSED_SCAN ? FUSED_PER_THREAD : 1];   // this thread's share of the per-cell counters (scan below)
     if (FUSED_SCAN) {
+        // (requested COALESCED -- counter k * 256 + t by thread t: four cache lines per wave and load instead of 64 with the
+        // consecutive-per-thread order the scan wants -- and handed over through LDS further down, once the Gaussian's own
+        // loads have been issued as well)
 #pragma unroll
         for (int k = 0; k < FUSED_PER_THREAD; ++k) {
-            const int q = (int)threadIdx.x * FUSED_PER_THREAD + k;
+            const int q = k * 256 + (int)threadIdx.x;
             c[k] = q < P.ncells + 1 + NDEAD ? V.cell_count[count_index(q, P.ncells, P.dead_off)] : 0u;
         }
     }
@@ -430,6 +433,14 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         sx = sigmas[i3 + 0]; sy = sigmas[i3 + 1]; rho = sigmas[i3 + 2];
         x = coords[i2 + 0]; y = coords[i2 + 1];
         col0 = colors[i3 + 0]; col1 = colors[i3 + 1]; col2 = colors[i3 + 2];
+    }
+    if constexpr (FUSED_SCAN) {     // transpose the counters: thread t now holds t * 17 .. t * 17 + 16
+#pragma unroll
+        for (int k = 0; k < FUSED_PER_THREAD; ++k) s_start[k * 256 + (int)threadIdx.x] = c[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < FUSED_PER_THREAD; ++k) c[k] = s_start[(int)threadIdx.x * FUSED_PER_THREAD + k];
+        // (s_start is rewritten only behind the scan's own barrier further down)
     }
     // The cutoff the windows are built with (adapt_kcut): from the largest cell count -- every block reduces the histogram it
     // holds anyway (FUSED_SCAN), or reads what the scan kernels left in the header.

@@ -31,6 +31,27 @@ def test_producer_contracts_cpu():
     assert not torch.allclose(p[0], q[0]) and torch.allclose(p[1], q[1])
 
 
+def test_fea2gs_architecture_decoder_contract_cpu():
+    """tools/c5_models.Fea2GSDecoder: the reference decoder's architecture at the shipped EDSR-baseline configuration
+    (options/train/paper/train_GSASR_EDSR-Baseline_paper_bicubic_x1_4.yml:64-78; utils/fea2gs.py:451-635) -- parameter count
+    class, output layout and ordering, dependence on the scale vector, windows talking to each other only through the shifted
+    layers, gradients reaching the seeds and the image features"""
+    torch.manual_seed(0)
+    dec = c5_models.Fea2GSDecoder()
+    n = sum(p.numel() for p in dec.parameters())
+    assert 18e6 < n < 21e6, n
+    feat = torch.randn(2, 64, 24, 12, requires_grad=True)                # 2 x 1 windows of 12 x 12
+    p = dec(feat, torch.tensor([4.0, 2.5]))
+    assert p.shape == (2, 16 * 24 * 12, 9)
+    mu = p[0, :, 7:9].detach().reshape(96, 48, 2)
+    cx, cy = (torch.arange(48) + 0.5) / 48, (torch.arange(96) + 0.5) / 96
+    assert (mu[..., 0] - cx[None, :]).abs().max() < 1.0 / 48 and (mu[..., 1] - cy[:, None]).abs().max() < 1.0 / 96
+    q = dec(feat, torch.tensor([2.0, 2.5]))
+    assert not torch.allclose(p[0], q[0]) and torch.allclose(p[1], q[1], atol=1e-6)
+    p[0, :, :7].sum().backward()
+    assert float(dec.seed.grad.abs().max()) > 0 and float(feat.grad[0].abs().max()) > 0 and float(feat.grad[1].abs().max()) == 0.0
+
+
 @pytest.mark.gpu
 def test_batched_step_gradient_equals_per_sample_loop():
     dev = torch.device("cuda:0")

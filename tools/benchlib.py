@@ -706,7 +706,7 @@ def run_c5e2e(args, dev, rank, world, as_leg=False):
     h_lr, w_lr, scale, desc = CONFIGS["c5e2e"]
     B, H, W = 16, int(h_lr * scale), int(w_lr * scale)
     torch.manual_seed(1234 + rank)
-    enc, dec = c5_models.EncoderEDSRShaped().to(dev), c5_models.Fea2GSShaped().to(dev)
+    enc, dec = c5_models.EncoderEDSRShaped().to(dev), c5_models.Fea2GSDecoder().to(dev)
     opt = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=2e-4)
     lq, gt = torch.rand(B, 3, h_lr, w_lr, device=dev), torch.rand(B, 3, H, W, device=dev)
     sizes, scales = [(H, W)] * B, [scale] * B
@@ -763,8 +763,9 @@ def run_c5e2e(args, dev, rank, world, as_leg=False):
            "config": {"workload": desc, "batch": B, "lr": [h_lr, w_lr], "H": H, "W": W, "gaussians_per_sample": 16 * h_lr * w_lr,
                       "dmax": dmax, "producer_parameters": n_params, "loss": float(loss),
                       "parallelism": f"independent replicas x{world}" if world > 1 else "single",
-                      "producers": "tools/c5_models.py: EDSR-baseline-shaped encoder (16 res blocks, 64 ch) + Fea2GS-SHAPED "
-                                   "convolutional stand-in (same interface / layout / ordering; not the reference's attention decoder)"},
+                      "producers": "tools/c5_models.py: EDSR-baseline-shaped encoder (16 res blocks, 64 ch) + the Fea2GS decoder's architecture at "
+                                   "the shipped EDSR-baseline configuration (channel 180, 6 heads, 12x12 windows, 144 seeds, 1 x 2 cross-attention + "
+                                   "6 x 6 self-attention layers, pixel-shuffle 2 x 2, five MLP heads), own code, random init"},
            "rasterizer": {"ms_fwd_bwd_wall": ms_raster, "ms_fwd_bwd_device": dev_raster, "share_of_step": dev_raster / ms,
                           "note": "generate_2D_gaussian_splatting_batch forward + backward alone on the decoder's output "
                                   "(prologue + plan + splat, splat backward + chain rule), events on the launch stream"}}
@@ -773,7 +774,7 @@ def run_c5e2e(args, dev, rank, world, as_leg=False):
         from oracle import gs_oracle, host_ref
         cores = gs_oracle.num_threads()
         torch.set_num_threads(cores)
-        enc_c, dec_c = c5_models.EncoderEDSRShaped(), c5_models.Fea2GSShaped()
+        enc_c, dec_c = c5_models.EncoderEDSRShaped(), c5_models.Fea2GSDecoder()
         enc_c.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
         dec_c.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
         x, y = lq[:1].cpu(), gt[:1].cpu()
