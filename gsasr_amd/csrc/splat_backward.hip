@@ -644,7 +644,10 @@ __device__ __forceinline__ void bt_eval(const PlanView &V, unsigned j, float dm,
 
 // (the 32-row tile runs twice the waves per workgroup with half the chunks each: the same rounds, the same waves per CU under
 // its 27 KB of LDS)
-template <bool BOUNDED, int BT_CHUNKS, int HLOG>
+// LISTS (round 5): the tile's survivors and their quadrants come from the plan's tile list (k_bin's tl_emit: {slot in cell order |
+// test << 31, quadrant mask | slot in part[] << 16}) instead of level 1's walk over the cells around the tile; a tile whose list
+// overflowed its capacity walks as before.
+template <bool BOUNDED, int BT_CHUNKS, int HLOG, bool LISTS>
 __global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_waves_per_eu((BT_CHUNKS * BT_WAVES << (HLOG - 4)) <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
     Params P, PlanView V, const float *__restrict__ grad, int tiles_x, int use_atomics)
 {
@@ -725,7 +728,14 @@ __global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_wav
     }
     const unsigned pex = pin - len;
     const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
-    const unsigned nchunks = (total + 63u) >> 6;
+    // the tile's list, if the plan wrote one that holds everything; else (and for the large class, which no list holds) the walk
+    const unsigned lcnt = LISTS ? (unsigned)__builtin_amdgcn_readfirstlane((int)V.tl_cursor[(size_t)tt * TL_STRIDE]) : 0u;
+    const bool uselist = LISTS && lcnt <= (unsigned)P.tl_cap;
+    const uint2 *__restrict__ ent = V.tl_entries + (size_t)tt * (size_t)P.tl_cap;
+    const unsigned nlarge_c = uselist ? (((unsigned)__builtin_amdgcn_readlane((int)len, nseg - 1) + 63u) >> 6) : 0u;   // chunks of the large segment
+    const unsigned lchunks = (lcnt + 63u) >> 6;
+    const unsigned nchunks = uselist ? lchunks + nlarge_c : (total + 63u) >> 6;
+    const unsigned large_q0 = (unsigned)__builtin_amdgcn_readlane((int)pex, nseg - 1);     // where the large segment starts in the flat walk
     const unsigned long long below = (1ull << lane) - 1ull;
     int rseg = 0;
     __syncthreads();
@@ -737,15 +747,30 @@ __global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_wav
 #pragma unroll
         for (int k = 0; k < BT_CHUNKS; ++k) {
             const unsigned c = base + (unsigned)wv + (unsigned)(WAVES * k);
-            cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
             cw[k] = make_uint2(0x7fffu, 0x7fffu);
+            if (uselist && c < lchunks) {          // a chunk of list entries: cw = the entry itself
+                const unsigned e = c * 64u + (unsigned)lane;
+                cj[k] = 0xffffffffu;
+                if (e < lcnt) {
+                    cw[k] = ent[e];
+                    cj[k] = cw[k].x & 0x7fffffffu;
+                }
+                continue;
+            }
+            if (uselist) {                          // behind the list: the large class alone, walked as ever
+                const unsigned q = large_q0 + (c - lchunks) * 64u + (unsigned)lane;
+                cj[k] = (c < nchunks && q < total) ? (unsigned)__builtin_amdgcn_readlane((int)sbeg, nseg - 1) + (q - large_q0) : 0xffffffffu;
+            } else {
+                cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
+            }
             if (cj[k] != 0xffffffffu) cw[k] = V.win[cj[k]];
         }
 #pragma unroll
         for (int k = 0; k < BT_CHUNKS; ++k) {
+            const bool from_list = uselist && base + (unsigned)wv + (unsigned)(WAVES * k) < lchunks;     // wave-uniform
             const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
             const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
-            const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
+            const bool hit = from_list ? cj[k] != 0xffffffffu : (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
             const unsigned long long m = __ballot(hit);
             if (m == 0ull) continue;
             unsigned at = 0;
@@ -759,7 +784,7 @@ __global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_wav
             int xl[NQY], xh[NQY];
 #pragma unroll
             for (int qy = 0; qy < NQY; ++qy) { xl[qy] = 1; xh[qy] = 0; }
-            if (hit) {
+            if (hit && !from_list) {
                 // per-8-row spans (qspan) when the window has at most eight such bands; a taller window (x12 and up) still has
                 // the forward's per-16-row spans in its window words: both quadrant rows of this tile then share one band
                 uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);
@@ -785,9 +810,13 @@ __global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_wav
                     }
                 }
             }
-            unsigned n_i = 0u;
+            // the quadrants as a mask (bit 4 qy + qx): from the spans just cut, or as the plan's list holds it
+            unsigned qmask = 0u;
 #pragma unroll
-            for (int qy = 0; qy < NQY; ++qy) n_i += (unsigned)max(xh[qy] - xl[qy] + 1, 0);
+            for (int qy = 0; qy < NQY; ++qy)
+                if (xh[qy] >= xl[qy]) qmask |= ((2u << xh[qy]) - (1u << xl[qy])) << (4 * qy);
+            if (from_list) qmask = hit ? (cw[k].y & 0xffffu) : 0u;
+            const unsigned n_i = (unsigned)__builtin_popcount(qmask);
             unsigned inc = n_i;
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned v = (unsigned)__shfl_up((int)inc, o);
@@ -797,18 +826,23 @@ __global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_wav
             if (lane == 63) ib = atomicAdd(&s_cnt[1], inc);
             ib = (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
             if (hit) {
-                s_list[pos] = cj[k] | ((cw[k].x & 0x8000u) << 16);
-                int ntx, wtx0, wty0;
-                const int nt = bt_tile_span(cw[k].x, cw[k].y, P.row0, HLOG, ntx, wtx0, wty0);
-                const unsigned slot = nt <= P.part_k ? (unsigned)((ty - wty0) * ntx + (tx - wtx0)) : BT_WIDE;
+                unsigned slot;
+                if (from_list) {       // (entry = {j | test << 31, mask | slot << 16})
+                    s_list[pos] = cw[k].x;
+                    slot = (cw[k].y >> 16) & 0xffu;
+                } else {
+                    s_list[pos] = cj[k] | ((cw[k].x & 0x8000u) << 16);
+                    int ntx, wtx0, wty0;
+                    const int nt = bt_tile_span(cw[k].x, cw[k].y, P.row0, HLOG, ntx, wtx0, wty0);
+                    slot = nt <= P.part_k ? (unsigned)((ty - wty0) * ntx + (tx - wtx0)) : BT_WIDE;
+                }
                 s_slot[pos] = (unsigned char)slot;
                 unsigned off = ib + inc - n_i;
                 const unsigned last = off + n_i - 1u;
-#pragma unroll
-                for (int qy = 0; qy < NQY; ++qy)
-                    for (int qx = xl[qy]; qx <= xh[qy]; ++qx, ++off)
-                        s_items[off] = (unsigned short)((unsigned)pos | (unsigned)(qy * 4 + qx) << 9 | (off == last ? 0x2000u : 0u));
-                if (n_i == 0u && slot != BT_WIDE && !use_atomics) {   // the ellipse misses the tile: its slot is still read
+                for (unsigned mm = qmask; mm; mm &= mm - 1u, ++off)
+                    s_items[off] = (unsigned short)((unsigned)pos | (unsigned)__builtin_ctz(mm) << 9 | (off == last ? 0x2000u : 0u));
+                // (the walk only: for the Gaussians of its lists the plan zeroes such slots itself, tl_emit)
+                if (!from_list && n_i == 0u && slot != BT_WIDE && !use_atomics) {   // the ellipse misses the tile: its slot is still read
                     float4 *o = reinterpret_cast<float4 *>(V.part + ((size_t)cj[k] * P.part_k + slot) * 8);
                     o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                     o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -998,7 +1032,10 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block((unsigned)BT_THREADS << (P.bt_hlog - 4));
         // small rounds + five waves per SIMD from 32 HR pixels per Gaussian up (where this kernel is the default)
         const bool sparse = (double)rows * (double)dims->w >= 32.0 * (double)dims->s;
-#define GSASR_BT(B, C, H) hipLaunchKernelGGL((k_render_bwd_tile<B, C, H>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2)
+        // (the plan's tile lists serve this kernel when their tiles are its tiles)
+        const bool lists = L.tl_ok && L.tl_hlog == P.bt_hlog;
+#define GSASR_BT(B, C, H) do { if (lists) hipLaunchKernelGGL((k_render_bwd_tile<B, C, H, true>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2); \
+                               else hipLaunchKernelGGL((k_render_bwd_tile<B, C, H, false>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2); } while (0)
 #define GSASR_BT2(B, C) do { if (P.bt_hlog == 5) GSASR_BT(B, (C) / 2, 5); else GSASR_BT(B, C, 4); } while (0)
         if (P.bounded) { if (sparse) GSASR_BT2(true, 4 / BT_WAVES); else GSASR_BT2(true, 8 / BT_WAVES); }
         else { if (sparse) GSASR_BT2(false, 4 / BT_WAVES); else GSASR_BT2(false, 8 / BT_WAVES); }

@@ -337,8 +337,11 @@ inline bool tl_dense(const gsasr_dims *d)
 inline int tl_hlog_for(const gsasr_dims *d)
 {
     if (d->list_cap < 0 || d->s <= 0 || lists_env() == 0) return 0;
-    // by default for dense plans only (tl_dense); an explicit capacity (or the development switch) asks for them anywhere
-    if (d->list_cap == 0 && lists_env() != 1 && !tl_dense(d)) return 0;
+    // by default for dense plans (tl_dense) and for plans whose BACKWARD reads them too -- the tile-stationary kernel on the same
+    // tiles (x8 and up: config 4, the shard's bands): two consumers pay for k_bin's atomics; an explicit capacity (or the
+    // development switch) asks for them anywhere
+    const bool both = !(d->flags & GSASR_FLAG_FORWARD_ONLY) && bwd_wants_tile(d) && fwd_wants_wide(d) == bt_tall(d);
+    if (d->list_cap == 0 && lists_env() != 1 && !tl_dense(d) && !both) return 0;
     const int rows = d->row1 - d->row0;
     if (fwd_wants_wide(d)) return 5;
     const long nsub = (long)((d->w + SUBX - 1) / SUBX) * ((rows + SUBY - 1) / SUBY);

@@ -133,9 +133,10 @@ __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int 
 // 4 (column) + 2 rows x 6 = 16 packed + 4 v_exp_f32 per record PAIR and 128 pixels = 96 cycles against 2 x 64.  The sums of
 // the even and the odd records of a list are kept apart (two accumulators per channel and row) and added at the end; a list
 // of odd length ends in a zero record (colour 0).
-#ifndef FWD_PAIR
-#define FWD_PAIR 1
-#endif
+// Which plans: the dense ones (tl_dense: at least one Gaussian per four pixels -- GSASR's 16 per LR pixel, the reference's published
+// workload) -- measured (profiles/r05_whatif.txt, r05_lists_ab.txt): 16 Gaussians per LR pixel -5% on the forward, the published
+// workload -11%; at one Gaussian per LR pixel (config 2: 40 hits per sub-tile) the 30 extra VGPRs cost two waves per SIMD and
+// the forward +6%, so those keep the pixel-packed evaluation.  -DFWD_PAIR=0 / 1 forces one of them everywhere (what-if builds).
 constexpr int STAGE_F4 = 136;    // float4 per wave's stage: 64 records + a zero record behind each of the two lists (pairs)
 
 __device__ __forceinline__ void stage_put_pair(float4 *stage, int slot, const float4 a, const float4 b)
@@ -187,7 +188,7 @@ __device__ __forceinline__ void fwd_eval_lds_pairs(const float4 *__restrict__ st
 
 // One chunk of a wave's walk: compact the hits' records (ra, rb of the hit lanes; those that need the dmax test behind the
 // others) into the wave's LDS stage and evaluate them on the lane's two pixels from broadcast LDS reads.
-template <bool BOUNDED>
+template <bool BOUNDED, bool PAIR>
 __device__ __forceinline__ void fwd_stage_eval(float4 *stage, bool hit, bool needs, const float4 ra, const float4 rb, int lane, float px,
                                                v2f py, float dmax, v2f &ar, v2f &ag, v2f &ab)
 {
@@ -200,7 +201,7 @@ __device__ __forceinline__ void fwd_stage_eval(float4 *stage, bool hit, bool nee
 #endif
     const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
     if (n0 + n1 == 0) return;
-#if FWD_PAIR
+    if constexpr (PAIR) {
     const int b1 = (n0 + 1) & ~1;     // first slot of the tested list (the lists are padded to whole pairs)
     __builtin_amdgcn_wave_barrier();
     if (hit) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void fwd_stage_eval(float4 *stage, bool hit, bool nee
     ar += (v2f){acc[0].x + acc[0].y, acc[3].x + acc[3].y};
     ag += (v2f){acc[1].x + acc[1].y, acc[4].x + acc[4].y};
     ab += (v2f){acc[2].x + acc[2].y, acc[5].x + acc[5].y};
-#else
+    } else {
     __builtin_amdgcn_wave_barrier();
     if (hit) {
         const int slot = needs ? n0 + __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
@@ -229,14 +230,14 @@ __device__ __forceinline__ void fwd_stage_eval(float4 *stage, bool hit, bool nee
     __builtin_amdgcn_wave_barrier();
     fwd_eval_lds<false>(stage, 0, n0, px, py, dmax, ar, ag, ab);
     if (BOUNDED) fwd_eval_lds<true>(stage, n0, n0 + n1, px, py, dmax, ar, ag, ab);
-#endif
+    }
 }
 
 // One wave, one 8x16 sub-tile at (sx0, sy0): accumulate every Gaussian binned near it into ar/ag/ab
 // (lane = column sx0 + lane%8, rows sy0 + lane/8 and +8).  With nparts > 1 the 64-candidate chunks are
 // dealt round-robin to `nparts` waves and the caller adds their partial sums.
 // LARGE_ONLY: the walk over the "large" class alone (what a list kernel still has to scan: tile lists hold the normal class).
-template <bool BOUNDED, bool LARGE_ONLY = false>
+template <bool BOUNDED, bool PAIR, bool LARGE_ONLY = false>
 __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int sx0, int sy0, int lane,
                                          unsigned part, unsigned nparts, float4 *stage, v2f &ar, v2f &ag, v2f &ab)
 {
@@ -322,7 +323,7 @@ __device__ __forceinline__ void fwd_tile(const Params &P, const PlanView &V, int
             ra = src[0];
             rb = src[1];
         }
-        fwd_stage_eval<BOUNDED>(stage, hit, needs, ra, rb, lane, px, py, P.dmax, ar, ag, ab);
+        fwd_stage_eval<BOUNDED, PAIR>(stage, hit, needs, ra, rb, lane, px, py, P.dmax, ar, ag, ab);
         c = nc; j = nj; bb = nbb; bs = nbs;
     }
 }
@@ -340,7 +341,7 @@ constexpr int COARSE_LIST = 4 * COARSE_CHUNKS * 64;       // candidates per roun
 
 // PARTS = 2: eight waves per workgroup, two per sub-tile taking alternate chunks of the survivor list (images with
 // fewer sub-tiles than the chip has wave slots); the caller adds the two partial sums.
-template <bool BOUNDED, int PARTS>
+template <bool BOUNDED, int PARTS, bool PAIR>
 __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, int bx0, int by0, int wv, int lane,
                                           float4 *stage, unsigned *s_list, unsigned *s_cnt, v2f &ar, v2f &ag, v2f &ab)
 {
@@ -454,7 +455,7 @@ __device__ __forceinline__ void fwd_block(const Params &P, const PlanView &V, in
                     ra = src[0];
                     rb = src[1];
                 }
-                fwd_stage_eval<BOUNDED>(stage, hit, needs, ra, rb, lane, px, py, P.dmax, ar, ag, ab);
+                fwd_stage_eval<BOUNDED, PAIR>(stage, hit, needs, ra, rb, lane, px, py, P.dmax, ar, ag, ab);
                 j = nj; bb = nbb; bs = nbs;
             }
         }
@@ -512,7 +513,7 @@ __device__ __forceinline__ void fwd_store(const Params &P, const PlanView &V, fl
 
 // Two-level walk (fwd_block).  PARTS = 1: large images, the workgroup shape of k_render_fwd.  PARTS = 2: images
 // with fewer sub-tiles than wave slots -- eight waves, two per sub-tile, partial sums combined through LDS.
-template <bool BOUNDED, int PARTS>
+template <bool BOUNDED, int PARTS, bool PAIR>
 __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView V, float *__restrict__ img, int tiles_x)
 {
     const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView 
     __syncthreads();
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
     const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
-    fwd_block<BOUNDED, PARTS>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
+    fwd_block<BOUNDED, PARTS, PAIR>(P, V, bx0, by0, wv, lane, s_stage[wv], s_list, s_cnt, ar, ag, ab);
     const int sub = wv & 3;
     if (PARTS > 1) {   // (fwd_block ends on a barrier)
         if (wv >= 4) {
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // chunk k+1 are in flight while chunk k is evaluated.  No barriers, no shared lists: the four waves of a workgroup only share
 // the tile.  A tile whose list overflowed its capacity is rendered by the one-level search (fwd_tile); the "large" class is
 // scanned by every tile as before.
-template <bool BOUNDED, int PARTS>
+template <bool BOUNDED, int PARTS, bool PAIR>
 __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanView V, float *__restrict__ img, int tiles_x)
 {
     const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanV
         uint2 e_first = q_first + (unsigned)lane < (unsigned)P.tl_cap ? ent[q_first + lane] : make_uint2(0u, 0u);
         const unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)V.tl_cursor[(size_t)t * TL_STRIDE]);
         if (cnt > (unsigned)P.tl_cap) {
-            fwd_tile<BOUNDED, false>(P, V, sx0, by0, lane, part, (unsigned)PARTS, stage, ar, ag, ab);
+            fwd_tile<BOUNDED, PAIR, false>(P, V, sx0, by0, lane, part, (unsigned)PARTS, stage, ar, ag, ab);
         } else {
             const int X = sx0 + (lane & 7);
             const float px = V.px[(P.batch > 1 ? (by0 / P.slot) * P.w : 0) + min(X, P.w - 1)];
@@ -786,12 +787,12 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanV
                 }
                 nq = q + 64u * PARTS;
                 ne = nq + (unsigned)lane < cnt ? ent[nq + lane] : none;
-                fwd_stage_eval<BOUNDED>(stage, chit, cneeds, ca, cb, lane, px, py, P.dmax, ar, ag, ab);
+                fwd_stage_eval<BOUNDED, PAIR>(stage, chit, cneeds, ca, cb, lane, px, py, P.dmax, ar, ag, ab);
             }
             // the large class (half-extent > 128 px) is in nobody's list
             const unsigned nlarge = V.cell_start[P.ncells + 1] - V.cell_start[P.ncells];
             if (__builtin_amdgcn_readfirstlane((int)nlarge) != 0)
-                fwd_tile<BOUNDED, true>(P, V, sx0, by0, lane, part, (unsigned)PARTS, stage, ar, ag, ab);
+                fwd_tile<BOUNDED, PAIR, true>(P, V, sx0, by0, lane, part, (unsigned)PARTS, stage, ar, ag, ab);
         }
     }
     if (PARTS > 1) {
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // Small images (fewer sub-tiles than the chip has wave slots, e.g. the 192x192 training crops of
 // BASELINE config 5): a workgroup = ONE sub-tile, its candidate chunks dealt to all `blockDim/64` waves,
 // partial sums combined through LDS.  Parallelism comes from the Gaussian list instead of from pixels.
-template <bool BOUNDED>
+template <bool BOUNDED, bool PAIR>
 __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V, float *__restrict__ img, int subs_x)
 {
     __shared__ float s_part[16][6][64];
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(1024) void k_render_fwd_split(Params P, PlanView V,
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = (int)(blockDim.x >> 6);
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
-    fwd_tile<BOUNDED>(P, V, sx0, sy0, lane, (unsigned)wv, (unsigned)nw, s_stage[wv], ar, ag, ab);
+    fwd_tile<BOUNDED, PAIR>(P, V, sx0, sy0, lane, (unsigned)wv, (unsigned)nw, s_stage[wv], ar, ag, ab);
     if (wv > 0) {
         s_part[wv][0][lane] = ar.x; s_part[wv][1][lane] = ar.y;
         s_part[wv][2][lane] = ag.x; s_part[wv][3][lane] = ag.y;
@@ -1010,6 +1011,11 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     const int subs_x = (dims->w + SUBX - 1) / SUBX, tiles_y = (rows + SUBY - 1) / SUBY;
     hipStream_t st = (hipStream_t)stream;
     const long nsub = (long)subs_x * tiles_y;
+#ifdef FWD_PAIR
+    const bool pair = FWD_PAIR != 0;
+#else
+    const bool pair = tl_dense(dims);     // record-pair packed evaluation for dense plans (fwd_eval_pair)
+#endif
     if (fwd_wants_wide(dims)) {
         const int wx = (dims->w + 2 * WIDE - 1) / (2 * WIDE), wy = (rows + 2 * WIDE - 1) / (2 * WIDE);
         const dim3 grid((unsigned)wx * (unsigned)wy), block(256);
@@ -1024,35 +1030,26 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         int nw = 2;
         while (nw < 16 && nsub * nw < 8192) nw *= 2;
         const dim3 grid((unsigned)nsub), block((unsigned)nw * 64u);
-        if (P.bounded)
-            hipLaunchKernelGGL(k_render_fwd_split<true>, grid, block, 0, st, P, V, img, subs_x);
-        else
-            hipLaunchKernelGGL(k_render_fwd_split<false>, grid, block, 0, st, P, V, img, subs_x);
-    } else if (L.tl_ok && L.tl_hlog == 4) {
-        // the plan's tile lists (32 x 16-px tiles: the same workgroup tile as the two-level walk, and its two shapes)
-        const int tx4 = (subs_x + 3) / 4;
-        const bool two = nsub < 8192;
-        const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
-        if (P.bounded) {
-            if (two) hipLaunchKernelGGL((k_render_fwd_list<true, 2>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd_list<true, 1>), grid, block, 0, st, P, V, img, tx4);
-        } else {
-            if (two) hipLaunchKernelGGL((k_render_fwd_list<false, 2>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd_list<false, 1>), grid, block, 0, st, P, V, img, tx4);
-        }
+#define GSASR_F1(K, B) do { if (pair) hipLaunchKernelGGL((K<B, true>), grid, block, 0, st, P, V, img, subs_x); \
+                            else hipLaunchKernelGGL((K<B, false>), grid, block, 0, st, P, V, img, subs_x); } while (0)
+        if (P.bounded) GSASR_F1(k_render_fwd_split, true);
+        else GSASR_F1(k_render_fwd_split, false);
+#undef GSASR_F1
     } else {
-        // two-level walk; images with fewer sub-tiles than the chip has wave slots (4096..8191, e.g. the batched canvas
-        // of config 5) get two waves per sub-tile (measured -13% at 4608 sub-tiles, +2..14% above 8192)
+        // the plan's tile lists (32 x 16-px tiles: the same workgroup tile as the two-level walk, and its two shapes), else the
+        // two-level walk; images with fewer sub-tiles than the chip has wave slots (4096..8191, e.g. the batched canvas of
+        // config 5) get two waves per sub-tile (measured -13% at 4608 sub-tiles, +2..14% above 8192)
         const int tx4 = (subs_x + 3) / 4;
-        const bool two = nsub < 8192;
+        const bool two = nsub < 8192, lists = L.tl_ok && L.tl_hlog == 4;
         const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
-        if (P.bounded) {
-            if (two) hipLaunchKernelGGL((k_render_fwd2<true, 2>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd2<true, 1>), grid, block, 0, st, P, V, img, tx4);
-        } else {
-            if (two) hipLaunchKernelGGL((k_render_fwd2<false, 2>), grid, block, 0, st, P, V, img, tx4);
-            else hipLaunchKernelGGL((k_render_fwd2<false, 1>), grid, block, 0, st, P, V, img, tx4);
-        }
+#define GSASR_F3(K, B, T) do { if (pair) hipLaunchKernelGGL((K<B, T, true>), grid, block, 0, st, P, V, img, tx4); \
+                               else hipLaunchKernelGGL((K<B, T, false>), grid, block, 0, st, P, V, img, tx4); } while (0)
+#define GSASR_F2(K) do { if (P.bounded) { if (two) GSASR_F3(K, true, 2); else GSASR_F3(K, true, 1); } \
+                         else { if (two) GSASR_F3(K, false, 2); else GSASR_F3(K, false, 1); } } while (0)
+        if (lists) GSASR_F2(k_render_fwd_list);
+        else GSASR_F2(k_render_fwd2);
+#undef GSASR_F2
+#undef GSASR_F3
     }
     HIP_TRY(hipGetLastError());
     return GSASR_OK;

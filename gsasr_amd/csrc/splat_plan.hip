@@ -298,6 +298,29 @@ __global__ __launch_bounds__(1024) void k_scan_fix(Params P, int n, unsigned *__
 // reaches, from the window words k_bin has just built (bb = bbox[2j], sp = the spans of bands 4..7): exactly the
 // window-rectangle + per-16-row-band column-span test the search kernels apply per sub-tile (fwd_block phase B), refined
 // to quadrant rows by the window's own first and last row.
+// The same from the per-8-row spans (`qs`: k_bin's qspan, present in plans whose backward is the tile-stationary kernel and for
+// windows of at most eight such bands): the cull that kernel's own level 1 applies.
+template <int HLOG>
+__device__ __forceinline__ unsigned tl_mask8(int tx, int ty, const uint4 bb, const uint4 qs, int row0)
+{
+    const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16), r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+    const int q0 = (r0 - row0) >> 3, cu0 = c0 >> 3;
+    constexpr int NQY = 1 << (HLOG - 3);     // quadrant rows per tile
+    unsigned mask = 0u;
+#pragma unroll
+    for (int qy = 0; qy < NQY; ++qy) {
+        const int G = ty * NQY + qy, y0 = row0 + (G << 3);
+        if (!(r0 <= y0 + 7 && r1 >= y0)) continue;
+        const unsigned t = (unsigned)(G - q0) & 7u, sh = (t & 3u) * 8u;
+        const unsigned l = ((t < 4u ? qs.x : qs.z) >> sh) & 0xffu, h = ((t < 4u ? qs.y : qs.w) >> sh) & 0xffu;
+        if (l > h) continue;
+        const int lo = cu0 + (int)l, hi = h == 255u ? (c1 >> 3) : cu0 + (int)h;      // (255 = as far as the window goes)
+        const int a = max(lo - 4 * tx, 0), b = min(hi - 4 * tx, 3);
+        if (a <= b) mask |= ((2u << b) - (1u << a)) << (4 * qy);
+    }
+    return mask;
+}
+
 template <int HLOG>
 __device__ __forceinline__ unsigned tl_mask(int tx, int ty, const uint4 bb, const uint2 sp, int row0)
 {
@@ -337,8 +360,12 @@ __device__ __forceinline__ unsigned tl_mask(int tx, int ty, const uint4 bb, cons
 // config 2's k_bin +10.5 us instead of +6, config 4's plan +165 us instead of +81: the atomics, not the loops, are what costs.)
 constexpr int TLB = 4;
 
+// Plans whose backward is the tile-stationary kernel on the same tiles (P.tl_hlog == P.bt_hlog, slots in use): the entry also carries
+// the Gaussian's slot in part[] for that tile (bits 16..23; BT_WIDE = more tiles than slots: atomics), and a tile of the window's
+// rectangle that the ellipse misses -- no entry -- has its slot zeroed here, because the gather adds every slot of the rectangle.
 template <int HLOG>
-__device__ __forceinline__ void tl_emit(const Params &P, const PlanView &V, bool emit, unsigned j, const uint4 bb, const uint2 sp)
+__device__ __forceinline__ void tl_emit(const Params &P, const PlanView &V, bool emit, unsigned j, const uint4 bb, const uint2 sp,
+                                        const uint4 qs, bool fine8)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -351,6 +378,8 @@ __device__ __forceinline__ void tl_emit(const Params &P, const PlanView &V, bool
         ntile = nx * (((r1 - P.row0) >> HLOG) - tY0 + 1);
     }
     const unsigned ex = j | ((bb.x & 0x8000u) << 16);
+    const bool slots = P.part_k > 0 && P.tl_hlog == P.bt_hlog;
+    const bool wide = !slots || ntile > P.part_k;      // (bt_tile_span counts the same rectangle of the same tiles)
     int ix = 0, iy = 0;
     for (int base = 0; __ballot(base < ntile) != 0ull; base += TLB) {
         unsigned m[TLB], ti[TLB], pos[TLB];
@@ -358,8 +387,17 @@ __device__ __forceinline__ void tl_emit(const Params &P, const PlanView &V, bool
 #pragma unroll
         for (int k = 0; k < TLB; ++k) {
             const bool v = base + k < ntile;
-            m[k] = v ? tl_mask<HLOG>(tX0 + ix, tY0 + iy, bb, sp, P.row0) : 0u;
+            m[k] = !v ? 0u : fine8 ? tl_mask8<HLOG>(tX0 + ix, tY0 + iy, bb, qs, P.row0) : tl_mask<HLOG>(tX0 + ix, tY0 + iy, bb, sp, P.row0);
             ti[k] = (unsigned)((tY0 + iy) * P.tl_ntx + tX0 + ix);
+            if (v) {
+                const unsigned slot = wide ? 0xffu : (unsigned)(base + k);      // tile `base + k` of the window, row-major: bt_tile_span's order
+                if (m[k]) m[k] |= slot << 16;
+                else if (!wide) {      // the ellipse misses this tile of its window: the gather still adds the slot
+                    float4 *o = reinterpret_cast<float4 *>(V.part + ((size_t)j * P.part_k + slot) * 8);
+                    o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
             if (v && ++ix == nx) { ix = 0; ++iy; }
             // lanes with the same tile in this slot: one group, one atomic
             mine[k] = 0ull;
@@ -408,12 +446,11 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     const bool valid = i < P.s;
     unsigned c[FUSED_SCAN ? FUSED_PER_THREAD : 1];   // this thread's share of the per-cell counters (scan below)
     if (FUSED_SCAN) {
-        // (requested COALESCED -- counter k * 256 + t by thread t: four cache lines per wave and load instead of 64 with the
-        // consecutive-per-thread order the scan wants -- and handed over through LDS further down, once the Gaussian's own
-        // loads have been issued as well)
+        // (measured in round 5 and dropped: requesting them coalesced -- counter k * 256 + t by thread t -- and transposing
+        // through LDS costs a barrier more than the 60 cache lines per load it saves: k_bin 9.97 us against 9.4-9.6)
 #pragma unroll
         for (int k = 0; k < FUSED_PER_THREAD; ++k) {
-            const int q = k * 256 + (int)threadIdx.x;
+            const int q = (int)threadIdx.x * FUSED_PER_THREAD + k;
             c[k] = q < P.ncells + 1 + NDEAD ? V.cell_count[count_index(q, P.ncells, P.dead_off)] : 0u;
         }
     }
@@ -423,6 +460,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     float4 recA = make_float4(0.f, 0.f, 0.f, 0.f), recB = recA, finA = recA, finB = recA;
     uint4 bb = make_uint4(0u, 0u, 0u, 0u), bc = bb;
     uint4 qs = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);   // quadrant-row spans: every column unless computed below
+    bool fine8 = false;                                        // ... computed: the tile lists' masks are cut from them
     bool large = false;
     unsigned fb_rx = 0u, fb_ry = 0u;
     float sx = 0.f, sy = 0.f, rho = 0.f, x = 0.f, y = 0.f, col0 = 0.f, col1 = 0.f, col2 = 0.f;
@@ -433,14 +471,6 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
         sx = sigmas[i3 + 0]; sy = sigmas[i3 + 1]; rho = sigmas[i3 + 2];
         x = coords[i2 + 0]; y = coords[i2 + 1];
         col0 = colors[i3 + 0]; col1 = colors[i3 + 1]; col2 = colors[i3 + 2];
-    }
-    if constexpr (FUSED_SCAN) {     // transpose the counters: thread t now holds t * 17 .. t * 17 + 16
-#pragma unroll
-        for (int k = 0; k < FUSED_PER_THREAD; ++k) s_start[k * 256 + (int)threadIdx.x] = c[k];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < FUSED_PER_THREAD; ++k) c[k] = s_start[(int)threadIdx.x * FUSED_PER_THREAD + k];
-        // (s_start is rewritten only behind the scan's own barrier further down)
     }
     // The cutoff the windows are built with (adapt_kcut): from the largest cell count -- every block reduces the histogram it
     // holds anyway (FUSED_SCAN), or reads what the scan kernels left in the header.
@@ -612,6 +642,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                     unsigned l8[2], h8[2];
                     spans(3, q0, q1 - q0 + 1, l8, h8);
                     qs = make_uint4(l8[0], h8[0], l8[1], h8[1]);
+                    fine8 = true;
                 }
                 bb.z = lo4[0]; bb.w = hi4[0];
                 bc.x = lo4[1]; bc.y = hi4[1];
@@ -721,7 +752,7 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
     }
     }
     if constexpr (TLH != 0)   // tile lists: the normal class only (the large one stays a segment every tile scans)
-        tl_emit<TLH == 0 ? 4 : TLH>(P, V, valid && key < (unsigned)P.ncells, j, bb, make_uint2(bc.x, bc.y));
+        tl_emit<TLH == 0 ? 4 : TLH>(P, V, valid && key < (unsigned)P.ncells, j, bb, make_uint2(bc.x, bc.y), qs, fine8);
 }
 
 }  // namespace

@@ -11,6 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -77,3 +78,30 @@ def test_fuzz_lists():
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "cases ok" in r.stdout
+
+
+@pytest.mark.parametrize("scale,wide", [(4.0, 0), (8.0, 1)], ids=["x4-32x16-tiles", "x8-32x32-tiles"])
+@pytest.mark.parametrize("cap", [2048, 64], ids=["lists", "overflowing-lists"])
+def test_tile_backward_from_lists_against_oracle(scale, wide, cap, dev):
+    """the tile-stationary backward reading the plan's tile lists instead of walking the cells around each tile (entries carry the
+    quadrant mask and the Gaussian's slot; k_bin zeroes the slots of tiles its ellipse misses): gradients against the oracle and
+    against the same kernel without lists; slots and atomics; a capacity so small that most tiles fall back to the walk"""
+    from gsasr_amd import _cabi, synthetic
+    from oracle import gs_oracle
+    from test_bwd_tile import per_gaussian_ok
+    sig, xy, col, H, W = synthetic.kernel_inputs(48, 40, scale, seed=41)
+    a, b, c = sig.to(dev), xy.to(dev), col.to(dev)
+    wgt = synthetic.grad_image(H, W, 42)
+    want = gs_oracle.backward_f64(sig.numpy(), xy.numpy(), col.numpy(), wgt.numpy(), 0.2)
+    fw = _cabi.FLAG_FWD_WIDE if wide else _cabi.FLAG_FWD_NARROW
+    got = {}
+    for name, flags, lc in (("lists", _cabi.FLAG_BWD_TILE, cap), ("search", _cabi.FLAG_BWD_TILE, -1),
+                            ("lists-atomic", _cabi.FLAG_BWD_TILE | _cabi.FLAG_BWD_ATOMIC, cap)):
+        plan = _cabi.plan(a, b, c, H, W, 0.2, flags=flags | fw, list_cap=lc)
+        g = [torch.full_like(t, float("nan")) for t in (a, b, c)]
+        _cabi.backward(plan, a, b, c, wgt.to(dev), *g, overwrite=True)
+        got[name] = [t.cpu().numpy() for t in g]
+        for arr, w_, tn in zip(got[name], want, ("sigmas", "coords", "colors")):
+            per_gaussian_ok(arr, w_, tn, rho=sig.numpy()[:, 2])
+    for x, y in zip(got["lists"], got["search"]):
+        assert np.abs(x - y).max() <= 2e-5 * max(1e-30, np.abs(y).max())

@@ -403,3 +403,40 @@ def test_published_workload_bands_against_oracle(dev):
             # (a pixel is a sequential fp32 sum of 2.6e5 terms: sqrt(n) * 2^-24 ~ 3e-5 of the sum is its rounding noise)
             err = float(np.abs(img[r[0]:r[1]].cpu().numpy() - ref).max())
             assert err <= 2e-4 * top, (tau, r, err, top)
+
+
+@pytest.mark.parametrize("config", ["c3", "c4"])
+def test_full_size_scattered_rows_against_oracle(config, dev):
+    """the full-size comparisons of configs 3 and 4 were 16-row bands at two places.  Here single rows
+    scattered over the WHOLE image (tile boundaries, the first and last row, rows that straddle the XCD bands of the launch
+    order) of the default render -- x12 wide forward; x8 wide forward from the plan's tile lists -- against the oracle with
+    every Gaussian, and at config 4 the gradient of those rows alone through the library's default backward"""
+    from gsasr_amd import _cabi, synthetic
+    from oracle import gs_oracle
+    from test_bwd_tile import per_gaussian_ok
+    h_lr, scale = (512, 12.0) if config == "c3" else (1024, 8.0)
+    sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, h_lr, scale, seed=0)
+    s, c, k = sig.numpy(), xy.numpy(), col.numpy()
+    a, b, d = sig.to(dev), xy.to(dev), col.to(dev)
+    plan = _cabi.plan(a, b, d, H, W, 0.1, flags=_cabi.FLAG_FORWARD_ONLY if config == "c3" else 0)
+    img = torch.empty(H, W, 3, device=dev)
+    _cabi.forward(plan, img, overwrite=True)
+    rng = np.random.default_rng(7)
+    rows = sorted(set([0, H - 1, H // 8 - 1, H // 8, 5 * H // 8 + 31, 5 * H // 8 + 32] + [int(r) for r in rng.integers(0, H, 4)]))
+    for r in rows:
+        ref = gs_oracle.forward_f64(s, c, k, H, W, 0.1, rows=(r, r + 1))
+        assert np.abs(img[r:r + 1].cpu().numpy() - ref).max() <= IMG_ATOL, (config, r)
+    if config == "c4":
+        # the gradient of three scattered rows: upstream gradient zero everywhere else, whole-image default backward
+        pick = rows[2:5]
+        wgt = torch.zeros(H, W, 3)
+        full = synthetic.grad_image(H, W, 11)
+        want = None
+        for r in pick:
+            wgt[r] = full[r]
+            g1 = gs_oracle.backward_f64(s, c, k, full[r:r + 1].contiguous().numpy(), 0.1, h=H, rows=(r, r + 1))
+            want = g1 if want is None else tuple(x + y for x, y in zip(want, g1))
+        g = [torch.empty_like(t) for t in (a, b, d)]
+        _cabi.backward(plan, a, b, d, wgt.to(dev), *g, overwrite=True)
+        for got, w_, name in zip(g, want, ("sigmas", "coords", "colors")):
+            per_gaussian_ok(got.cpu().numpy(), w_, name, rho=s[:, 2])

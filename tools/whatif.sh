@@ -4,9 +4,9 @@
 #   BUILD_ONLY=1 bash tools/whatif.sh      (anywhere hipcc is)  then   bash tools/whatif.sh > gpurun_out/whatif.txt   (on the GPU box)
 #     FWD_EXP_NOEVAL   records found, fetched and staged, one per chunk evaluated      FWD_EXP_NOSTORE  no image store
 #     BWD_EXP_NOLOAD   synthetic gradient values instead of the loads of a trip        BWD_EXP_NOMATH   loads consumed by adds, no trip arithmetic
-#     FWD_PAIR=0       the pixel-packed forward evaluation of rounds 1-4 instead of the record-pair packed one
+#     FWD_PAIR=0 | 1   the pixel-packed forward evaluation of rounds 1-4 | the record-pair packed one, everywhere (default: by density)
 cd "$(dirname "$0")/.."
-for v in "base" "noeval -DFWD_EXP_NOEVAL" "nostore -DFWD_EXP_NOSTORE" "noeval_nostore -DFWD_EXP_NOEVAL -DFWD_EXP_NOSTORE" "nopair -DFWD_PAIR=0" \
+for v in "base" "noeval -DFWD_EXP_NOEVAL" "nostore -DFWD_EXP_NOSTORE" "noeval_nostore -DFWD_EXP_NOEVAL -DFWD_EXP_NOSTORE" "nopair -DFWD_PAIR=0" "pair -DFWD_PAIR=1" \
          "noload -DBWD_EXP_NOLOAD" "nomath -DBWD_EXP_NOMATH" "noload_nomath -DBWD_EXP_NOLOAD -DBWD_EXP_NOMATH"; do
   set -- $v; name=$1; shift
   # (built where hipcc is: tools/bin/ travels with gpurun, so binaries made in the authoring container are reused on the GPU box)
