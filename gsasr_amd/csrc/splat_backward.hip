@@ -87,16 +87,19 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
     R.kb2 = fmaf(g.b2, v.y, R.kb2);
 }
 
-template <bool TEST, int LXLOG, bool UNROLL>
+// LX = 16 / 21 / 32 / 64 columns: 4 / 3 / 2 / 1 row slots of lanes, i.e. 8 / 6 / 4 / 2 rows per trip.  LX = 21 (round 5; 63 lanes, the
+// last one idle) is for the windows of 17..21 columns -- over half of GSASR's at x4 since the data-derived cutoff narrowed them:
+// 6 rows per trip instead of 4, so a 20-row window takes 4 trips instead of 5-6 and 21 of 21 columns work instead of 21 of 32.
+template <bool TEST, int LX, bool UNROLL>
 __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int lane, const Params &P,
                                           const float *__restrict__ pxt, const float *__restrict__ pyt,
                                           const float *__restrict__ grad, float x, float y, float cr, float cg,
                                           float cb, float cinv, float rho, float kappa, float isx, float isy,
                                           float *spy, float (&acc)[8])
 {
-    constexpr int LX = 1 << LXLOG, RPI = 64 >> LXLOG;
+    constexpr int RPI = 64 / LX, RPT = 2 * RPI;        // row slots of lanes; rows per trip
     constexpr float HALF_LOG2E = 0.72134752044448170368f;
-    const int col = lane & (LX - 1), rsub = lane >> LXLOG;
+    const int col = lane % LX, rsub = lane / LX;
     const unsigned pitchb = (unsigned)P.w * 12u;   // bytes per gradient row (< 2^19); all offsets below are unsigned 32 x 32 -> 64
     const float nK1 = -HALF_LOG2E * cinv;
     // issued together with the px load below: one round trip for both tables instead of two dependent ones
@@ -107,7 +110,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
         const float dx = pxt[X] - x;
         // lanes outside the window (or, with TEST, outside the dmax box in x) are switched off through K0:
         // the exponent becomes -inf, v = 0 exactly, and every product with it is 0
-        const bool inx = cc < bw && (!TEST || fabsf(dx) <= P.dmax);
+        const bool inx = cc < bw && (LX * RPI == 64 || rsub < RPI) && (!TEST || fabsf(dx) <= P.dmax);
         const float u = dx * isx, rho_u = rho * u;
         const float K0 = inx ? -HALF_LOG2E * u * u : -INFINITY;
         BwdRow R;
@@ -132,8 +135,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 const_cast<char *>(blk), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
             int soff = 0;
             // trip counts up front: the loops below count down (one scalar add + compare + branch per iteration)
-            constexpr int TRIP_SHIFT = 7 - LXLOG;                 // log2(rows per trip) = log2(2 RPI)
-            const int nrows = rend - rb + 1, ntrip = nrows >> TRIP_SHIFT;
+            const int nrows = rend - rb + 1, ntrip = nrows / RPT;
             const int voff_b = voff + halfb;
             // Lanes outside the window sit the trips out (exec mask): the backward is co-limited by the CU's
             // vector-memory pipe (two 768-byte loads per trip and wave, four SIMDs behind one L1), and idle
@@ -186,8 +188,8 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 bwd_trip<TEST, false>(R, bwd_load(rsrc, voff, voff_b, soff), n0, w0, true, true, K0, nK1, rho_u, cr,
                                       cg, cb, P.dmax);
             }
-            if (nrows & ((1 << TRIP_SHIFT) - 1)) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
-                const int Yb = rb + (ntrip << TRIP_SHIFT);
+            if (nrows % RPT) {  // ragged last trip: rows past the window are masked (reads past the slab give 0)
+                const int Yb = rb + ntrip * RPT;
                 const int Ya = Yb + rsub, Yc = Ya + RPI;
                 const int ia = min(Ya, rend) - rb, ic = min(Yc, rend) - rb;
                 const v2f n0 = {spy[ia], spy[ic]};
@@ -325,9 +327,10 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
     if (!empty) {
 #define GSASR_SWEEP(T, L) \
     bwd_sweep<T, L, UNROLL>(c0, bw, r0, r1, lane, P, V.px + G.fin[5], V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
-        if (bw <= 16) { if (test) GSASR_SWEEP(true, 4); else GSASR_SWEEP(false, 4); }
-        else if (bw <= 32) { if (test) GSASR_SWEEP(true, 5); else GSASR_SWEEP(false, 5); }
-        else { if (test) GSASR_SWEEP(true, 6); else GSASR_SWEEP(false, 6); }
+        if (bw <= 16) { if (test) GSASR_SWEEP(true, 16); else GSASR_SWEEP(false, 16); }
+        else if (bw <= BWD_LX21_MAX) { if (test) GSASR_SWEEP(true, 21); else GSASR_SWEEP(false, 21); }
+        else if (bw <= 32) { if (test) GSASR_SWEEP(true, 32); else GSASR_SWEEP(false, 32); }
+        else { if (test) GSASR_SWEEP(true, 64); else GSASR_SWEEP(false, 64); }
 #undef GSASR_SWEEP
         bwd_scale(a, fa.x, fa.w, fb.x);
         d = wave_sum8(a, lane, red);   // lane 8k now holds gradient component k

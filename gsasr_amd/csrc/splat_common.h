@@ -51,6 +51,9 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #define FWD_WIDE_MIN 25.0    // HR pixels per Gaussian from which the wide forward (16 x 16 sub-tiles, k_render_fwd16) is used:
                              // x5 -3..-7%, x8 -4..-10%, x12 -13..-15%, x16 -20%, x32 -25%; x4: +8% (profiles/r04_fwd_wide.txt)
 #endif
+#ifndef BWD_LX21_MAX
+#define BWD_LX21_MAX 21      // windows of 17..21 columns sweep 21 columns x 3 row slots (bwd_sweep; k_bin pads their rows to 6); 16 = off
+#endif
 #ifndef BWD_UNROLL_MIN
 #define BWD_UNROLL_MIN 32.0
 #endif

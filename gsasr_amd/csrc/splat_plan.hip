@@ -654,8 +654,8 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 // Batched canvas: inside the sample's own rows (whatever gradient the caller left in the padding of the
                 // slot must not be read).  Worked out here, once, instead of by every backward wave on its scalar unit.
                 const int bwid = b.c1 - b.c0 + 1, nr = b.r1 - b.r0 + 1;
-                const int rpt = bwid <= 16 ? 8 : (bwid <= 32 ? 4 : 2);
-                const int pad = (rpt - (nr & (rpt - 1))) & (rpt - 1);
+                const int rpt = bwid <= 16 ? 8 : (bwid <= BWD_LX21_MAX ? 6 : (bwid <= 32 ? 4 : 2));      // (bwd_sweep's rows per trip)
+                const int pad = (rpt - nr % rpt) % rpt;
                 const int lo = max(P.row0, g.base), hi = min(P.row1, g.base + g.h) - 1;
                 int r0p = b.r0, r1p = b.r1;
                 if (r1p + pad <= hi) r1p += pad;
