@@ -254,7 +254,7 @@ class _BandSplatPacked(Function):
         if band and backend is HipBackend:      # (proper bands of a replicated set: the tile-stationary backward, see HipBackend.forward)
             from . import _cabi
             flags = _cabi.FLAG_BWD_TILE
-        slab, state = backend.forward_packed(packed, h, w, dmax, rows, cutoff, flags) if flags else \
+        slab, state = backend.forward_packed(packed, h, w, dmax, rows, cutoff, flags=flags) if flags else \
             backend.forward_packed(packed, h, w, dmax, rows, cutoff)
         ctx.save_for_backward(packed)
         ctx.state, ctx.group, ctx.grad_reduce, ctx.backend = state, group, grad_reduce, backend
@@ -536,7 +536,8 @@ class _BandLocalSplat(Function):
             ex.own.copy_(packed_local)
         records = ex.exchange_forward()
         # (ex.cutoff is the conservative tau the selection used; the plan may build its windows with the data-derived one below it)
-        slab, state = ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff, ex.plan_flags) if ex.plan_flags \
+        # (a backend that declares CUTOFF_CAP_FLAG takes `flags` by keyword; one that does not is never handed the argument)
+        slab, state = ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff, flags=ex.plan_flags) if ex.plan_flags \
             else ex.backend.forward_packed(records, ex.h, ex.w, ex.dmax, ex.rows, ex.cutoff)
         ctx.ex, ctx.state, ctx.version = ex, state, ex.version
         if slab.numel():
