@@ -564,8 +564,13 @@ int gsasr_step_sample_forward(const float *gs_parameters, const float *step_size
     StepLayout S;
     StepSrc SS{};
     SS.step = step_size;
-    if (int rc = step_prologue_plan(gs_parameters, SS, dims, workspace, workspace_bytes, stream, S)) return rc;
-    return gsasr_splat_sample_forward(dims, workspace, S.plan_bytes, points, n_points, out, sample_ws, sample_ws_bytes, stream);
+    if (!dims) return fail(GSASR_ERR_ARG, "bad dims");
+    // (the sampled kernels walk the cells around their points: a plan made for them carries no tile lists.  All three sampled
+    // step entry points lay the workspace out the same way; gsasr_step_workspace_bytes(dims) is never smaller)
+    gsasr_dims dn = *dims;
+    dn.list_cap = -1;
+    if (int rc = step_prologue_plan(gs_parameters, SS, &dn, workspace, workspace_bytes, stream, S)) return rc;
+    return gsasr_splat_sample_forward(&dn, workspace, S.plan_bytes, points, n_points, out, sample_ws, sample_ws_bytes, stream);
 }
 
 int gsasr_step_sample_forward_sm(const float *gs_parameters, const float *scale_modify, int sm_stride, float default_step_size,
@@ -576,8 +581,11 @@ int gsasr_step_sample_forward_sm(const float *gs_parameters, const float *scale_
     StepSrc SS{};
     SS.sm = scale_modify; SS.stride = sm_stride; SS.def_step = default_step_size; SS.mismatch = mismatch;
     if (!scale_modify && dims && dims->s > 0) return fail(GSASR_ERR_ARG, "null pointer");
-    if (int rc = step_prologue_plan(gs_parameters, SS, dims, workspace, workspace_bytes, stream, S)) return rc;
-    return gsasr_splat_sample_forward(dims, workspace, S.plan_bytes, points, n_points, out, sample_ws, sample_ws_bytes, stream);
+    if (!dims) return fail(GSASR_ERR_ARG, "bad dims");
+    gsasr_dims dn = *dims;      // (no tile lists for the sampled kernels: gsasr_step_sample_forward)
+    dn.list_cap = -1;
+    if (int rc = step_prologue_plan(gs_parameters, SS, &dn, workspace, workspace_bytes, stream, S)) return rc;
+    return gsasr_splat_sample_forward(&dn, workspace, S.plan_bytes, points, n_points, out, sample_ws, sample_ws_bytes, stream);
 }
 
 int gsasr_step_sample_backward(const float *gs_parameters, const float *step_size, const float *grad_out,
@@ -586,6 +594,9 @@ int gsasr_step_sample_backward(const float *gs_parameters, const float *step_siz
 {
     if (!dims_ok(dims)) return fail(GSASR_ERR_ARG, "bad dims");
     if (dims->flags & GSASR_FLAG_STRIDE8) return fail(GSASR_ERR_ARG, "GSASR_FLAG_STRIDE8 does not apply to the step entry points");
+    gsasr_dims dn = *dims;      // (the layout the sampled forward planned with: no tile lists)
+    dn.list_cap = -1;
+    dims = &dn;
     const StepLayout S = make_step_layout(dims, workspace);
     if (!workspace || ((uintptr_t)workspace & 255u) || workspace_bytes < S.total)
         return fail(GSASR_ERR_WORKSPACE, "workspace null, misaligned or smaller than gsasr_step_workspace_bytes()");

@@ -120,6 +120,27 @@ int main(void)
         printf("plan API  dmax=%g band [%d,%d): image max|err| %.3e, grad(colors) rel err %.2e\n", dmax, h / 2, h, eimg, e4);
         if (!(eimg <= 2e-4) || !(e4 <= 2e-4)) bad = 1;
         CK(hipFree(ws));
+
+        /* the same band from the plan's tile lists (gsasr_dims.list_cap, ABI 5): forward rendered from the lists, the
+         * tile-stationary backward reading them too; a bigger workspace, the same numbers */
+        gsasr_dims dl = d;
+        dl.flags |= GSASR_FLAG_BWD_TILE;
+        dl.list_cap = 256;
+        const size_t lbytes = gsasr_splat_workspace_bytes(&dl);
+        if (!(lbytes > bytes)) { printf("list_cap did not grow the workspace\n"); bad = 1; }
+        CK(hipMalloc(&ws, lbytes));
+        OK(gsasr_splat_plan(d_sig, d_xy, d_col, &dl, ws, lbytes, st));
+        OK(gsasr_splat_forward(&dl, ws, lbytes, d_img, st));
+        OK(gsasr_splat_backward(d_sig, d_xy, d_col, d_wgt + (size_t)(h / 2) * w * 3, d_gs, d_gc, d_gk, &dl, ws, lbytes, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(img, d_img, sizeof(float) * 3 * rows * w, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gk, d_gk, sizeof(float) * 3 * s, hipMemcpyDeviceToHost));
+        eimg = 0;
+        for (int i = 0; i < 3 * rows * w; ++i) { double dd = fabs((double)img[i] - ref[i]); if (dd > eimg) eimg = dd; }
+        const double e5 = maxrel(gk, rk, 3 * s);
+        printf("tile lists dmax=%g band [%d,%d): image max|err| %.3e, grad(colors) rel err %.2e\n", dmax, h / 2, h, eimg, e5);
+        if (!(eimg <= 2e-4) || !(e5 <= 2e-4)) bad = 1;
+        CK(hipFree(ws));
     }
     /* batched canvas (gsasr_dims.batch): two samples of different size from the same Gaussians, kernel-frame inputs;
      * every sample must equal the oracle's single-image result on ITS grid, padding must be zero */
