@@ -29,6 +29,8 @@ struct Grad6 {  // the three gradient channels of the two pixels (rows Y, Y+RPI)
 };
 
 typedef unsigned u3v __attribute__((ext_vector_type(3)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // Two 12-byte pixels through a raw buffer resource: address = base(SGPR x4) + per-lane byte offset (one VGPR per
 // row of the pair, constant over the sweep) + ONE running row offset (SGPR), so a trip spends no VALU instruction and
@@ -43,6 +45,16 @@ __device__ __forceinline__ Grad6 bwd_load(__amdgpu_buffer_rsrc_t rsrc, int voff,
     s.a0 = __int_as_float(voff | 0x3f000000); s.a1 = __int_as_float(soff_a | 0x3f000000); s.a2 = 0.25f;
     s.b0 = __int_as_float(voff_b | 0x3f000000); s.b1 = 0.5f; s.b2 = __int_as_float(soff_b | 0x3e000000);
     return s;
+#endif
+#ifdef BWD_EXP_PAIRPLANAR   // what-if build (tools/whatif.sh): the cost of a gradient stored as row-pair planes {r0,r1 | g0,g1 | b0,b1}
+    {                       // per (column, row pair) -- one 16-byte + one 8-byte load, three natural register pairs (values are WRONG)
+        const u4v a4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff_a, 0);
+        const u2v b2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_b, soff_b, 0);
+        Grad6 p;
+        p.a0 = __uint_as_float(a4.x); p.a1 = __uint_as_float(a4.y); p.a2 = __uint_as_float(a4.z);
+        p.b0 = __uint_as_float(a4.w); p.b1 = __uint_as_float(b2.x); p.b2 = __uint_as_float(b2.y);
+        return p;
+    }
 #endif
     const u3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff_a, 0);
     const u3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff_b, soff_b, 0);
@@ -72,6 +84,21 @@ __device__ __forceinline__ void bwd_trip(BwdRow &R, const Grad6 g, v2f dyn, v2f 
         v.x = ((!TAIL || ok1) && (!TEST || fabsf(dyraw.x) <= dmax)) ? v.x : 0.f;
         v.y = ((!TAIL || ok2) && (!TEST || fabsf(dyraw.y) <= dmax)) ? v.y : 0.f;
     }
+#ifdef BWD_EXP_PAIRPLANAR
+    {   // three packed FMAs for <grad, colour> and three for the colour sums instead of six + five
+        const v2f pr = {g.a0, g.a1}, pg = {g.a2, g.b0}, pb = {g.b1, g.b2};
+        const v2f gpp = pb * cb + (pg * cg + pr * cr);
+        const v2f qq = gpp * v, qqB = qq * Bv;
+        R.m1 += qqB;
+        R.m2 += qqB * Bv;
+        R.k01 += pr * v;
+        v2f kg = {R.ka2, R.kb0}, kb = {R.kb1, R.kb2};      // (two more packed accumulators)
+        kg += pg * v;
+        kb += pb * v;
+        R.ka2 = kg.x; R.kb0 = kg.y; R.kb1 = kb.x; R.kb2 = kb.y;
+        return;
+    }
+#endif
     // six consecutive-in-memory floats per pixel pair are used as they land: no register shuffling
     const v2f gp = {fmaf(g.a2, cb, fmaf(g.a1, cg, g.a0 * cr)), fmaf(g.b2, cb, fmaf(g.b1, cg, g.b0 * cr))};  // gs.cu:150
     const v2f q = gp * v, qB = q * Bv;
@@ -251,8 +278,6 @@ __device__ __forceinline__ void bwd_write(float v, int lane, const Params &P, un
     else atomicAdd(dst, v);   // fire-and-forget: the wave must not end on a load-add-store round trip
 }
 
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u8v __attribute__((ext_vector_type(8)));
 
 // Everything the sweep needs about Gaussian j, fetched by the SCALAR unit in one batch (one round trip).
