@@ -27,6 +27,7 @@ EXPORTS = (
     "gsasr_sample_workspace_bytes", "gsasr_splat_sample_forward", "gsasr_splat_sample_backward",
     "gsasr_step_sample_forward", "gsasr_step_sample_backward",
     "gsasr_step_forward_sm", "gsasr_step_sample_forward_sm", "gsasr_plan_cutoff", "gsasr_release_launcher_scratch", "gsasr_forward_subtile_width",
+    "gsasr_set_kernel_choice", "gsasr_get_kernel_choice", "gsasr_clear_kernel_choices",
 )
 
 FLAG_OVERWRITE_IMAGE = 2   # GSASR_FLAG_OVERWRITE_IMAGE
@@ -124,7 +125,12 @@ def lib():
         L.gsasr_forward_subtile_width.argtypes = [dp]
         L.gsasr_plan_cutoff.restype = i
         L.gsasr_plan_cutoff.argtypes = [dp, vp, sz, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]
-        if L.gsasr_abi_version() != 5:
+        L.gsasr_set_kernel_choice.restype = i
+        L.gsasr_set_kernel_choice.argtypes = [dp, ctypes.c_uint, i]
+        L.gsasr_get_kernel_choice.restype = i
+        L.gsasr_get_kernel_choice.argtypes = [dp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_int)]
+        L.gsasr_clear_kernel_choices.restype = None
+        if L.gsasr_abi_version() != 6:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
     return _lib
@@ -391,6 +397,13 @@ def backward(p: Plan, sigmas, coords, colors, grad_img, g_sigmas, g_coords, g_co
                                          p.workspace.numel(), _stream(p.device)), "gsasr_splat_backward")
 
 
+_AUTOTUNE = os.environ.get("GSASR_AMD_AUTOTUNE", "0") not in ("", "0")
+
+
+def _tune_on() -> bool:
+    return _AUTOTUNE
+
+
 def plan_forward(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, img: torch.Tensor,
                  dmax: Optional[float]) -> Plan:
     """`plan` + `forward` (accumulating into `img[H,W,3]`) as one host call: what `GSCUDA.forward` does, with one device /
@@ -407,6 +420,10 @@ def plan_forward(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tenso
         raise RuntimeError("sigmas, coords, colors disagree on the number of Gaussians")
     if img.device != dev:
         raise RuntimeError("rendered_img does not match the plan (shape / device)")
+    if _tune_on():      # GSASR_AMD_AUTOTUNE=1: a shape's first call measures the kernel combinations (gsasr_amd/tune.py)
+        from . import tune
+        tune.autotune_hook(sigmas, coords, colors, h, w, dmax,
+                           torch.is_grad_enabled() and (sigmas.requires_grad or coords.requires_grad or colors.requires_grad))
     variants, nbytes = _plan_dims(s, h, w, dmax, None, 0.0, 0)
     L = lib()
     with _on(dev):
@@ -866,3 +883,28 @@ def plan_cutoff(p: Plan) -> Tuple[float, int]:
 def resolve_cutoff(cutoff: float, s: int) -> float:
     """tau a plan with `cutoff` (0 = process default) over `s` Gaussians uses."""
     return float(lib().gsasr_resolve_cutoff(float(cutoff), int(s)))
+
+
+# ---- kernel choices registered per shape (include/gsasr_splat.h: gsasr_set_kernel_choice; gsasr_amd/tune.py measures them) ----
+CHOICE_FLAGS = FLAG_FWD_WIDE | FLAG_FWD_NARROW | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN
+
+
+def set_kernel_choice(shape: Dims, flags: int, list_cap: int = 0) -> None:
+    """Register the kernel choice for plans of `shape` (a Dims as `make_dims` / `make_batch_dims` builds them; only its shape
+    fields and FLAG_FORWARD_ONLY are read).  Later calls without an explicit choice of their own follow it."""
+    check(lib().gsasr_set_kernel_choice(ctypes.byref(shape), int(flags), int(list_cap)), "gsasr_set_kernel_choice")
+    _PLAN_DIMS.clear()      # workspace sizes follow the registered choice
+    _STEP_DIMS.clear()
+
+
+def get_kernel_choice(shape: Dims) -> Optional[Tuple[int, int]]:
+    f, c = ctypes.c_uint(0), ctypes.c_int(0)
+    if not lib().gsasr_get_kernel_choice(ctypes.byref(shape), ctypes.byref(f), ctypes.byref(c)):
+        return None
+    return int(f.value), int(c.value)
+
+
+def clear_kernel_choices() -> None:
+    lib().gsasr_clear_kernel_choices()
+    _PLAN_DIMS.clear()
+    _STEP_DIMS.clear()

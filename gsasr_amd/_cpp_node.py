@@ -20,6 +20,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 EXT_PATH = os.path.join(PKG, "lib", "_gsasr_autograd.so")
 _ext = None
 _tried = False
+_AUTOTUNE = os.environ.get("GSASR_AMD_AUTOTUNE", "0") not in ("", "0")
 
 
 def load():
@@ -68,6 +69,10 @@ def _call(sigmas, coords, colors, rendered_img, dmax):
         raise RuntimeError("sigmas must be a CUDA tensor")
     dev = sigmas.device
     d = -1.0 if dmax is None else float(dmax)
+    if _AUTOTUNE and rendered_img.dim() == 3:      # GSASR_AMD_AUTOTUNE=1 (gsasr_amd/tune.py)
+        from . import tune
+        tune.autotune_hook(sigmas, coords, colors, rendered_img.shape[0], rendered_img.shape[1], dmax,
+                           torch.is_grad_enabled() and (sigmas.requires_grad or coords.requires_grad or colors.requires_grad))
     if dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             return _ext.gscuda_apply(sigmas, coords, colors, rendered_img, d, torch.cuda.current_stream(dev).cuda_stream,

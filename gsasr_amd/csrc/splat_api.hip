@@ -25,6 +25,39 @@ float default_cutoff()
 
 void store_default_cutoff(float tau) { g_default_cutoff.store(tau, std::memory_order_relaxed); }
 
+// Kernel choices registered per shape (gsasr_set_kernel_choice).  A handful of entries, looked up by the policy functions of
+// splat_common.h on every call: one relaxed load says "nothing registered" (the normal case), else a linear search under a mutex.
+struct ChoiceEntry { int s, h, w, row0, row1, batch, slot; float dmax, cutoff; bool fwd_only; KernelChoice c; };
+static std::mutex g_choice_mu;
+static std::vector<ChoiceEntry> g_choices;
+static std::atomic<int> g_nchoices{0};
+
+static ChoiceEntry choice_key(const gsasr_dims *d)
+{
+    ChoiceEntry e{};
+    e.s = d->s; e.h = d->h; e.w = d->w; e.row0 = d->row0; e.row1 = d->row1;
+    e.batch = batch_of(d); e.slot = d->batch > 1 ? d->slot : 0;
+    e.dmax = d->dmax >= 0.f ? d->dmax : -1.f; e.cutoff = d->cutoff;
+    e.fwd_only = (d->flags & GSASR_FLAG_FORWARD_ONLY) != 0;
+    return e;
+}
+
+static bool same_shape(const ChoiceEntry &a, const ChoiceEntry &b)
+{
+    return a.s == b.s && a.h == b.h && a.w == b.w && a.row0 == b.row0 && a.row1 == b.row1 && a.batch == b.batch && a.slot == b.slot &&
+           a.dmax == b.dmax && a.cutoff == b.cutoff && a.fwd_only == b.fwd_only;
+}
+
+KernelChoice registered_choice(const gsasr_dims *d)
+{
+    if (g_nchoices.load(std::memory_order_relaxed) == 0) return KernelChoice{0u, 0};
+    const ChoiceEntry k = choice_key(d);
+    std::lock_guard<std::mutex> lk(g_choice_mu);
+    for (const ChoiceEntry &e : g_choices)
+        if (same_shape(e, k)) return e.c;
+    return KernelChoice{0u, 0};
+}
+
 // Which plans carry slots.  The slot count of a workspace follows from the flags of the dims the PLAN was made with; a
 // backward (or the gather of a step call) that derives it from its OWN flags would, when the two disagree, read slots and
 // spans the plan never wrote.  The plan therefore leaves a note {workspace -> slots per Gaussian} here and every later
@@ -121,6 +154,45 @@ const char *gsasr_last_error(void) { return last_error_message(); }
 void gsasr_set_default_cutoff(float tau) { store_default_cutoff(tau); }
 
 float gsasr_get_default_cutoff(void) { return default_cutoff(); }
+
+int gsasr_set_kernel_choice(const gsasr_dims *shape, unsigned flags, int list_cap)
+{
+    constexpr unsigned ALLOWED = GSASR_FLAG_FWD_WIDE | GSASR_FLAG_FWD_NARROW | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_GAUSSIAN;
+    if (!shape) return fail(GSASR_ERR_ARG, "null shape");
+    if (flags & ~ALLOWED) return fail(GSASR_ERR_ARG, "a kernel choice holds GSASR_FLAG_FWD_WIDE | _FWD_NARROW | _BWD_TILE | _BWD_GAUSSIAN only");
+    if ((flags & GSASR_FLAG_FWD_WIDE) && (flags & GSASR_FLAG_FWD_NARROW)) return fail(GSASR_ERR_ARG, "GSASR_FLAG_FWD_WIDE and _FWD_NARROW exclude each other");
+    if ((flags & GSASR_FLAG_BWD_TILE) && (flags & GSASR_FLAG_BWD_GAUSSIAN)) return fail(GSASR_ERR_ARG, "GSASR_FLAG_BWD_TILE and _BWD_GAUSSIAN exclude each other");
+    ChoiceEntry k = choice_key(shape);
+    k.c = KernelChoice{flags, list_cap};
+    std::lock_guard<std::mutex> lk(g_choice_mu);
+    for (ChoiceEntry &e : g_choices)
+        if (same_shape(e, k)) { e.c = k.c; return GSASR_OK; }
+    if (g_choices.size() >= 256) return fail(GSASR_ERR_ARG, "256 kernel choices are registered: gsasr_clear_kernel_choices first");
+    g_choices.push_back(k);
+    g_nchoices.store((int)g_choices.size(), std::memory_order_relaxed);
+    return GSASR_OK;
+}
+
+int gsasr_get_kernel_choice(const gsasr_dims *shape, unsigned *flags, int *list_cap)
+{
+    if (!shape || g_nchoices.load(std::memory_order_relaxed) == 0) return 0;
+    const ChoiceEntry k = choice_key(shape);
+    std::lock_guard<std::mutex> lk(g_choice_mu);
+    for (const ChoiceEntry &e : g_choices)
+        if (same_shape(e, k)) {
+            if (flags) *flags = e.c.flags;
+            if (list_cap) *list_cap = e.c.list_cap;
+            return 1;
+        }
+    return 0;
+}
+
+void gsasr_clear_kernel_choices(void)
+{
+    std::lock_guard<std::mutex> lk(g_choice_mu);
+    g_choices.clear();
+    g_nchoices.store(0, std::memory_order_relaxed);
+}
 
 float gsasr_resolve_cutoff(float cutoff, int s) { return resolve_cutoff(cutoff, s); }
 

@@ -352,13 +352,22 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
     if (!empty) {
 #define GSASR_SWEEP(T, L) \
     bwd_sweep<T, L, UNROLL>(c0, bw, r0, r1, lane, P, V.px + G.fin[5], V.py, grad, x, y, cr, cg, cb, fa.x, fa.z, fa.y, fa.w, fb.x, spy, a)
+#ifdef BWD_EXP_NOSWEEP   // what-if build (tools/whatif.sh): no sweep at all -- what remains is the record fetch, the wave reduction and the write
+        for (int k = 0; k < 8; ++k) a[k] = __int_as_float((lane + k + bw) | 0x3f000000) * x;
+#else
         if (bw <= 16) { if (test) GSASR_SWEEP(true, 16); else GSASR_SWEEP(false, 16); }
         else if (bw <= BWD_LX21_MAX) { if (test) GSASR_SWEEP(true, 21); else GSASR_SWEEP(false, 21); }
         else if (bw <= 32) { if (test) GSASR_SWEEP(true, 32); else GSASR_SWEEP(false, 32); }
         else { if (test) GSASR_SWEEP(true, 64); else GSASR_SWEEP(false, 64); }
+#endif
 #undef GSASR_SWEEP
         bwd_scale(a, fa.x, fa.w, fb.x);
+#ifdef BWD_EXP_NOREDUCE   // what-if build: no wave reduction (lane 8k writes its own partial of value k)
+        d = a[0];
+        for (int k = 1; k < 8; ++k) d = (lane >> 3) == k ? a[k] : d;
+#else
         d = wave_sum8(a, lane, red);   // lane 8k now holds gradient component k
+#endif
     }
     if (atomic) {
         // Large class: the row chunks add into sums[] and count themselves; the wave that finishes the
@@ -979,6 +988,7 @@ int bwd_mode(const gsasr_dims *dims, const Layout &L)
     if (f & GSASR_FLAG_BWD_GAUSSIAN) mode = 0;
     else if (f & GSASR_FLAG_BWD_ATOMIC) mode = 2;
     else if (f & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_CHW_GRAD)) mode = 1;
+    else if (const unsigned rf = registered_choice(dims).flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE)) mode = (rf & GSASR_FLAG_BWD_TILE) ? 1 : 0;
     else if (bwd_env()) mode = bwd_env() - 1;
     if (L.part_k == 0 && mode == 1) mode = (f & GSASR_FLAG_CHW_GRAD) ? 2 : 0;   // a forward-only plan has no slots
     return mode;

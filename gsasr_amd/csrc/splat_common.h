@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "gsasr_splat.h"
 
@@ -23,6 +24,8 @@ namespace gsasr_detail {
 int fail(int code, const char *msg);                 // sets the thread-local message of gsasr_last_error(), returns `code`
 int hip_fail(hipError_t e, const char *where);
 const char *last_error_message();
+struct KernelChoice { unsigned flags; int list_cap; };
+KernelChoice registered_choice(const gsasr_dims *d);   // gsasr_set_kernel_choice's entry for this shape, {0, 0} when none (splat_api.hip)
 float default_cutoff();                              // process default of the support cutoff (0 = adaptive)
 void store_default_cutoff(float tau);
 
@@ -50,6 +53,12 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #ifndef FWD_WIDE_MIN
 #define FWD_WIDE_MIN 25.0    // HR pixels per Gaussian from which the wide forward (16 x 16 sub-tiles, k_render_fwd16) is used:
                              // x5 -3..-7%, x8 -4..-10%, x12 -13..-15%, x16 -20%, x32 -25%; x4: +8% (profiles/r04_fwd_wide.txt)
+#endif
+#ifndef TL_MIN_SUB
+#define TL_MIN_SUB 2048      // sub-tiles (8 x 16 px) from which a dense plan carries tile lists by default: 512^2 and up.  Measured at 16
+                             // Gaussians per LR pixel (profiles/r05_small_dense.txt): 512^2 forward 134 -> 72 us for +8 us of plan, 640^2
+                             // 207 -> 126; 384^2 level (+7 us of plan, nothing off the forward), 256^2 and below the split search kernel
+                             // wins (33 against 48 us; four waves per sub-tile instead of two: 42)
 #endif
 #ifndef BWD_LX21_MAX
 #define BWD_LX21_MAX 21      // windows of 17..21 columns sweep 21 columns x 3 row slots (bwd_sweep; k_bin pads their rows to 6); 16 = off
@@ -231,7 +240,11 @@ inline int fwd_wide_env()
 // single image.
 inline bool fwd_wants_wide(const gsasr_dims *d)
 {
-    const int want = (d->flags & GSASR_FLAG_FWD_WIDE) ? 1 : (d->flags & GSASR_FLAG_FWD_NARROW) ? 0 : fwd_wide_env();
+    int want = (d->flags & GSASR_FLAG_FWD_WIDE) ? 1 : (d->flags & GSASR_FLAG_FWD_NARROW) ? 0 : -1;
+    if (want < 0) {   // no explicit flag: the registered choice of this shape, then the development switch
+        const unsigned rf = registered_choice(d).flags;
+        want = (rf & GSASR_FLAG_FWD_WIDE) ? 1 : (rf & GSASR_FLAG_FWD_NARROW) ? 0 : fwd_wide_env();
+    }
     if (d->batch > 1 || want == 0) return false;
     if (want == 1) return true;
     const int rows = d->row1 - d->row0;
@@ -267,7 +280,13 @@ inline int bwd_env()
 inline bool bwd_wants_tile(const gsasr_dims *d)
 {
     if (d->flags & (GSASR_FLAG_FORWARD_ONLY | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_ATOMIC)) return false;
-    if ((d->flags & GSASR_FLAG_BWD_TILE) || bwd_env() == 2) return true;
+    if (d->flags & GSASR_FLAG_BWD_TILE) return true;
+    {   // the registered choice of this shape (gsasr_set_kernel_choice)
+        const unsigned rf = registered_choice(d).flags;
+        if (rf & GSASR_FLAG_BWD_GAUSSIAN) return false;
+        if (rf & GSASR_FLAG_BWD_TILE) return true;
+    }
+    if (bwd_env() == 2) return true;
     // (by default only for whole images: a row band of a sharded image may hold all the Gaussians or just its own, so
     // its pixels per Gaussian say nothing about the window size -- the shard's caller knows the scale and sets the flag)
     if (bwd_env() != 0 || d->batch > 1 || d->row0 != 0 || d->row1 != d->h) return false;
@@ -337,18 +356,25 @@ inline bool tl_dense(const gsasr_dims *d)
 
 // log2 of the list tiles' height for a plan of these dims: 5 where the forward will be the wide kernel (32 x 32-px tiles),
 // 4 for the two-level 8 x 16 kernels (32 x 16), 0 = no lists (small images: the split kernel; list_cap < 0; no Gaussians)
+// gsasr_dims.list_cap, or when that is 0 the registered choice of the shape
+inline int list_cap_of(const gsasr_dims *d) { return d->list_cap != 0 ? d->list_cap : registered_choice(d).list_cap; }
+
 inline int tl_hlog_for(const gsasr_dims *d)
 {
-    if (d->list_cap < 0 || d->s <= 0 || lists_env() == 0) return 0;
+    const int list_cap = list_cap_of(d);
+    if (list_cap < 0 || d->s <= 0 || lists_env() == 0) return 0;
     // by default for dense plans (tl_dense) and for plans whose BACKWARD reads them too -- the tile-stationary kernel on the same
     // tiles (x8 and up: config 4, the shard's bands): two consumers pay for k_bin's atomics; an explicit capacity (or the
     // development switch) asks for them anywhere
-    const bool both = !(d->flags & GSASR_FLAG_FORWARD_ONLY) && bwd_wants_tile(d) && fwd_wants_wide(d) == bt_tall(d);
-    if (d->list_cap == 0 && lists_env() != 1 && !tl_dense(d) && !both) return 0;
+    // (up to ~x10: at x12 a window meets 16 and more 32 x 32-px tiles and k_bin's appends cost more than the two kernels save --
+    // 3072^2 x12 fwd+bwd: plan +33 us for -13 us of forward, profiles/r05_policy_sweep.txt)
+    const bool both = !(d->flags & GSASR_FLAG_FORWARD_ONLY) && bwd_wants_tile(d) && fwd_wants_wide(d) == bt_tall(d) &&
+                      (double)d->h * (double)d->w < 100.0 * (double)d->s;
+    if (list_cap == 0 && lists_env() != 1 && !tl_dense(d) && !both) return 0;
     const int rows = d->row1 - d->row0;
     if (fwd_wants_wide(d)) return 5;
     const long nsub = (long)((d->w + SUBX - 1) / SUBX) * ((rows + SUBY - 1) / SUBY);
-    return (nsub >= 4096 || d->list_cap > 0) ? 4 : 0;      // (an explicit capacity asks for lists on any image: tests)
+    return (nsub >= TL_MIN_SUB || list_cap > 0) ? 4 : 0;      // (an explicit capacity asks for lists on any image: tests)
 }
 
 // Entries per tile.  gsasr_dims.list_cap when given; else four times what a tile of GSASR-shaped Gaussians (about one LR
@@ -356,7 +382,7 @@ inline int tl_hlog_for(const gsasr_dims *d)
 inline int tl_cap_for(const gsasr_dims *d, int hlog)
 {
     if (!hlog) return 0;
-    long cap = d->list_cap;
+    long cap = list_cap_of(d);
     if (cap <= 0) {
         const double rows = (double)(d->row1 - d->row0 > 0 ? d->row1 - d->row0 : 1);
         // (density over the rows rendered; a row band that is handed every Gaussian of the image sees most of them dead: its
@@ -521,7 +547,9 @@ inline Params make_params(const gsasr_dims *d, const Layout &L)
     }
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
     P.flags = d->flags;
-    if (!(P.flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)))   // (development A/B switch)
+    if (!(P.flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)))   // (the registered choice; the development A/B switch)
+        P.flags |= registered_choice(d).flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE);
+    if (!(P.flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)))
         P.flags |= bwd_env() == 2 ? GSASR_FLAG_BWD_TILE : bwd_env() == 3 ? GSASR_FLAG_BWD_ATOMIC : 0u;
     P.batch = batch_of(d);
     P.slot = d->batch > 1 ? d->slot : d->h;

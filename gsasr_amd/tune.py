@@ -1,0 +1,175 @@
+"""Kernel choice measured on the caller's own Gaussians (opt-in).
+
+The library picks its kernels from the SHAPE of a problem -- pixels per Gaussian, image size -- because the window sizes
+that really decide live on the device and no entry point synchronises to read them.  Those rules were drawn on GSASR-shaped
+synthetic Gaussians ("about one LR pixel": gsasr_amd/synthetic.py).  On other size distributions another combination of
+
+    forward  : 8 x 16 or 16 x 16-px sub-tiles           (FLAG_FWD_NARROW / FLAG_FWD_WIDE)
+    backward : Gaussian- or tile-stationary             (FLAG_BWD_GAUSSIAN / FLAG_BWD_TILE)
+    lists    : the plan's tile lists, or the search     (list_cap > 0 / < 0)
+
+can be 5..45% faster (profiles/r05_policy_regret.txt).  `tune()` times the combinations on the tensors it is given --
+plan + forward (+ backward), a few repetitions each in three rounds after a 30 ms warm-up -- and registers the winner
+for the shape in the C library (`gsasr_set_kernel_choice`, include/gsasr_splat.h), so that every later call of that shape
+through any entry point (the GSCUDA drop-in, the C++ autograd node, the C ABI itself) follows it.  All combinations compute
+the same sums in another order (tests/test_tune.py).
+
+    from gsasr_amd import tune
+    tune.tune(sigmas, coords, colors, H, W, dmax=0.1)          # once per shape, e.g. on the first batch
+
+or `GSASR_AMD_AUTOTUNE=1` in the environment: the GSCUDA drop-in tunes each new shape on its first call (like
+`torch.backends.cudnn.benchmark`; that first call synchronises and takes ~10 steps' worth of time; never during stream capture).
+Nothing here is on the default path: without a call or the variable the library's own rules apply.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _cabi
+
+AUTOTUNE = _cabi._AUTOTUNE
+WARM_MS = 30.0          # milliseconds of the default combination run before anything is timed (clock ramp)
+MIN_GAIN = 0.03         # a combination replaces the library's own choice only when it is at least this much faster
+_SEEN = set()           # shapes the autotune hook has handled (tuned or declined) in this process
+
+
+@dataclass
+class TuneResult:
+    name: str                       # winning combination ("default" = the library's own rule stays)
+    flags: int
+    list_cap: int
+    ms: Dict[str, float] = field(default_factory=dict)      # combination -> milliseconds per plan + forward (+ backward)
+    registered: bool = False
+
+
+def default_list_capacity(s: int, w: int, rows: int, wide: bool) -> int:
+    """entries per tile the library would give a plan with lists (tl_cap_for, gsasr_amd/csrc/splat_common.h): four times what a
+    tile of LR-pixel sized Gaussians collects, + 64"""
+    rho = max(float(s) / (float(w) * float(max(rows, 1))), 1e-9)
+    e = 5.0 / math.sqrt(rho)
+    want = 4.0 * rho * (32.0 + e) * ((32.0 if wide else 16.0) + e) + 64.0
+    return int(min(max(want, 64.0), 65536.0))
+
+
+def _shape_key(s, h, w, dmax, rows, cutoff, forward_only):
+    return (int(s), int(h), int(w), None if dmax is None else float(dmax), rows, float(cutoff), bool(forward_only))
+
+
+def candidates(s: int, w: int, rows: int, backward: bool):
+    """(name, flags, list_cap) of every combination, the library's own choice first"""
+    out = [("default", 0, 0)]
+    for fw, ff in (("narrow", _cabi.FLAG_FWD_NARROW), ("wide", _cabi.FLAG_FWD_WIDE)):
+        for bw, bf in ((("gaussian", _cabi.FLAG_BWD_GAUSSIAN), ("tile", _cabi.FLAG_BWD_TILE)) if backward else (("", 0),)):
+            for lists in (False, True):
+                cap = default_list_capacity(s, w, rows, fw == "wide") if lists else -1
+                out.append(("-".join(x for x in (fw, bw, "lists" if lists else "search") if x), ff | bf, cap))
+    return out
+
+
+def tune(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: int, w: int, dmax: Optional[float],
+         *, backward: bool = True, rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0, iters: int = 3,
+         register: bool = True, grad: Optional[torch.Tensor] = None, forward_only_plan: Optional[bool] = None,
+         rounds: int = 3) -> TuneResult:
+    """Time every kernel combination on these Gaussians and (by default) register the fastest for the shape.
+
+    `backward=False`: only plan + forward are timed, and the result is registered for plans made with FLAG_FORWARD_ONLY
+    (`forward_only_plan=False`: for full plans whose backward never runs -- the GSCUDA drop-in under no_grad).  `grad`: the
+    upstream gradient to time the backward with ([rows, w, 3]; default: ones).  Synchronises the device; do not call during
+    stream capture."""
+    if not sigmas.is_cuda:
+        raise RuntimeError("tune() measures on the GPU: CUDA tensors required")
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("tune() synchronises: not during stream capture")
+    s = int(sigmas.shape[0])
+    r0, r1 = (0, int(h)) if rows is None else rows
+    nrows = r1 - r0
+    if forward_only_plan is None:
+        forward_only_plan = not backward
+    if backward and forward_only_plan:
+        raise RuntimeError("a FLAG_FORWARD_ONLY plan has no backward to time")
+    base = _cabi.FLAG_FORWARD_ONLY if forward_only_plan else 0
+    shape = _cabi.make_dims(s, h, w, dmax, rows, cutoff, base)
+    prev = _cabi.get_kernel_choice(shape)
+    if prev is not None:            # measure the library's own rule as "default", not an earlier registration
+        _cabi.set_kernel_choice(shape, 0, 0)
+    dev = sigmas.device
+    res = TuneResult("default", 0, 0)
+    cands = candidates(s, w, nrows, backward)
+    with torch.no_grad():
+        img = torch.empty(nrows, w, 3, device=dev)
+        if backward:
+            g = grad if grad is not None else torch.ones(nrows, w, 3, device=dev)
+            gs, gc, gk = torch.empty_like(sigmas), torch.empty_like(coords), torch.empty_like(colors)
+
+        def step(flags, cap):
+            p = _cabi.plan(sigmas, coords, colors, h, w, dmax, rows, cutoff, base | flags, cap)
+            _cabi.forward(p, img, overwrite=True)
+            if backward:
+                _cabi.backward(p, sigmas, coords, colors, g, gs, gc, gk, overwrite=True)
+
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # The GPU's clocks follow its load: a burst of a few steps after an idle gap runs slower than the same steps a moment
+        # later, which would favour whichever combination is measured last.  So: warm up on the default for WARM_MS first, keep
+        # the queue busy from then on (one synchronisation per measurement), go round the combinations `rounds` times and keep
+        # each one's fastest round.
+        a.record()
+        t = 0.0
+        while t < WARM_MS:
+            for _ in range(4):
+                step(0, 0)
+            b.record()
+            b.synchronize()
+            t = a.elapsed_time(b)
+        alive = {}
+        for name, flags, cap in cands:
+            try:
+                step(flags, cap)                        # (first use of a layout: workspace allocation)
+                alive[name] = (flags, cap)
+            except RuntimeError:
+                pass                                    # a combination this shape does not admit
+        n = max(1, iters)
+        for _ in range(max(1, rounds)):
+            for name, (flags, cap) in alive.items():
+                a.record()
+                for _ in range(n):
+                    step(flags, cap)
+                b.record()
+                b.synchronize()
+                ms = a.elapsed_time(b) / n
+                res.ms[name] = min(ms, res.ms.get(name, ms))
+    if prev is not None and not register:
+        _cabi.set_kernel_choice(shape, *prev)
+    if "default" not in res.ms:
+        raise RuntimeError("tune(): the default combination failed")
+    best = min(res.ms, key=res.ms.get)
+    if best != "default" and res.ms[best] <= (1.0 - MIN_GAIN) * res.ms["default"]:
+        res.name = best
+        res.flags, res.list_cap = next((f, c) for nm, f, c in cands if nm == best)
+    if register:
+        _cabi.set_kernel_choice(shape, res.flags, res.list_cap)
+        res.registered = True
+    _SEEN.add(_shape_key(s, h, w, dmax, rows, cutoff, forward_only_plan))
+    return res
+
+
+def autotune_hook(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: int, w: int, dmax: Optional[float],
+                  backward: bool) -> None:
+    """called by the drop-in's forward when GSASR_AMD_AUTOTUNE=1: tune a shape the first time it is seen"""
+    key = _shape_key(sigmas.shape[0], h, w, dmax, None, 0.0, False)     # (the drop-in's plans are full plans)
+    if key in _SEEN:
+        return
+    if not sigmas.is_cuda or sigmas.shape[0] == 0 or torch.cuda.is_current_stream_capturing():
+        return
+    _SEEN.add(key)
+    tune(sigmas.detach(), coords.detach(), colors.detach(), h, w, dmax, backward=backward, forward_only_plan=False)
+
+
+def reset() -> None:
+    """forget every registered choice (and what the autotune hook has seen)"""
+    _SEEN.clear()
+    _cabi.clear_kernel_choices()

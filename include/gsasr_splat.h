@@ -44,7 +44,7 @@ extern "C" {
 #define GSASR_API
 #endif
 
-#define GSASR_SPLAT_ABI_VERSION 5 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags; 4: the _sm step entry points, step_size = NULL in the step backwards; 5: gsasr_dims.list_cap (tile lists) */
+#define GSASR_SPLAT_ABI_VERSION 6 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags; 4: the _sm step entry points, step_size = NULL in the step backwards; 5: gsasr_dims.list_cap (tile lists); 6: the kernel-choice registry */
 
 enum gsasr_status {
     GSASR_OK = 0,
@@ -316,6 +316,24 @@ GSASR_API int gsasr_plan_cutoff(const gsasr_dims *dims, const void *workspace, s
  * the width of a wave's sub-tile in pixels -- 16 = the wide forward (16 x 16 sub-tiles, four pixels per lane: scale factors
  * from x5 up on single images of 2 Mpx and more, or GSASR_FLAG_FWD_WIDE), 8 = the 8 x 16 kernels.  < 0: invalid dims. */
 GSASR_API int gsasr_forward_subtile_width(const gsasr_dims *dims);
+
+/* Kernel choices registered per problem shape (round 5; gsasr_amd/tune.py measures and registers them).
+ * The library picks its kernels -- 8 x 16 or 16 x 16 forward sub-tiles, Gaussian- or tile-stationary backward, tile lists or the
+ * search -- from the SHAPE of the problem (pixels per Gaussian, image size): the window sizes that really decide live on the device,
+ * and no entry point synchronises to read them.  On Gaussians much smaller or larger than "about one LR pixel" another
+ * combination can be 5..45% faster (profiles/r05_policy_regret.txt).  A caller who knows better -- it timed the combinations on
+ * its own data -- registers the choice once; every later plan / forward / backward whose dims match `shape` in {s, h, w, row0,
+ * row1, batch, slot, dmax, cutoff, GSASR_FLAG_FORWARD_ONLY} and carry NO explicit choice of their own (flags below, list_cap != 0)
+ * behaves as if it had been given
+ *     flags    : any of GSASR_FLAG_FWD_WIDE | GSASR_FLAG_FWD_NARROW, GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_GAUSSIAN
+ *     list_cap : as gsasr_dims.list_cap (0 = the library's rule, > 0 entries per tile, < 0 no lists).
+ * Results are the same sums in another order.  Register BEFORE sizing workspaces for the shape (gsasr_splat_workspace_bytes
+ * follows the registered choice; a workspace sized earlier may be too small and is refused, never overrun).  Process-wide,
+ * thread-safe; at most 256 shapes (GSASR_ERR_ARG beyond, or on flags outside the four above). */
+GSASR_API int gsasr_set_kernel_choice(const gsasr_dims *shape, unsigned flags, int list_cap);
+/* 1 and the registered values if `shape` has a registered choice, else 0 */
+GSASR_API int gsasr_get_kernel_choice(const gsasr_dims *shape, unsigned *flags, int *list_cap);
+GSASR_API void gsasr_clear_kernel_choices(void);
 
 #ifdef __cplusplus
 }

@@ -62,15 +62,31 @@ int main(int argc, char **argv)
     auto sigm = [](float v) { return 1.f / (1.f + expf(-v)); };
     std::vector<float> sig(3 * (size_t)n), xy(2 * (size_t)n), col(3 * (size_t)n), grad((size_t)H * W * 3);
     const float step = 1.2f / scale;
+    // MB_DIST: which Gaussians (tools/policy_sweep.sh).  0 = SURVEY 8(d)'s (sigma = sigmoid(N(0, 0.5)) of the decoder's range);
+    // 1 small (0.1..0.3 of the range); 2 saturated (0.85..1); 3 log-uniform over 0.05..1; 4 needles (0.9 x 0.1, |rho| 0.9);
+    // 5 bimodal (90% at 0.15, 10% at 0.95); 6 = 0 with the means jittered over +-3 LR pixels (clusters and holes)
+    const int dist = getenv("MB_DIST") ? atoi(getenv("MB_DIST")) : 0;
+    std::mt19937 rng2(1);
     for (int k = 0; k < n; ++k) {
         const int i = k / (lrw * gpp), j = (k / gpp) % lrw;
-        const float sx = 0.99999f * sigm(nd(rng)) + 1e-6f, sy = 0.99999f * sigm(nd(rng)) + 1e-6f;
+        float sx = 0.99999f * sigm(nd(rng)) + 1e-6f, sy = 0.99999f * sigm(nd(rng)) + 1e-6f;
+        float rho = 0.999999f * tanhf(nd(rng)), jit = 1.f;
+        const float r1 = ud(rng2), r2 = ud(rng2), r3 = ud(rng2);   // (own stream: MB_DIST=0 draws what it always drew)
+        switch (dist) {
+        case 1: sx = 0.1f + 0.2f * r1; sy = 0.1f + 0.2f * r2; break;
+        case 2: sx = 0.85f + 0.15f * r1; sy = 0.85f + 0.15f * r2; break;
+        case 3: sx = 0.05f * powf(20.f, r1); sy = 0.05f * powf(20.f, r2); break;
+        case 4: sx = r3 < 0.5f ? 0.9f : 0.1f; sy = r3 < 0.5f ? 0.1f : 0.9f; rho = (r1 < 0.5f ? -0.9f : 0.9f) * (0.5f + 0.5f * r2); break;
+        case 5: sx = sy = r3 < 0.9f ? 0.15f : 0.95f; break;
+        case 6: jit = 6.f; break;
+        default: break;
+        }
         sig[3 * k + 0] = sy / step * 2 / (W - 1);
         sig[3 * k + 1] = sx / step * 2 / (H - 1);
-        sig[3 * k + 2] = 0.999999f * tanhf(nd(rng));
+        sig[3 * k + 2] = rho;
         const float a = sigm(nd(rng));
         for (int c = 0; c < 3; ++c) col[3 * k + c] = sigm(nd(rng)) * a;
-        const float mx = ((j + 0.5f + ud(rng) - 0.5f) / lrw) * 2 - 1, my = ((i + 0.5f + ud(rng) - 0.5f) / lrh) * 2 - 1;
+        const float mx = ((j + 0.5f + jit * (ud(rng) - 0.5f)) / lrw) * 2 - 1, my = ((i + 0.5f + jit * (ud(rng) - 0.5f)) / lrh) * 2 - 1;
         xy[2 * k + 0] = (mx + 1 - 1.f / W) * W / (W - 1) - 1.f;
         xy[2 * k + 1] = (my + 1 - 1.f / H) * H / (H - 1) - 1.f;
     }
@@ -78,6 +94,7 @@ int main(int argc, char **argv)
 
     const unsigned flags = argc > 8 ? (unsigned)atoi(argv[8]) : 0u;   // 6 = overwrite image + grads
     gsasr_dims d{n, H, W, 3, dmax, 0, H, tau, flags};
+    if (getenv("MB_LIST_CAP")) d.list_cap = atoi(getenv("MB_LIST_CAP"));   // > 0: tile lists of that capacity on any image; < 0: none
     const size_t wsb = gsasr_splat_workspace_bytes(&d);
     float *dsig, *dxy, *dcol, *dgrad, *dimg, *dgs, *dgc, *dgk;
     void *ws;
