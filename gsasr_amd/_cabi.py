@@ -889,10 +889,19 @@ def resolve_cutoff(cutoff: float, s: int) -> float:
 CHOICE_FLAGS = FLAG_FWD_WIDE | FLAG_FWD_NARROW | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN
 
 
+_N_CHOICES = 0      # registrations made through this module since the last clear (0 = the fused host path skips its lookup)
+
+
+def kernel_choices_registered() -> bool:
+    return _N_CHOICES > 0
+
+
 def set_kernel_choice(shape: Dims, flags: int, list_cap: int = 0) -> None:
     """Register the kernel choice for plans of `shape` (a Dims as `make_dims` / `make_batch_dims` builds them; only its shape
     fields and FLAG_FORWARD_ONLY are read).  Later calls without an explicit choice of their own follow it."""
+    global _N_CHOICES
     check(lib().gsasr_set_kernel_choice(ctypes.byref(shape), int(flags), int(list_cap)), "gsasr_set_kernel_choice")
+    _N_CHOICES += 1
     _PLAN_DIMS.clear()      # workspace sizes follow the registered choice
     _STEP_DIMS.clear()
 
@@ -905,6 +914,8 @@ def get_kernel_choice(shape: Dims) -> Optional[Tuple[int, int]]:
 
 
 def clear_kernel_choices() -> None:
+    global _N_CHOICES
     lib().gsasr_clear_kernel_choices()
+    _N_CHOICES = 0
     _PLAN_DIMS.clear()
     _STEP_DIMS.clear()

@@ -126,7 +126,7 @@ def _render_chunked(sigmas, xy, col, H, W, dmax, device, buffer_size):
 BACKWARD_KERNEL = "auto"
 
 
-def _tile_backward(n_pixels: int, n_gaussians: int) -> bool:
+def _tile_backward(n_pixels: int, n_gaussians: int, shape=None) -> bool:
     """Measured through this API on MI355X (tools/e2e_modes.py, profiles/r02_e2e_modes.txt): with >= 4 HR pixels per
     Gaussian (one Gaussian per LR pixel at x2 and up) the tile-stationary backward is level or ahead end to end -- it reads
     the planar gradient in place, where the Gaussian-stationary kernel needs it interleaved first -- and it is
@@ -134,7 +134,23 @@ def _tile_backward(n_pixels: int, n_gaussians: int) -> bool:
     Gaussians and the Gaussian-stationary kernel is 15-50% faster.  Small images have too few tiles to fill the chip."""
     if BACKWARD_KERNEL != "auto":
         return BACKWARD_KERNEL == "tile"
+    if shape is not None:       # a choice measured and registered for this shape (gsasr_amd/tune.py) goes before the rule
+        from . import _cabi
+        if _cabi.kernel_choices_registered():
+            hit = _cabi.get_kernel_choice(shape())
+            if hit is not None and hit[0] & (_cabi.FLAG_BWD_TILE | _cabi.FLAG_BWD_GAUSSIAN):
+                return bool(hit[0] & _cabi.FLAG_BWD_TILE)
     return n_pixels >= 4 * n_gaussians and n_pixels >= 128 * 1024
+
+
+def _step_shape(n, H, W, dm):
+    from . import _cabi
+    return lambda: _cabi.make_dims(n, H, W, dm)
+
+
+def _batch_shape(n_per, sizes, dm):
+    from . import _cabi
+    return lambda: _cabi.make_batch_dims(n_per, sizes, max(w for _, w in sizes), max(h for h, _ in sizes), dm)
 
 
 def _plan_flags(needs_grad: bool, tile: bool) -> int:
@@ -163,7 +179,7 @@ class _FusedStep(torch.autograd.Function):
         # the planar gradient autograd hands back goes to the C call as it is (GSASR_FLAG_CHW_GRAD): the
         # tile-stationary backward stages the planes directly, the Gaussian-stationary one behind one interleaving
         # kernel inside the same call -- no torch permute / allocation on the host path either way
-        flags = _plan_flags(ctx.needs_input_grad[0], _tile_backward(H * W, gs_parameters.shape[0]))
+        flags = _plan_flags(ctx.needs_input_grad[0], _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dmax)))
         img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax, flags, scale_modify, default_step)   # one C call: prologue + plan + splat
         ctx.save_for_backward(gs_parameters, step)
         ctx.plan = plan
@@ -295,7 +311,7 @@ def _fused_step(gs_parameters, step, H, W, dm, scale_modify=None, default_step=1
     if _cpp_node.load() is None:
         return _FusedStep.apply(gs_parameters, step, H, W, dm, scale_modify, default_step)
     needs_grad = gs_parameters.requires_grad and torch.is_grad_enabled()
-    flags = _plan_flags(needs_grad, _tile_backward(H * W, gs_parameters.shape[0]))
+    flags = _plan_flags(needs_grad, _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dm)))
     return _cpp_node.fused_step_apply(gs_parameters, step, H, W, dm, flags, scale_modify, default_step)
 
 
@@ -305,7 +321,8 @@ def _fused_batch(gs_parameters, steps, sizes, dm, scale_modify=None, default_ste
     if _cpp_node.load() is None:
         return _FusedBatch.apply(gs_parameters, steps, sizes, dm, scale_modify, default_step)
     needs_grad = gs_parameters.requires_grad and torch.is_grad_enabled()
-    tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1])
+    tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1],
+                          _batch_shape(gs_parameters.shape[1], sizes, dm))
     return _cpp_node.fused_step_apply(gs_parameters, steps, 0, 0, dm, _plan_flags(needs_grad, tile), scale_modify, default_step, sizes=sizes)
 
 
@@ -490,7 +507,8 @@ class _FusedBatch(torch.autograd.Function):
     @fp32_boundary_fwd
     def forward(ctx, gs_parameters, steps, sizes, dmax, scale_modify=None, default_step=1.2):
         from . import _cabi
-        tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1])
+        tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1],
+                              _batch_shape(gs_parameters.shape[1], sizes, dmax))
         flags = _plan_flags(ctx.needs_input_grad[0], tile)
         img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax, flags, scale_modify, default_step)
         ctx.save_for_backward(gs_parameters, steps)

@@ -71,6 +71,51 @@ def candidates(s: int, w: int, rows: int, backward: bool):
     return out
 
 
+def _measure(cands, step, iters: int, rounds: int) -> TuneResult:
+    """time `step(flags, list_cap)` for every (name, flags, list_cap) of `cands` (the first one is the default)"""
+    res = TuneResult(cands[0][0], cands[0][1], cands[0][2])
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # The GPU's clocks follow its load: a burst of a few steps after an idle gap runs slower than the same steps a moment
+    # later, which would favour whichever combination is measured last.  So: warm up on the default for WARM_MS first, keep
+    # the queue busy from then on (one synchronisation per measurement), go round the combinations `rounds` times and keep
+    # each one's fastest round.
+    a.record()
+    t = 0.0
+    while t < WARM_MS:
+        for _ in range(4):
+            step(cands[0][1], cands[0][2])
+        b.record()
+        b.synchronize()
+        t = a.elapsed_time(b)
+    alive = {}
+    for name, flags, cap in cands:
+        try:
+            step(flags, cap)                        # (first use of a layout: workspace allocation)
+            alive[name] = (flags, cap)
+        except RuntimeError:
+            pass                                    # a combination this shape does not admit
+    n = max(1, iters)
+    for _ in range(max(1, rounds)):
+        for name, (flags, cap) in alive.items():
+            a.record()
+            for _ in range(n):
+                step(flags, cap)
+            b.record()
+            b.synchronize()
+            ms = a.elapsed_time(b) / n
+            res.ms[name] = min(ms, res.ms.get(name, ms))
+    return res
+
+
+def _pick(res: TuneResult, cands) -> None:
+    if cands[0][0] not in res.ms:
+        raise RuntimeError("tune: the default combination failed")
+    best = min(res.ms, key=res.ms.get)
+    if best != cands[0][0] and res.ms[best] <= (1.0 - MIN_GAIN) * res.ms[cands[0][0]]:
+        res.name = best
+        res.flags, res.list_cap = next((f, c) for nm, f, c in cands if nm == best)
+
+
 def tune(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: int, w: int, dmax: Optional[float],
          *, backward: bool = True, rows: Optional[Tuple[int, int]] = None, cutoff: float = 0.0, iters: int = 3,
          register: bool = True, grad: Optional[torch.Tensor] = None, forward_only_plan: Optional[bool] = None,
@@ -98,7 +143,6 @@ def tune(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
     if prev is not None:            # measure the library's own rule as "default", not an earlier registration
         _cabi.set_kernel_choice(shape, 0, 0)
     dev = sigmas.device
-    res = TuneResult("default", 0, 0)
     cands = candidates(s, w, nrows, backward)
     with torch.no_grad():
         img = torch.empty(nrows, w, 3, device=dev)
@@ -112,49 +156,86 @@ def tune(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
             if backward:
                 _cabi.backward(p, sigmas, coords, colors, g, gs, gc, gk, overwrite=True)
 
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # The GPU's clocks follow its load: a burst of a few steps after an idle gap runs slower than the same steps a moment
-        # later, which would favour whichever combination is measured last.  So: warm up on the default for WARM_MS first, keep
-        # the queue busy from then on (one synchronisation per measurement), go round the combinations `rounds` times and keep
-        # each one's fastest round.
-        a.record()
-        t = 0.0
-        while t < WARM_MS:
-            for _ in range(4):
-                step(0, 0)
-            b.record()
-            b.synchronize()
-            t = a.elapsed_time(b)
-        alive = {}
-        for name, flags, cap in cands:
-            try:
-                step(flags, cap)                        # (first use of a layout: workspace allocation)
-                alive[name] = (flags, cap)
-            except RuntimeError:
-                pass                                    # a combination this shape does not admit
-        n = max(1, iters)
-        for _ in range(max(1, rounds)):
-            for name, (flags, cap) in alive.items():
-                a.record()
-                for _ in range(n):
-                    step(flags, cap)
-                b.record()
-                b.synchronize()
-                ms = a.elapsed_time(b) / n
-                res.ms[name] = min(ms, res.ms.get(name, ms))
+        res = _measure(cands, step, iters, rounds)
     if prev is not None and not register:
         _cabi.set_kernel_choice(shape, *prev)
-    if "default" not in res.ms:
-        raise RuntimeError("tune(): the default combination failed")
-    best = min(res.ms, key=res.ms.get)
-    if best != "default" and res.ms[best] <= (1.0 - MIN_GAIN) * res.ms["default"]:
-        res.name = best
-        res.flags, res.list_cap = next((f, c) for nm, f, c in cands if nm == best)
+    _pick(res, cands)
     if register:
         _cabi.set_kernel_choice(shape, res.flags, res.list_cap)
         res.registered = True
     _SEEN.add(_shape_key(s, h, w, dmax, rows, cutoff, forward_only_plan))
     return res
+
+
+def _fused_candidates(s: int, w: int, rows: int, default_tile: bool):
+    """backward kernel x lists for the fused entry points (their forward is the 8 x 16 kernel or, on single images, the library's
+    own choice): the first entry is what gsasr_amd.gaussian_splatting does untuned"""
+    T, G = _cabi.FLAG_BWD_TILE, _cabi.FLAG_BWD_GAUSSIAN
+    cap = default_list_capacity(s, w, rows, False)
+    return [("default", T if default_tile else G, 0), ("gaussian-search", G, -1), ("gaussian-lists", G, cap),
+            ("tile-search", T, -1), ("tile-lists", T, cap)]
+
+
+def _tune_fused(shape, cands, run, iters, rounds, register) -> TuneResult:
+    prev = _cabi.get_kernel_choice(shape)
+    state = {"cap": None}
+
+    def step(flags, cap):
+        if cap != state["cap"]:                     # the fused calls carry no list_cap of their own: the registry supplies it
+            _cabi.set_kernel_choice(shape, 0, cap)
+            state["cap"] = cap
+        run(flags)
+
+    try:
+        with torch.no_grad():
+            res = _measure(cands, step, iters, rounds)
+    finally:
+        _cabi.set_kernel_choice(shape, *(prev if prev is not None else (0, 0)))
+    _pick(res, cands)
+    if register:
+        _cabi.set_kernel_choice(shape, res.flags if res.name != "default" else 0, res.list_cap)
+        res.registered = True
+    return res
+
+
+def tune_batch(gs_parameters: torch.Tensor, steps: torch.Tensor, sizes, dmax: Optional[float], *, iters: int = 3, rounds: int = 3,
+               register: bool = True) -> TuneResult:
+    """The batched training step (`generate_2D_gaussian_splatting_batch`: `gs_parameters[B,N,9]`, per-sample step sizes and
+    `(h, w)`): time prologue + plan + forward + backward for {Gaussian-, tile-stationary backward} x {lists, search} on THIS
+    batch and register the winner for the canvas shape; the fused host path follows the registration from then on."""
+    from .gaussian_splatting import _tile_backward
+    if not gs_parameters.is_cuda or torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("tune_batch() measures on the GPU, outside stream capture")
+    B, n = gs_parameters.shape[0], gs_parameters.shape[1]
+    h_max, w_max = max(h for h, _ in sizes), max(w for _, w in sizes)
+    shape = _cabi.make_batch_dims(n, sizes, w_max, h_max, dmax)
+    gp = gs_parameters.detach().contiguous()
+    grad = torch.ones(B, 3, h_max, w_max, device=gp.device)
+
+    def run(flags):
+        _, plan = _cabi.batch_forward(gp, steps, sizes, dmax, _cabi.FLAG_CHW_GRAD | flags)
+        _cabi.batch_backward(plan, gp, None, grad, chw=True)
+
+    default_tile = _tile_backward(sum(h * w for h, w in sizes), B * n)
+    return _tune_fused(shape, _fused_candidates(B * n, w_max, shape.slot * B, default_tile), run, iters, rounds, register)
+
+
+def tune_step(gs_parameters: torch.Tensor, step: torch.Tensor, h: int, w: int, dmax: Optional[float], *, iters: int = 3,
+              rounds: int = 3, register: bool = True) -> TuneResult:
+    """The fused single-image step (`generate_2D_gaussian_splatting_step` on raw decoder output `[N,9]`): as `tune_batch`."""
+    from .gaussian_splatting import _tile_backward
+    if not gs_parameters.is_cuda or torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("tune_step() measures on the GPU, outside stream capture")
+    n = gs_parameters.shape[0]
+    shape = _cabi.make_dims(n, h, w, dmax)
+    gp = gs_parameters.detach().contiguous()
+    grad = torch.ones(3, int(h), int(w), device=gp.device)
+
+    def run(flags):
+        _, plan = _cabi.step_forward(gp, step, h, w, dmax, _cabi.FLAG_CHW_GRAD | flags)
+        _cabi.step_backward(plan, gp, None, grad, chw=True)
+
+    return _tune_fused(shape, _fused_candidates(n, w, h, _tile_backward(h * w, n)), run, iters, rounds, register)
 
 
 def autotune_hook(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: int, w: int, dmax: Optional[float],

@@ -125,3 +125,57 @@ def test_autotune_hook_tunes_a_shape_once(monkeypatch):
     assert _cabi.get_kernel_choice(_cabi.make_dims(sig.shape[0], H, W, 0.1)) is not None
     # (the same combination both times; list order -- hence fp32 summation order -- may differ between two plans)
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
+@pytest.mark.gpu
+def test_tune_batch_registers_for_the_canvas_and_the_fused_path_follows(monkeypatch):
+    """the batched training step: tune_batch times {backward kernel} x {lists, search} on the batch, registers the winner under the
+    canvas shape; gaussian_splatting's fused path reads the registration (backward kernel in Python, lists in the C library) and
+    computes the gradients of the untuned path"""
+    from gsasr_amd import gaussian_splatting as gsp
+    dev = torch.device("cuda:0")
+    B, lr, scale = 4, 24, 4.0
+    sizes = [(96, 96)] * B
+    p = torch.stack([synthetic.gs_parameters(lr, lr, seed=20 + b, gpp=16) for b in range(B)]).to(dev)
+    sms = [torch.tensor([scale, scale]) for _ in range(B)]
+    wgt = torch.rand(B, 3, 96, 96, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def grads():
+        pa = p.clone().requires_grad_(True)
+        out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, [scale] * B, sms, dmax=0.5)
+        (out * wgt).sum().backward()
+        return out.detach(), pa.grad
+
+    ref = grads()
+    steps = torch.full((B,), 1.2 / scale, device=dev)
+    res = tune.tune_batch(p, steps, sizes, 0.5)
+    assert res.registered and set(res.ms) >= {"default", "gaussian-search", "tile-search"}
+    shape = _cabi.make_batch_dims(p.shape[1], sizes, 96, 96, 0.5)
+    assert _cabi.get_kernel_choice(shape) is not None
+    # force the combination the rule would NOT pick, through the registry alone, and check the fused path really switches
+    seen = []
+    real = _cabi.batch_forward
+    monkeypatch.setattr(_cabi, "batch_forward", lambda *a, **k: seen.append(a[4] if len(a) > 4 else k.get("extra_flags", 0)) or real(*a, **k))
+    from gsasr_amd import _cpp_node
+    monkeypatch.setattr(_cpp_node, "load", lambda: None)        # (the Python node: its flags are visible here)
+    for flag in (_cabi.FLAG_BWD_TILE, _cabi.FLAG_BWD_GAUSSIAN):
+        _cabi.set_kernel_choice(shape, flag, -1)
+        out = grads()
+        assert seen[-1] & (_cabi.FLAG_BWD_TILE | _cabi.FLAG_BWD_GAUSSIAN) == flag
+        for a, b, what in zip(out, ref, ("image", "d gs_parameters")):
+            top = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 3e-5 * max(top, 1.0), (flag, what)
+
+
+@pytest.mark.gpu
+def test_tune_step_on_a_single_fused_image():
+    from gsasr_amd import gaussian_splatting as gsp
+    dev = torch.device("cuda:0")
+    p = synthetic.gs_parameters(64, 64, seed=31, gpp=4).to(dev)
+    step = torch.tensor([0.3], device=dev)
+    res = tune.tune_step(p, step, 256, 256, 0.1)
+    assert res.registered and "default" in res.ms and res.ms[res.name] <= res.ms["default"]
+    pa = p.clone().requires_grad_(True)
+    out = gsp.generate_2D_gaussian_splatting_step((256, 256), pa, 4.0, torch.tensor([4.0, 4.0]), dmax=0.1)
+    out.sum().backward()
+    assert torch.isfinite(pa.grad).all() and float(out.abs().max()) > 0
