@@ -684,12 +684,16 @@ __device__ __forceinline__ void bt_eval(const PlanView &V, unsigned j, float dm,
 // LISTS (round 5): the tile's survivors and their quadrants come from the plan's tile list (k_bin's tl_emit: {slot in cell order |
 // test << 31, quadrant mask | slot in part[] << 16}) instead of level 1's walk over the cells around the tile; a tile whose list
 // overflowed its capacity walks as before.
-template <bool BOUNDED, int BT_CHUNKS, int HLOG, bool LISTS>
-__global__ __launch_bounds__(BT_THREADS << (HLOG - 4)) __attribute__((amdgpu_waves_per_eu((BT_CHUNKS * BT_WAVES << (HLOG - 4)) <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
+// WV = waves per tile: two per 16 rows (BT_WAVES); FOUR on 32 x 16-px tiles of dense plans read from lists (round 5) -- at 16
+// Gaussians per LR pixel a tile's list holds ~2 000 entries = 75 item chunks, and 2 048 tiles x 2 waves leave the chip one
+// generation of four waves per SIMD with nothing to balance: config-5 canvas 320 -> 266 us, 1024^2 at 16 per LR pixel 459 -> 424
+// (profiles/r05_bt_variants.txt; the same four waves on x8's 32 x 32-px tiles lose: 1 210 -> 1 648 us at config 4).
+template <bool BOUNDED, int BT_CHUNKS, int HLOG, bool LISTS, int WV = (BT_WAVES << (HLOG - 4))>
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu((BT_CHUNKS * WV) <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
     Params P, PlanView V, const float *__restrict__ grad, int tiles_x, int use_atomics)
 {
     constexpr int BT_H = 1 << HLOG, NQY = BT_H / 8, NQ = 4 * NQY;   // tile height, quadrant rows, quadrants (8 or 16)
-    constexpr int WAVES = BT_WAVES << (HLOG - 4), THREADS = 64 * WAVES;
+    constexpr int WAVES = WV, THREADS = 64 * WAVES;
     constexpr int BT_LIST = WAVES * BT_CHUNKS * 64;     // survivors per round at most (512 / 256)
     __shared__ __attribute__((aligned(16))) float s_g[NQ * BT_QSTRIDE];
     __shared__ float s_px[BT_W], s_py[BT_H];
@@ -1067,15 +1071,19 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
     if (rows > 0) {
         const int bth = 1 << P.bt_hlog;
         const int tiles_x = (dims->w + BT_W - 1) / BT_W, tiles_y = (rows + bth - 1) / bth;
-        const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block((unsigned)BT_THREADS << (P.bt_hlog - 4));
+        dim3 grid((unsigned)tiles_x * (unsigned)tiles_y), block((unsigned)BT_THREADS << (P.bt_hlog - 4));
         // small rounds + five waves per SIMD from 32 HR pixels per Gaussian up (where this kernel is the default)
         const bool sparse = (double)rows * (double)dims->w >= 32.0 * (double)dims->s;
         // (the plan's tile lists serve this kernel when their tiles are its tiles)
         const bool lists = L.tl_ok && L.tl_hlog == P.bt_hlog;
 #define GSASR_BT(B, C, H) do { if (lists) hipLaunchKernelGGL((k_render_bwd_tile<B, C, H, true>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2); \
                                else hipLaunchKernelGGL((k_render_bwd_tile<B, C, H, false>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2); } while (0)
-#define GSASR_BT2(B, C) do { if (P.bt_hlog == 5) GSASR_BT(B, (C) / 2, 5); else GSASR_BT(B, C, 4); } while (0)
-        if (P.bounded) { if (sparse) GSASR_BT2(true, 4 / BT_WAVES); else GSASR_BT2(true, 8 / BT_WAVES); }
+#define GSASR_BT2(B, C) do { if (P.bt_hlog == 5) GSASR_BT(B, ((C) / 2 > 0 ? (C) / 2 : 1), 5); else GSASR_BT(B, C, 4); } while (0)
+        if (lists && !sparse && P.bt_hlog == 4 && tl_dense(dims)) {   // dense plans from lists: four waves per tile (rounds of 512 entries)
+            block = dim3(256);
+            if (P.bounded) hipLaunchKernelGGL((k_render_bwd_tile<true, 2, 4, true, 4>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2);
+            else hipLaunchKernelGGL((k_render_bwd_tile<false, 2, 4, true, 4>), grid, block, 0, st, P, V, grad_img, tiles_x, mode == 2);
+        } else if (P.bounded) { if (sparse) GSASR_BT2(true, 4 / BT_WAVES); else GSASR_BT2(true, 8 / BT_WAVES); }
         else { if (sparse) GSASR_BT2(false, 4 / BT_WAVES); else GSASR_BT2(false, 8 / BT_WAVES); }
 #undef GSASR_BT2
 #undef GSASR_BT
