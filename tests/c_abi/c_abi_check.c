@@ -141,6 +141,37 @@ int main(void)
         printf("tile lists dmax=%g band [%d,%d): image max|err| %.3e, grad(colors) rel err %.2e\n", dmax, h / 2, h, eimg, e5);
         if (!(eimg <= 2e-4) || !(e5 <= 2e-4)) bad = 1;
         CK(hipFree(ws));
+
+        /* the same choice REGISTERED for the shape instead of written into the dims (gsasr_set_kernel_choice, ABI 6): the plain dims
+         * `d` now size, plan and render like `dl`; explicit flags still win; clearing the registry restores the library's rule */
+        {
+            unsigned rf = 0; int rcap = 0;
+            if (gsasr_get_kernel_choice(&d, &rf, &rcap) != 0) { printf("a choice before any registration\n"); bad = 1; }
+            OK(gsasr_set_kernel_choice(&d, GSASR_FLAG_BWD_TILE | GSASR_FLAG_FWD_NARROW, 256));
+            if (gsasr_get_kernel_choice(&d, &rf, &rcap) != 1 || rf != (GSASR_FLAG_BWD_TILE | GSASR_FLAG_FWD_NARROW) || rcap != 256) { printf("registered choice not returned\n"); bad = 1; }
+            if (gsasr_set_kernel_choice(&d, GSASR_FLAG_OVERWRITE_IMAGE, 0) == GSASR_OK) { printf("a non-choice flag was accepted\n"); bad = 1; }
+            const size_t rbytes = gsasr_splat_workspace_bytes(&d);
+            if (rbytes != lbytes) { printf("registered choice: workspace %zu, explicit flags %zu\n", rbytes, lbytes); bad = 1; }
+            gsasr_dims dg = d;
+            dg.flags |= GSASR_FLAG_BWD_GAUSSIAN;
+            dg.list_cap = -1;
+            if (gsasr_splat_workspace_bytes(&dg) != bytes) { printf("explicit flags did not win over the registration\n"); bad = 1; }
+            CK(hipMalloc(&ws, rbytes));
+            OK(gsasr_splat_plan(d_sig, d_xy, d_col, &d, ws, rbytes, st));
+            OK(gsasr_splat_forward(&d, ws, rbytes, d_img, st));
+            OK(gsasr_splat_backward(d_sig, d_xy, d_col, d_wgt + (size_t)(h / 2) * w * 3, d_gs, d_gc, d_gk, &d, ws, rbytes, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(img, d_img, sizeof(float) * 3 * rows * w, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(gk, d_gk, sizeof(float) * 3 * s, hipMemcpyDeviceToHost));
+            eimg = 0;
+            for (int i = 0; i < 3 * rows * w; ++i) { double dd = fabs((double)img[i] - ref[i]); if (dd > eimg) eimg = dd; }
+            const double e6 = maxrel(gk, rk, 3 * s);
+            printf("registered choice dmax=%g band [%d,%d): image max|err| %.3e, grad(colors) rel err %.2e\n", dmax, h / 2, h, eimg, e6);
+            if (!(eimg <= 2e-4) || !(e6 <= 2e-4)) bad = 1;
+            CK(hipFree(ws));
+            gsasr_clear_kernel_choices();
+            if (gsasr_get_kernel_choice(&d, &rf, &rcap) != 0 || gsasr_splat_workspace_bytes(&d) != bytes) { printf("clearing the registry did not restore the rule\n"); bad = 1; }
+        }
     }
     /* batched canvas (gsasr_dims.batch): two samples of different size from the same Gaussians, kernel-frame inputs;
      * every sample must equal the oracle's single-image result on ITS grid, padding must be zero */
