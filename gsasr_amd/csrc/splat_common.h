@@ -212,7 +212,7 @@ inline int classify_blocks(const gsasr_dims *d)
 // kernel choice the library makes by shape.  They are read ONLY when GSASR_SPLAT_DEV=1 is set as well -- a production process
 // that happens to carry one of the names in its environment is not affected -- and each is read once.
 //   GSASR_SPLAT_FWD_WIDE=0|1   GSASR_SPLAT_BWD=gaussian|tile|atomic   GSASR_SPLAT_BT_TALL=0|1   GSASR_SPLAT_ADAPT=0
-//   GSASR_SPLAT_FUSED_MAX=<k_bin blocks>   GSASR_SPLAT_LISTS=0|1   GSASR_SPLAT_BWD8=0|1
+//   GSASR_SPLAT_FUSED_MAX=<k_bin blocks>   GSASR_SPLAT_LISTS=0|1   GSASR_SPLAT_BWD8=0|1   GSASR_SPLAT_FWD_SPLIT=0
 // (GSASR_SPLAT_CUTOFF is not one of them: it is the documented process default of the support cutoff, INTEGRATION.md.)
 inline const char *dev_switch(const char *name)
 {
@@ -232,6 +232,13 @@ inline int fwd_wide_env()
         cached.store(v, std::memory_order_relaxed);
     }
     return v;
+}
+
+// development switch: GSASR_SPLAT_FWD_SPLIT=0 sends small images (< 4096 sub-tiles) to the two-level kernels instead of k_render_fwd_split
+inline bool fwd_split_env()
+{
+    static const bool on = [] { const char *e = dev_switch("GSASR_SPLAT_FWD_SPLIT"); return !e || atoi(e) != 0; }();
+    return on;
 }
 
 // Which forward kernel.  Scale factors from x5 up (FWD_WIDE_MIN HR pixels per Gaussian: windows of ~25 px and more), single

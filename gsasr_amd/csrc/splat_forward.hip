@@ -1024,9 +1024,12 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
             else hipLaunchKernelGGL(k_render_fwd16_list<false>, grid, block, 0, st, P, V, img, wx);
         } else if (P.bounded) hipLaunchKernelGGL(k_render_fwd16<true>, grid, block, 0, st, P, V, img, wx);
         else hipLaunchKernelGGL(k_render_fwd16<false>, grid, block, 0, st, P, V, img, wx);
-    } else if (nsub < 4096 && !(L.tl_ok && L.tl_hlog == 4)) {
-        // fewer sub-tiles than half the chip's 8192 wave slots: split each sub-tile's Gaussian list over
-        // 2..16 waves so that about one full set of waves is in flight
+    } else if (nsub < 4096 && !(L.tl_ok && L.tl_hlog == 4) && tl_dense(dims) && fwd_split_env()) {
+        // fewer sub-tiles than half the chip's 8192 wave slots on a DENSE plan (a 192^2 training crop at 16 Gaussians per LR
+        // pixel: thousands of candidates per sub-tile): split each sub-tile's Gaussian list over 2..16 waves so that about one
+        // full set of waves is in flight.  Sparse small images (one Gaussian per LR pixel: a sub-tile has a few dozen hits, and
+        // sixteen waves would each search all the candidates for them) take the two-level kernel below, two waves per sub-tile:
+        // 512^2 x4 forward 21.6 -> 11.8 us, 640^2 31.1 -> 15.8, 256^2 level (profiles/r05_split_vs_twolevel.txt)
         int nw = 2;
         while (nw < 16 && nsub * nw < 8192) nw *= 2;
         const dim3 grid((unsigned)nsub), block((unsigned)nw * 64u);
