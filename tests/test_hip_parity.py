@@ -326,7 +326,10 @@ def test_overwrite_flags_store_instead_of_accumulate(dev):
         plan = _cabi.plan(sig, xy, col, H, W, dmax)
         ref = _cabi.forward(plan, torch.zeros(H, W, 3, device=dev))
         out = _cabi.forward(plan, torch.full((H, W, 3), float("nan"), device=dev), overwrite=True)
-        assert torch.equal(out, ref)
+        # (the same sums, stored instead of added to zeros.  Not bit-equal: a sparse small image renders through the two-level
+        # forward since round 5, whose survivor list is built with LDS atomics -- the order of the fp32 additions differs from
+        # launch to launch by design, as the reference's own atomic adds do)
+        assert not torch.isnan(out).any() and float((out - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
         gz = [torch.zeros_like(t) for t in (sig, xy, col)]
         _cabi.backward(plan, sig, xy, col, wgt, *gz)
         gn = [torch.full_like(t, float("nan")) for t in (sig, xy, col)]
@@ -487,7 +490,7 @@ def test_chw_image_flag(dev):
         nr = H if rows is None else rows[1] - rows[0]
         hwc = _cabi.forward(plan, torch.zeros(nr, W, 3, device=dev))
         chw = _cabi.forward(plan, torch.full((3, nr, W), float("nan"), device=dev), overwrite=True, chw=True)
-        assert torch.equal(chw, hwc.permute(2, 0, 1))
+        assert not torch.isnan(chw).any() and float((chw - hwc.permute(2, 0, 1)).abs().max()) <= 1e-6 * max(1.0, float(hwc.abs().max()))   # (summation order: see above)
         base = torch.rand(3, nr, W, device=dev)
         acc = _cabi.forward(plan, base.clone(), chw=True)
         assert float((acc - (base + chw)).abs().max()) <= 1e-6
