@@ -1052,7 +1052,8 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         // Two instantiations of the same sweep (identical results): with the two-trip unrolled loop (88 VGPRs, 5 waves
         // per SIMD) for windows of many trips, without it (70 VGPRs, 7 waves) for small windows.  The window sizes are on
         // the device; GSASR's Gaussians are LR-pixel sized, so pixels per Gaussian is a good proxy (x4: 16, x8: 64).
-        const bool unroll = (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
+        static const int unroll_env = dev_switch("GSASR_SPLAT_BWD_UNROLL") ? atoi(dev_switch("GSASR_SPLAT_BWD_UNROLL")) : -1;   // development: 0 | 1
+        const bool unroll = unroll_env >= 0 ? unroll_env != 0 : (double)rows * (double)dims->w >= BWD_UNROLL_MIN * (double)dims->s;
         // (Measured dead ends, git history: two Gaussians per wave one after the other, side by side in half waves, and --
         // round 3 -- sharing every gradient load over the union of their windows: 44-50 us against 37 us at config 2; rows
         // or a cell's window staged in LDS; a planar-gradient sweep.  A wave's life is its chain of dependent round trips:

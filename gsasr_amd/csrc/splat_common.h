@@ -213,6 +213,7 @@ inline int classify_blocks(const gsasr_dims *d)
 // that happens to carry one of the names in its environment is not affected -- and each is read once.
 //   GSASR_SPLAT_FWD_WIDE=0|1   GSASR_SPLAT_BWD=gaussian|tile|atomic   GSASR_SPLAT_BT_TALL=0|1   GSASR_SPLAT_ADAPT=0
 //   GSASR_SPLAT_FUSED_MAX=<k_bin blocks>   GSASR_SPLAT_LISTS=0|1   GSASR_SPLAT_BWD8=0|1   GSASR_SPLAT_FWD_SPLIT=0
+//   GSASR_SPLAT_FWD_PARTS=1|2 (waves per sub-tile of the 8 x 16 forward)   GSASR_SPLAT_BWD_UNROLL=0|1 (Gaussian-stationary sweep)
 // (GSASR_SPLAT_CUTOFF is not one of them: it is the documented process default of the support cutoff, INTEGRATION.md.)
 inline const char *dev_switch(const char *name)
 {
