@@ -285,6 +285,9 @@ inline int bwd_env()
 // or by default where it is the faster one on this chip: measured the two backward kernels are level at
 // GSASR's x4 (one Gaussian per 16 HR pixels; the Gaussian-stationary one 10% ahead), and the tile-stationary one wins
 // from ~32 pixels per Gaussian up (x8: -7%), where a window holds enough quadrants to amortise the per-tile search.
+inline int lists_env();                          // (defined with the tile lists below)
+inline int list_cap_of(const gsasr_dims *d);
+
 inline bool bwd_wants_tile(const gsasr_dims *d)
 {
     if (d->flags & (GSASR_FLAG_FORWARD_ONLY | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_ATOMIC)) return false;
@@ -299,6 +302,13 @@ inline bool bwd_wants_tile(const gsasr_dims *d)
     // its pixels per Gaussian say nothing about the window size -- the shard's caller knows the scale and sets the flag)
     if (bwd_env() != 0 || d->batch > 1 || d->row0 != 0 || d->row1 != d->h) return false;
     const double px_per_gaussian = (double)d->h * (double)d->w / (double)(d->s > 0 ? d->s : 1);
+    // Round 5: one Gaussian per 2..4 pixels on a megapixel and more (x2 at one per LR pixel, x4 at four) -- a dense plan, whose
+    // tile lists this kernel then reads (same 32 x 16-px tiles as the 8 x 16 forward): 1024^2 x2 -16% per step, 2048^2 x2 -21%,
+    // 1024^2 x4 at 4 per LR pixel -4%, level at x8 / 16 per LR pixel; 512^2 images lose 4..15% and keep the Gaussian-stationary
+    // kernel, as do denser plans (16 per LR pixel at x4: level to +1%).  profiles/r05_pxg4.txt; the fused host path has drawn
+    // the same line since round 2 (gaussian_splatting._tile_backward).
+    if (px_per_gaussian >= 2.0 && px_per_gaussian <= 4.0 && (double)d->h * (double)d->w >= 1048576.0 && list_cap_of(d) >= 0 && lists_env() != 0)
+        return true;
     // (round 4, with the windows of the data-derived cutoff: at 2048^2 x8 the Gaussian-stationary kernel is 7% ahead, at
     // 3072^2 x6 the tile-stationary one 3%, from 5120^2 up 4..10%: the line is drawn at 8 Mpx)
     return px_per_gaussian >= 32.0 && (double)d->h * (double)d->w >= 8388608.0;
