@@ -1042,10 +1042,12 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         // the plan's tile lists (32 x 16-px tiles: the same workgroup tile as the two-level walk, and its two shapes), else the
         // two-level walk; images with fewer than 4096 sub-tiles (half the chip's wave slots) get two waves per sub-tile: 512^2
         // -8..-11%, 640^2 level, 768^2..896^2 +3..4%, above that +5..11% (profiles/r05_fwd_parts.txt; until the lists of round 5
-        // the line was at 8192: the search of a 4608-sub-tile canvas gained 13% from the second wave, its list walk gains nothing)
+        // the line was at 8192: the search of a 4608-sub-tile canvas gained 13% from the second wave).  From lists the second wave
+        // pays a little longer -- 768^2 at 16 per LR pixel -1%, the 4608-sub-tile canvas of config 5 -3%, 896^2 +1%: 6144 there
         const int tx4 = (subs_x + 3) / 4;
         static const int parts_env = dev_switch("GSASR_SPLAT_FWD_PARTS") ? atoi(dev_switch("GSASR_SPLAT_FWD_PARTS")) : 0;   // development: 1 | 2 waves per sub-tile
-        const bool two = parts_env ? parts_env == 2 : nsub < 4096, lists = L.tl_ok && L.tl_hlog == 4;
+        const bool lists = L.tl_ok && L.tl_hlog == 4;
+        const bool two = parts_env ? parts_env == 2 : nsub < (lists ? 6144 : 4096);
         const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
 #define GSASR_F3(K, B, T) do { if (pair) hipLaunchKernelGGL((K<B, T, true>), grid, block, 0, st, P, V, img, tx4); \
                                else hipLaunchKernelGGL((K<B, T, false>), grid, block, 0, st, P, V, img, tx4); } while (0)
