@@ -244,3 +244,25 @@ def test_compat_install_rebinds_models_that_import_at_package_import(tmp_path):
              "assert not left, left\nprint('ok')\n" % (ROOT, str(tmp_path)))
     r = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_default_backward_rule_by_workspace_size():
+    """which plans carry slots for the tile-stationary backward by default (bwd_wants_tile, gsasr_amd/csrc/splat_common.h): x8 and up
+    from 8 Mpx; since round 5 one Gaussian per 2..4 px from 1 Mpx (a dense plan whose tile lists that kernel reads).  Seen from the
+    host as the workspace a plan asks for, against the same dims with GSASR_FLAG_BWD_GAUSSIAN."""
+    import ctypes
+    from gsasr_amd import _cabi
+
+    def slots(s, h, w, **kw):
+        a = _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(_cabi.make_dims(s, h, w, 0.1, **kw)))
+        b = _cabi.lib().gsasr_splat_workspace_bytes(ctypes.byref(_cabi.make_dims(s, h, w, 0.1, flags=_cabi.FLAG_BWD_GAUSSIAN, **kw)))
+        assert a >= b
+        return a - b >= s * 32 * 8
+    assert slots(512 * 512, 1024, 1024)                  # x2, one Gaussian per LR pixel: 4 px per Gaussian on 1 Mpx
+    assert slots(4 * 256 * 256, 1024, 1024)              # x4 at four per LR pixel
+    assert not slots(256 * 256, 512, 512)                # x2 on 512^2: too few tiles
+    assert not slots(256 * 256, 1024, 1024)              # config 2: 16 px per Gaussian
+    assert not slots(16 * 256 * 256, 1024, 1024)         # 16 per LR pixel at x4: 1 px per Gaussian
+    assert not slots(512 * 512, 1024, 1024, rows=(0, 512))      # a row band: the caller decides (shard.py sets the flag)
+    assert not slots(512 * 512, 1024, 1024, list_cap=-1)        # no lists, no tile kernel at this density
+    assert slots(1024 * 1024, 8192, 8192)                # config 4
