@@ -119,14 +119,15 @@ int main(int argc, char **argv)
         dp.flags |= GSASR_FLAG_COUNTERS_CLEAN | ((++nplans & 1) ? 0u : GSASR_FLAG_PARITY);
         chk(gsasr_splat_plan(dsig, dxy, dcol, &dp, ws, wsb, st), "plan"); }, iters, st);
     const float t_fwd = time_us([&] { chk(gsasr_splat_forward(&d, ws, wsb, dimg, st), "fwd"); }, iters, st);
-    const float t_bwd = time_us([&] { chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d, ws, wsb, st), "bwd"); }, iters, st);
+    const bool fwd_only = (flags & GSASR_FLAG_FORWARD_ONLY) != 0u;      // (flags 70 = inference: a forward-only plan, no backward timed)
+    const float t_bwd = fwd_only ? 0.f : time_us([&] { chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d, ws, wsb, st), "bwd"); }, iters, st);
     CK(hipStreamSynchronize(st));
     // checksums so variants can be compared for (approximate) equality
     std::vector<float> img(grad.size()), gs(sig.size());
     CK(hipMemset(dimg, 0, grad.size() * 4)); CK(hipMemset(dgs, 0, sig.size() * 4));
     CK(hipMemset(dgc, 0, xy.size() * 4)); CK(hipMemset(dgk, 0, col.size() * 4));
     chk(gsasr_splat_forward(&d, ws, wsb, dimg, st), "fwd");
-    chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d, ws, wsb, st), "bwd");
+    if (!fwd_only) chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d, ws, wsb, st), "bwd");
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(img.data(), dimg, img.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(gs.data(), dgs, gs.size() * 4, hipMemcpyDeviceToHost));
