@@ -153,6 +153,20 @@ def _batch_shape(n_per, sizes, dm):
     return lambda: _cabi.make_batch_dims(n_per, sizes, max(w for _, w in sizes), max(h for h, _ in sizes), dm)
 
 
+# The caller's scale factor as a HINT for the forward kernel (never for the numbers).  The C library sees pixels per Gaussian, which
+# says "x2-sized windows" for x8 at Fea2GS's 16 Gaussians per LR pixel (4 px per Gaussian) -- the windows there are x8's, and the
+# wide forward (16 x 16-px sub-tiles) is 5..8% ahead (profiles/r05_inference_sweep.txt: x8d16_2048).  This module knows the scale.
+SCALE_HINT = True
+
+
+def _forward_flag(scale, H: int, W: int) -> int:
+    """FLAG_FWD_WIDE from x5 up on images of 2 Mpx and more (the library's own line at one Gaussian per LR pixel), else 0"""
+    if not SCALE_HINT or isinstance(scale, bool) or not isinstance(scale, (int, float)):
+        return 0            # (a tensor would cost a synchronisation to read: the library's rule stays)
+    from . import _cabi
+    return _cabi.FLAG_FWD_WIDE if scale >= 5.0 and H * W >= 2 * 1024 * 1024 else 0
+
+
 def _plan_flags(needs_grad: bool, tile: bool) -> int:
     """flags of a fused step's plan: the backward kernel is chosen HERE, explicitly (the library's own default would
     otherwise plan slots for large images that this module then never uses); planar gradient in, forward-only plans
@@ -174,12 +188,12 @@ class _FusedStep(torch.autograd.Function):
 
     @staticmethod
     @fp32_boundary_fwd
-    def forward(ctx, gs_parameters, step, H, W, dmax, scale_modify=None, default_step=1.2):
+    def forward(ctx, gs_parameters, step, H, W, dmax, scale_modify=None, default_step=1.2, extra_flags=0):
         from . import _cabi
         # the planar gradient autograd hands back goes to the C call as it is (GSASR_FLAG_CHW_GRAD): the
         # tile-stationary backward stages the planes directly, the Gaussian-stationary one behind one interleaving
         # kernel inside the same call -- no torch permute / allocation on the host path either way
-        flags = _plan_flags(ctx.needs_input_grad[0], _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dmax)))
+        flags = _plan_flags(ctx.needs_input_grad[0], _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dmax))) | int(extra_flags)
         img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax, flags, scale_modify, default_step)   # one C call: prologue + plan + splat
         ctx.save_for_backward(gs_parameters, step)
         ctx.plan = plan
@@ -192,7 +206,7 @@ class _FusedStep(torch.autograd.Function):
         from . import _cabi
         gs_parameters, step = ctx.saved_tensors
         g = _cabi.step_backward(ctx.plan, gs_parameters, step, grad_output.contiguous(), chw=True)
-        return g, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None
 
 
 class _FusedStepSampled(torch.autograd.Function):
@@ -292,26 +306,26 @@ class _StepSource:
         self.scale_modify, self.default_step = scale_modify, default_step
 
 
-def _fused_render(gs_parameters, sr_size, step_size, dmax):
+def _fused_render(gs_parameters, sr_size, step_size, dmax, scale=None):
     """[3,H,W] through the fused prologue; `step_size` may be a python number, a (GPU) tensor or a `_StepSource`."""
     H, W = _hw(sr_size)
     dm = None if dmax is None else float(dmax)
     if step_size.__class__ is _StepSource:
-        out = _fused_step(gs_parameters.contiguous(), None, H, W, dm, step_size.scale_modify, step_size.default_step)
+        out = _fused_step(gs_parameters.contiguous(), None, H, W, dm, step_size.scale_modify, step_size.default_step, _forward_flag(scale, H, W))
         deferred_asserts.watch(gs_parameters.device)      # (after the launch: a look covers this call's own pair)
         return out
     step = _step_tensor(step_size, gs_parameters.device)
-    return _fused_step(gs_parameters.contiguous(), step, H, W, dm)
+    return _fused_step(gs_parameters.contiguous(), step, H, W, dm, extra_flags=_forward_flag(scale, H, W))
 
 
-def _fused_step(gs_parameters, step, H, W, dm, scale_modify=None, default_step=1.2):
+def _fused_step(gs_parameters, step, H, W, dm, scale_modify=None, default_step=1.2, extra_flags=0):
     """`_FusedStep.apply`, as a C++ autograd node when the extension is there (gsasr_amd/_cpp_node.py: the engine calls its
     backward without taking the GIL -- the reference's training loop makes sixteen of these nodes per step)"""
     from . import _cpp_node
     if _cpp_node.load() is None:
-        return _FusedStep.apply(gs_parameters, step, H, W, dm, scale_modify, default_step)
+        return _FusedStep.apply(gs_parameters, step, H, W, dm, scale_modify, default_step, extra_flags)
     needs_grad = gs_parameters.requires_grad and torch.is_grad_enabled()
-    flags = _plan_flags(needs_grad, _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dm)))
+    flags = _plan_flags(needs_grad, _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dm))) | int(extra_flags)
     return _cpp_node.fused_step_apply(gs_parameters, step, H, W, dm, flags, scale_modify, default_step)
 
 
@@ -479,7 +493,7 @@ def generate_2D_gaussian_splatting_step(sr_size, gs_parameters, scale, scale_mod
                 deferred_asserts.watch(gs_parameters.device)
                 return out
             return _FusedStepSampled.apply(gs_parameters.contiguous(), _step_tensor(step_size, gs_parameters.device), H, W, dm, pts)
-        return _sample(_fused_render(gs_parameters, (H, W), step_size, dmax_eff), sample_coords)
+        return _sample(_fused_render(gs_parameters, (H, W), step_size, dmax_eff, scale), sample_coords)
     sigma_x, sigma_y, rho, coords, colours_with_alpha = _activate(gs_parameters)
     dev = sigma_x.device
     if cuda_rendering:

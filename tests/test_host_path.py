@@ -379,3 +379,26 @@ def test_cpp_autograd_node_is_loaded_and_equals_the_python_node(dev):
         G1.apply(a.t().contiguous().t(), b, c, torch.zeros(H, W, 3, device=dev), 0.3)      # non-contiguous sigmas
     with pytest.raises(RuntimeError):
         G1.apply(a, b, c, torch.zeros(H, W, 4, device=dev), 0.3)
+
+
+def test_scale_hint_picks_the_wide_forward_without_changing_the_numbers(dev):
+    """gaussian_splatting._forward_flag: from x5 up on >= 2 Mpx the fused path asks for the wide forward whatever the Gaussians per LR
+    pixel (the library's pixels-per-Gaussian rule reads x8 at 16 per LR pixel as small windows); same image and gradient either way"""
+    from gsasr_amd import _cabi, gaussian_splatting as gsp, synthetic
+    assert gsp._forward_flag(8, 2048, 2048) == _cabi.FLAG_FWD_WIDE and gsp._forward_flag(8.0, 1024, 1024) == 0
+    assert gsp._forward_flag(4, 4096, 4096) == 0 and gsp._forward_flag(torch.tensor(8.0), 4096, 4096) == 0
+    p = synthetic.gs_parameters(184, 184, seed=41, gpp=4).to(dev)           # x8 -> 1472^2 = 2.17 Mpx, 4 Gaussians per LR pixel
+    sm = torch.tensor([8.0, 8.0])
+    out = {}
+    old = gsp.SCALE_HINT
+    try:
+        for hint in (True, False):
+            gsp.SCALE_HINT = hint
+            pa = p.clone().requires_grad_(True)
+            img = gsp.generate_2D_gaussian_splatting_step((1472, 1472), pa, 8, sm, dmax=0.1)
+            img.square().sum().backward()
+            out[hint] = (img.detach(), pa.grad)
+    finally:
+        gsp.SCALE_HINT = old
+    for a, b in zip(out[True], out[False]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
