@@ -39,6 +39,7 @@ FLAG_FORWARD_ONLY = 64     # GSASR_FLAG_FORWARD_ONLY
 FLAG_BWD_GAUSSIAN = 128    # GSASR_FLAG_BWD_GAUSSIAN
 FLAG_BWD_TILE = 256        # GSASR_FLAG_BWD_TILE
 FLAG_BWD_ATOMIC = 512      # GSASR_FLAG_BWD_ATOMIC
+FLAG_BWD_HOME = 32768      # GSASR_FLAG_BWD_HOME (home-tile backward, ABI 7)
 FLAG_COUNTERS_CLEAN = 1024 # GSASR_FLAG_COUNTERS_CLEAN
 FLAG_PARITY = 2048         # GSASR_FLAG_PARITY
 FLAG_CUTOFF_CAP = 4096     # GSASR_FLAG_CUTOFF_CAP
@@ -130,7 +131,7 @@ def lib():
         L.gsasr_get_kernel_choice.restype = i
         L.gsasr_get_kernel_choice.argtypes = [dp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_int)]
         L.gsasr_clear_kernel_choices.restype = None
-        if L.gsasr_abi_version() != 6:
+        if L.gsasr_abi_version() != 7:
             raise RuntimeError("libgsasr_splat.so ABI version mismatch")
         _lib = L
     return _lib
@@ -314,7 +315,7 @@ def plan(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
     return Plan(d, ws, dev, pool_key, parity)
 
 
-_LAYOUT_FLAGS = FLAG_FORWARD_ONLY | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN | FLAG_BWD_ATOMIC | FLAG_CHW_GRAD | FLAG_STRIDE8
+_LAYOUT_FLAGS = FLAG_FORWARD_ONLY | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN | FLAG_BWD_ATOMIC | FLAG_BWD_HOME | FLAG_CHW_GRAD | FLAG_STRIDE8
 
 
 def _pool_key(d: Dims, nbytes: int, dev):
@@ -886,7 +887,7 @@ def resolve_cutoff(cutoff: float, s: int) -> float:
 
 
 # ---- kernel choices registered per shape (include/gsasr_splat.h: gsasr_set_kernel_choice; gsasr_amd/tune.py measures them) ----
-CHOICE_FLAGS = FLAG_FWD_WIDE | FLAG_FWD_NARROW | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN
+CHOICE_FLAGS = FLAG_FWD_WIDE | FLAG_FWD_NARROW | FLAG_BWD_TILE | FLAG_BWD_GAUSSIAN | FLAG_BWD_HOME
 
 
 _N_CHOICES = 0      # registrations made through this module since the last clear (0 = the fused host path skips its lookup)

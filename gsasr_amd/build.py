@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 # the translation units of the library (csrc/gsasr_splat.hip is the same code as ONE unit: the micro-benchmark tools/mb.hip builds that)
-PARTS = ["splat_api", "splat_plan", "splat_forward", "splat_backward", "splat_step", "splat_sampled", "splat_shard"]
+PARTS = ["splat_api", "splat_plan", "splat_forward", "splat_backward", "splat_backward_home", "splat_step", "splat_sampled", "splat_shard"]
 INC = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
@@ -33,7 +33,7 @@ def hipcc() -> str:
 
 
 def _deps():
-    return [os.path.join(CSRC, p + ".hip") for p in PARTS] + [os.path.join(CSRC, "splat_common.h"), os.path.join(INC, "gsasr_splat.h")]
+    return [os.path.join(CSRC, p + ".hip") for p in PARTS] + [os.path.join(CSRC, "splat_common.h"), os.path.join(CSRC, "splat_bwd_sweep.h"), os.path.join(INC, "gsasr_splat.h")]
 
 
 def needs_build() -> bool:
@@ -50,7 +50,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
     cc = hipcc()
-    common = os.path.getmtime(os.path.join(CSRC, "splat_common.h"))
+    common = max(os.path.getmtime(os.path.join(CSRC, "splat_common.h")), os.path.getmtime(os.path.join(CSRC, "splat_bwd_sweep.h")))
     header = os.path.getmtime(os.path.join(INC, "gsasr_splat.h"))
     tag = "" if out == LIB else "_" + os.path.splitext(os.path.basename(out))[0]
 

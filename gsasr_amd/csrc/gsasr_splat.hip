@@ -55,6 +55,7 @@
 #include "splat_plan.hip"
 #include "splat_forward.hip"
 #include "splat_backward.hip"
+#include "splat_backward_home.hip"
 #include "splat_step.hip"
 #include "splat_sampled.hip"
 #include "splat_shard.hip"

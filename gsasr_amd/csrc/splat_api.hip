@@ -157,11 +157,12 @@ float gsasr_get_default_cutoff(void) { return default_cutoff(); }
 
 int gsasr_set_kernel_choice(const gsasr_dims *shape, unsigned flags, int list_cap)
 {
-    constexpr unsigned ALLOWED = GSASR_FLAG_FWD_WIDE | GSASR_FLAG_FWD_NARROW | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_GAUSSIAN;
+    constexpr unsigned ALLOWED = GSASR_FLAG_FWD_WIDE | GSASR_FLAG_FWD_NARROW | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_HOME;
     if (!shape) return fail(GSASR_ERR_ARG, "null shape");
-    if (flags & ~ALLOWED) return fail(GSASR_ERR_ARG, "a kernel choice holds GSASR_FLAG_FWD_WIDE | _FWD_NARROW | _BWD_TILE | _BWD_GAUSSIAN only");
+    if (flags & ~ALLOWED) return fail(GSASR_ERR_ARG, "a kernel choice holds GSASR_FLAG_FWD_WIDE | _FWD_NARROW | _BWD_TILE | _BWD_GAUSSIAN | _BWD_HOME only");
     if ((flags & GSASR_FLAG_FWD_WIDE) && (flags & GSASR_FLAG_FWD_NARROW)) return fail(GSASR_ERR_ARG, "GSASR_FLAG_FWD_WIDE and _FWD_NARROW exclude each other");
-    if ((flags & GSASR_FLAG_BWD_TILE) && (flags & GSASR_FLAG_BWD_GAUSSIAN)) return fail(GSASR_ERR_ARG, "GSASR_FLAG_BWD_TILE and _BWD_GAUSSIAN exclude each other");
+    if (__builtin_popcount(flags & (GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_HOME)) > 1)
+        return fail(GSASR_ERR_ARG, "GSASR_FLAG_BWD_TILE, _BWD_GAUSSIAN and _BWD_HOME exclude each other");
     ChoiceEntry k = choice_key(shape);
     k.c = KernelChoice{flags, list_cap};
     std::lock_guard<std::mutex> lk(g_choice_mu);

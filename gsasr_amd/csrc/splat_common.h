@@ -268,7 +268,7 @@ inline int bwd_env()
     int v = cached.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = dev_switch("GSASR_SPLAT_BWD");
-        v = !e ? 0 : !strcmp(e, "gaussian") ? 1 : !strcmp(e, "tile") ? 2 : !strcmp(e, "atomic") ? 3 : 0;
+        v = !e ? 0 : !strcmp(e, "gaussian") ? 1 : !strcmp(e, "tile") ? 2 : !strcmp(e, "atomic") ? 3 : !strcmp(e, "home") ? 4 : 0;
         cached.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -290,7 +290,7 @@ inline int list_cap_of(const gsasr_dims *d);
 
 inline bool bwd_wants_tile(const gsasr_dims *d)
 {
-    if (d->flags & (GSASR_FLAG_FORWARD_ONLY | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_ATOMIC)) return false;
+    if (d->flags & (GSASR_FLAG_FORWARD_ONLY | GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_ATOMIC | GSASR_FLAG_BWD_HOME)) return false;
     if (d->flags & GSASR_FLAG_BWD_TILE) return true;
     {   // the registered choice of this shape (gsasr_set_kernel_choice)
         const unsigned rf = registered_choice(d).flags;
@@ -565,10 +565,11 @@ inline Params make_params(const gsasr_dims *d, const Layout &L)
     }
     P.ncx = L.ncx; P.ncy = L.ncy; P.ncells = L.ncells;
     P.flags = d->flags;
-    if (!(P.flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)))   // (the registered choice; the development A/B switch)
-        P.flags |= registered_choice(d).flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE);
-    if (!(P.flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC)))
-        P.flags |= bwd_env() == 2 ? GSASR_FLAG_BWD_TILE : bwd_env() == 3 ? GSASR_FLAG_BWD_ATOMIC : 0u;
+    constexpr unsigned BWD_ANY = GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_ATOMIC | GSASR_FLAG_BWD_HOME;
+    if (!(P.flags & BWD_ANY))   // (the registered choice; the development A/B switch)
+        P.flags |= registered_choice(d).flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_HOME);
+    if (!(P.flags & BWD_ANY))
+        P.flags |= bwd_env() == 2 ? GSASR_FLAG_BWD_TILE : bwd_env() == 3 ? GSASR_FLAG_BWD_ATOMIC : bwd_env() == 4 ? GSASR_FLAG_BWD_HOME : 0u;
     P.batch = batch_of(d);
     P.slot = d->batch > 1 ? d->slot : d->h;
     P.nper = d->batch > 1 ? d->s / d->batch : d->s;
@@ -925,6 +926,9 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
 int splat_backward(const float *sigmas, const float *coords, const float *colors, const float *grad_img, float *g_sigmas,
                    float *g_coords, float *g_colors, const gsasr_dims *dims, const void *workspace, size_t workspace_bytes,
                    void *stream, bool gather, int *mode_out);
+// splat_backward_home.hip
+int launch_bwd_home(const Params &P, const PlanView &V, const float *grad_img, float *g_sigmas, float *g_coords, float *g_colors,
+                    int variant, hipStream_t st);
 // splat_step.hip
 struct StepLayout {
     size_t plan_bytes, off_step, off_sig, off_xy, off_col, off_gsig, off_gxy, off_gcol, off_ghwc, total;

@@ -44,7 +44,7 @@ extern "C" {
 #define GSASR_API
 #endif
 
-#define GSASR_SPLAT_ABI_VERSION 6 /* 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags; 4: the _sm step entry points, step_size = NULL in the step backwards; 5: gsasr_dims.list_cap (tile lists); 6: the kernel-choice registry */
+#define GSASR_SPLAT_ABI_VERSION 7 /* 7: GSASR_FLAG_BWD_HOME; 2: gsasr_dims gained batch / slot / sample_hw; 3: grad_rows, the backward flags; 4: the _sm step entry points, step_size = NULL in the step backwards; 5: gsasr_dims.list_cap (tile lists); 6: the kernel-choice registry */
 
 enum gsasr_status {
     GSASR_OK = 0,
@@ -83,6 +83,12 @@ enum gsasr_status {
                                          that were not written */
 #define GSASR_FLAG_BWD_ATOMIC 512u    /* tile-stationary with ONE fp32 atomic set per (tile, Gaussian) instead of the
                                          slots (the measured alternative of DESIGN.md 3c; order-dependent rounding)  */
+#define GSASR_FLAG_BWD_HOME 32768u    /* home-tile backward (ABI 7): a workgroup owns the Gaussians BINNED in its tile of plan cells, stages
+                                         the tile + a 16-px halo of grad_img once in LDS and finishes each of its Gaussians itself
+                                         (items of 8 x 8 px per lane, added in LDS, one write per Gaussian): no slots, no gather, no
+                                         atomics, deterministic.  Needs nothing from the plan beyond what the Gaussian-stationary
+                                         kernel reads; a Gaussian whose window does not fit the region is swept by a whole wave
+                                         (that kernel's code), so any input stays correct.  Interleaved [rows, w, 3] gradients */
 #define GSASR_FLAG_COUNTERS_CLEAN 1024u /* plan: the caller keeps this workspace between plans and promises that the
                                          per-cell counters of the parity given by GSASR_FLAG_PARITY are zero: the plan
                                          skips its memset launch.  Every plan zeroes the OTHER parity's counters on the

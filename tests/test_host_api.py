@@ -82,7 +82,7 @@ def test_cabi_exports_every_declared_symbol():
     L = ctypes.CDLL(_cabi.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _cabi.lib().gsasr_abi_version() == 6
+    assert _cabi.lib().gsasr_abi_version() == 7
 
 
 def test_workspace_bytes_and_bad_dims_no_gpu():

@@ -134,6 +134,42 @@ int main(int argc, char **argv)
     double si = 0, sg = 0;
     for (float v : img) si += v;
     for (float v : gs) sg += fabs(v);
+    // MB_ALT_FLAGS=<flags>: the backward again with these flags OR-ed in (another kernel on the same plan), timed and compared
+    // element by element with the first one: worst difference relative to the tensor's max-abs and to the Gaussian's own row
+    if (getenv("MB_ALT_FLAGS") && !fwd_only) {
+        gsasr_dims d2 = d;
+        d2.flags |= (unsigned)atoi(getenv("MB_ALT_FLAGS"));
+        std::vector<float> gc(xy.size()), gk(col.size()), gs2(sig.size()), gc2(xy.size()), gk2(col.size());
+        CK(hipMemcpy(gc.data(), dgc, gc.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gk.data(), dgk, gk.size() * 4, hipMemcpyDeviceToHost));
+        const float t_alt = time_us([&] { chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d2, ws, wsb, st), "bwd alt"); }, iters, st);
+        CK(hipMemset(dgs, 0, sig.size() * 4)); CK(hipMemset(dgc, 0, xy.size() * 4)); CK(hipMemset(dgk, 0, col.size() * 4));
+        chk(gsasr_splat_backward(dsig, dxy, dcol, dgrad, dgs, dgc, dgk, &d2, ws, wsb, st), "bwd alt");
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(gs2.data(), dgs, gs2.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gc2.data(), dgc, gc2.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gk2.data(), dgk, gk2.size() * 4, hipMemcpyDeviceToHost));
+        auto cmp = [&](const std::vector<float> &a, const std::vector<float> &b, int w, const char *name) {
+            double mx = 0, worst = 0, worst_row = 0;
+            long bad = -1, nan = 0;
+            for (float v : a) mx = std::max(mx, (double)fabs(v));
+            for (size_t k = 0; k < a.size() / w; ++k) {
+                double rm = 0, re = 0;
+                for (int c = 0; c < w; ++c) {
+                    rm = std::max(rm, (double)fabs(a[k * w + c]));
+                    const double e = fabs((double)a[k * w + c] - (double)b[k * w + c]);
+                    if (!(e == e)) ++nan;
+                    re = std::max(re, e);
+                }
+                worst = std::max(worst, re);
+                const double rr = re / (rm + 1e-5 * mx + 1e-30);
+                if (rr > worst_row) { worst_row = rr; bad = (long)k; }
+            }
+            printf("  alt %s: max|a|=%.4e worst abs diff / max = %.3e, worst row-relative = %.3e (Gaussian %ld) nan=%ld\n", name, mx, worst / (mx + 1e-30), worst_row, bad, nan);
+        };
+        printf("alt flags %u: bwd %.1f us (first %.1f us)\n", d2.flags, t_alt, t_bwd);
+        cmp(gs, gs2, 3, "g_sigmas"); cmp(gc, gc2, 2, "g_coords"); cmp(gk, gk2, 3, "g_colors");
+    }
     unsigned hdr[16];
     CK(hipMemcpy(hdr, ws, 64, hipMemcpyDeviceToHost));
     float tau_w;
