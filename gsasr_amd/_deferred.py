@@ -108,27 +108,35 @@ class _DeferredAsserts:
 deferred_asserts = _DeferredAsserts()
 
 
+_EXIT_FAILED = False
+
+
 def _flush_at_exit():
+    global _EXIT_FAILED
     try:
         deferred_asserts.flush()
     except AssertionError as e:      # (an exception in an atexit hook is printed, not raised: say it plainly, and fail the process)
         import os
         import sys
         print(f"gsasr_amd: deferred check failed at exit: {e}", file=sys.stderr)
-        if os.environ.get("GSASR_AMD_DEFERRED_EXIT", "1") == "0":    # opt-out: report only, leave the exit status alone
-            return
-        # The exit status can only be changed with os._exit, which skips every handler still to run (this one was registered
-        # at import, so it runs late, but process groups, loggers and profilers registered even earlier come after it):
-        # run those first, flush, then fail the process.
-        try:
-            atexit._run_exitfuncs()
-        except Exception:
-            pass
-        sys.stderr.flush()
-        sys.stdout.flush()
-        os._exit(1)
+        if os.environ.get("GSASR_AMD_DEFERRED_EXIT", "1") != "0":    # opt-out: report only, leave the exit status alone
+            _EXIT_FAILED = True      # (_exit_if_failed, which runs behind every handler registered since this import, fails the process)
     except Exception:
         pass
 
 
+def _exit_if_failed():
+    """The exit status can only be changed with os._exit, which skips every atexit handler still to run.  This handler is
+    registered BEFORE _flush_at_exit, i.e. it runs after it and after every handler registered later than this module's import
+    (the user's destroy_process_group, file closes, profilers): each of them has run exactly once by then.  (Round 5 re-ran
+    atexit's whole list from inside the failing handler, which ran the later-registered ones twice: ADVICE r5.)"""
+    if _EXIT_FAILED:
+        import os
+        import sys
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)
+
+
+atexit.register(_exit_if_failed)
 atexit.register(_flush_at_exit)

@@ -52,24 +52,31 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     cc = hipcc()
     common = max(os.path.getmtime(os.path.join(CSRC, "splat_common.h")), os.path.getmtime(os.path.join(CSRC, "splat_bwd_sweep.h")))
     header = os.path.getmtime(os.path.join(INC, "gsasr_splat.h"))
-    tag = "" if out == LIB else "_" + os.path.splitext(os.path.basename(out))[0]
+    # objects are cached per output name AND per flag list (a what-if build with other -D switches must not link stale objects)
+    import hashlib
+    flag_tag = hashlib.sha1(" ".join([*HIPCC_FLAGS, *extra_flags]).encode()).hexdigest()[:8]
+    tag = ("" if out == LIB else "_" + os.path.splitext(os.path.basename(out))[0]) + "_" + flag_tag
 
     def one(part):
         src, obj = os.path.join(CSRC, part + ".hip"), os.path.join(OBJ_DIR, part + tag + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), common, header):
             return obj
-        cmd = [cc, *HIPCC_FLAGS, *extra_flags, "-I", INC, "-c", src, "-o", obj]
+        tmp = f"{obj}.{os.getpid()}.tmp"      # (ranks that build at first import must not link each other's half-written objects)
+        cmd = [cc, *HIPCC_FLAGS, *extra_flags, "-I", INC, "-c", src, "-o", tmp]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(tmp, obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(PARTS)) as ex:
         objs = list(ex.map(one, PARTS))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", out]
+    tmp_out = f"{out}.{os.getpid()}.tmp"
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", tmp_out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(tmp_out, out)
     return out
 
 

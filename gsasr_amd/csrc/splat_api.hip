@@ -69,6 +69,11 @@ KernelChoice registered_choice(const gsasr_dims *d)
 // a note overwritten by a colliding workspace -- is ignored.
 constexpr int NOTES = 1024;
 static std::atomic<unsigned long long> g_notes[NOTES];
+// ... and a second word per note: the capacity of the plan's tile lists (the stride of tl_entries), tagged with the same shape
+// hash.  The capacity follows from gsasr_dims.list_cap OR from the kernel choice registered for the shape at PLAN time; a
+// forward / backward that re-derived it from the registry would, after a tune() / reset between the plan and the render, read
+// the lists with another stride than k_bin wrote them with.  The plan's value is frozen here instead.
+static std::atomic<unsigned long long> g_note_caps[NOTES];
 
 static unsigned note_slot(const void *ws) { return (unsigned)(((uintptr_t)ws >> 8) * 2654435761u >> 22) & (NOTES - 1); }
 
@@ -81,30 +86,37 @@ static unsigned long long note_shape(const gsasr_dims *d)
 }
 
 // (payload byte: slots per Gaussian in bits 0..4, the tile lists' tile height in bits 5..6: 0 none, 1 = 16 rows, 2 = 32)
-void note_plan(const void *ws, const gsasr_dims *d, int part_k, int tl_hlog)
+void note_plan(const void *ws, const gsasr_dims *d, int part_k, int tl_hlog, int tl_cap)
 {
+    // (the capacity first: a reader that sees the new first word also sees a capacity of the same plan or a newer one of the
+    // same workspace and shape -- concurrent plans on ONE workspace are the caller's race either way)
+    g_note_caps[note_slot(ws)].store((note_shape(d) << 32) | (unsigned long long)(unsigned)tl_cap, std::memory_order_release);
     const unsigned long long w = ((unsigned long long)(uintptr_t)ws & 0x0000ffffffffff00ull) << 16 | note_shape(d) << 8 |
                                  (unsigned long long)((part_k & 0x1f) | (tl_hlog ? (tl_hlog - 3) << 5 : 0));
-    g_notes[note_slot(ws)].store(w, std::memory_order_relaxed);
+    g_notes[note_slot(ws)].store(w, std::memory_order_release);
 }
 
 // layout of the plan in `ws`: from the note its plan left, else from these dims -- except the tile lists, which a call uses
 // only on the note's word (a lost note means the search, never a list nobody wrote)
 Layout plan_layout(const gsasr_dims *d, const void *ws)
 {
-    int part_k = -1, tl_hlog = -1;
+    int part_k = -1, tl_hlog = -1, tl_cap = -1;
+    bool cap_lost = false;
     if (ws) {
-        const unsigned long long w = g_notes[note_slot(ws)].load(std::memory_order_relaxed);
+        const unsigned long long w = g_notes[note_slot(ws)].load(std::memory_order_acquire);
         const unsigned long long key = ((unsigned long long)(uintptr_t)ws & 0x0000ffffffffff00ull) << 16 | note_shape(d) << 8;
         if ((w & ~0xffull) == key) {
             part_k = (int)(w & 0x1full);
             tl_hlog = (int)((w >> 5) & 3ull) ? (int)((w >> 5) & 3ull) + 3 : 0;
+            const unsigned long long c = g_note_caps[note_slot(ws)].load(std::memory_order_acquire);
+            if ((c >> 32) == note_shape(d)) tl_cap = (int)(unsigned)(c & 0xffffffffull);
+            else cap_lost = true;  // (the capacity word belongs to another plan: the lists are not read -- never with a guessed stride)
         }
     }
     // (without a note the list region is still SIZED from the dims -- the step entry points place their scratch behind the
     // plan -- but nothing reads it)
-    Layout L = make_layout(d, part_k, tl_hlog);
-    if (tl_hlog < 0) L.tl_ok = false;
+    Layout L = make_layout(d, part_k, tl_hlog, tl_cap);
+    if (tl_hlog < 0 || cap_lost) L.tl_ok = false;
     return L;
 }
 
@@ -168,7 +180,12 @@ int gsasr_set_kernel_choice(const gsasr_dims *shape, unsigned flags, int list_ca
     std::lock_guard<std::mutex> lk(g_choice_mu);
     for (ChoiceEntry &e : g_choices)
         if (same_shape(e, k)) { e.c = k.c; return GSASR_OK; }
-    if (g_choices.size() >= 256) return fail(GSASR_ERR_ARG, "256 kernel choices are registered: gsasr_clear_kernel_choices first");
+    if (flags == 0u && list_cap == 0) return GSASR_OK;      // "no choice" for a shape without an entry: nothing to store
+    if (g_choices.size() >= 256) {      // full: the oldest registration goes (a training run over ragged crop sizes must not
+        static unsigned oldest = 0;     // start failing at its 257th shape; that shape falls back to the library's rule)
+        g_choices[oldest++ & 255u] = k;
+        return GSASR_OK;
+    }
     g_choices.push_back(k);
     g_nchoices.store((int)g_choices.size(), std::memory_order_relaxed);
     return GSASR_OK;

@@ -413,7 +413,9 @@ inline int tl_cap_for(const gsasr_dims *d, int hlog)
     return (int)(cap > 65536 ? 65536 : cap);
 }
 
-inline Layout make_layout(const gsasr_dims *d, int part_k = -1, int tl_hlog = -1)
+// part_k / tl_hlog / tl_cap >= 0: the values the PLAN of this workspace was made with (its note, plan_layout) -- a forward or
+// backward must lay the workspace out as its plan did, whatever kernel choice has been registered or cleared for the shape since
+inline Layout make_layout(const gsasr_dims *d, int part_k = -1, int tl_hlog = -1, int tl_cap = -1)
 {
     Layout L{};
     L.ncx = (d->w + CELL - 1) / CELL;
@@ -449,7 +451,7 @@ inline Layout make_layout(const gsasr_dims *d, int part_k = -1, int tl_hlog = -1
     // tile lists LAST: a caller whose flags differ from the plan's (GSASR_FLAG_FWD_WIDE at forward time) lays out everything
     // else identically; whether the workspace carries lists, and of which tile height, is the plan's note (plan_layout)
     L.tl_hlog = tl_hlog >= 0 ? tl_hlog : tl_hlog_for(d);
-    L.tl_cap = tl_cap_for(d, L.tl_hlog);
+    L.tl_cap = (tl_cap >= 0 && L.tl_hlog) ? tl_cap : tl_cap_for(d, L.tl_hlog);
     L.tl_ntx = (d->w + TL_W - 1) / TL_W;
     L.tl_ntiles = L.tl_hlog ? L.tl_ntx * ((d->row1 - d->row0 + (1 << L.tl_hlog) - 1) >> L.tl_hlog) : 0;
     L.off_tlc = o;    o += align_up((size_t)L.tl_ntiles * TL_STRIDE * 4, 256);
@@ -582,7 +584,7 @@ inline Params make_params(const gsasr_dims *d, const Layout &L)
 }
 
 // ---- plan notes (splat_api.hip) ----
-void note_plan(const void *ws, const gsasr_dims *d, int part_k, int tl_hlog);
+void note_plan(const void *ws, const gsasr_dims *d, int part_k, int tl_hlog, int tl_cap);
 Layout plan_layout(const gsasr_dims *d, const void *ws);     // layout of the plan in `ws`: from the note its plan left, else from these dims
 int check_ws(const gsasr_dims *dims, const void *ws, size_t ws_bytes, Layout &L, bool planning = false);
 

@@ -782,7 +782,7 @@ int plan_impl(const float *sigmas, const float *coords, const float *colors, con
 {
     Layout L;
     if (int rc = check_ws(dims, workspace, workspace_bytes, L, true)) return rc;
-    note_plan(workspace, dims, L.part_k, L.tl_hlog);
+    note_plan(workspace, dims, L.part_k, L.tl_hlog, L.tl_cap);
     if (dims->s > 0 && (!sigmas || !coords || !colors)) return fail(GSASR_ERR_ARG, "null input pointer");
     hipStream_t st = (hipStream_t)stream;
     const Params P = make_params(dims, L);

@@ -266,14 +266,14 @@ int gsasr_step_backward(const float *gs_parameters, const float *step_size, cons
         HIP_TRY(hipGetLastError());
         grad_img = hwc;
         d.flags &= ~GSASR_FLAG_CHW_GRAD;
-        d.flags |= GSASR_FLAG_BWD_GAUSSIAN;
+        if (!(d.flags & GSASR_FLAG_BWD_HOME)) d.flags |= GSASR_FLAG_BWD_GAUSSIAN;      // (the home-tile kernel sweeps interleaved gradients too)
     }
     int mode = 0;
     if (int rc = splat_backward(sig, xy, col, grad_img, gs, gc, gk, &d, workspace, S.plan_bytes, stream, false, &mode)) return rc;
     if (dims->s == 0) return GSASR_OK;
     if (!gs_parameters || !step_size || !g_parameters) return fail(GSASR_ERR_ARG, "null pointer");
     const dim3 grid((unsigned)((dims->s + 255) / 256)), block(256);
-    if (mode != 0) {   // tile-stationary: gather of the slots + chain rule in one kernel
+    if (mode == 1 || mode == 2) {   // tile-stationary: gather of the slots + chain rule in one kernel
         const Layout L = plan_layout(dims, workspace);
         const PlanView V = make_view(L, workspace);
         hipLaunchKernelGGL(k_prologue_bwd_gather, grid, block, 0, (hipStream_t)stream, make_params(&d, L), V, (int)(mode == 2 || d.row1 == d.row0),

@@ -121,9 +121,25 @@ def _render_chunked(sigmas, xy, col, H, W, dmax, device, buffer_size):
 
 
 # Which backward kernel the fused entry points plan for: "gaussian" (one wave per Gaussian; needs the upstream gradient
-# permuted to [H,W,3]), "tile" (one workgroup per 32x16-px tile; reads the planar gradient in place; deterministic), or
-# "auto" (the measured choice per shape).
+# permuted to [H,W,3]), "tile" (one workgroup per 32x16-px tile; reads the planar gradient in place; deterministic), "home"
+# (round 6: a workgroup finishes the Gaussians binned in its tile from a staged region; interleaved gradient; deterministic)
+# or "auto" (the measured choice per shape).
 BACKWARD_KERNEL = "auto"
+
+
+def _backward_kernel(n_pixels: int, n_gaussians: int, shape=None) -> int:
+    """the C flag of the backward kernel the fused entry points plan for (FLAG_BWD_TILE / _GAUSSIAN / _HOME)"""
+    from . import _cabi
+    forced = {"tile": _cabi.FLAG_BWD_TILE, "gaussian": _cabi.FLAG_BWD_GAUSSIAN, "home": _cabi.FLAG_BWD_HOME}.get(BACKWARD_KERNEL)
+    if forced is not None:
+        return forced
+    if shape is not None and _cabi.kernel_choices_registered():      # a choice measured and registered for this shape (gsasr_amd/tune.py)
+        hit = _cabi.get_kernel_choice(shape())
+        if hit is not None:
+            for f in (_cabi.FLAG_BWD_TILE, _cabi.FLAG_BWD_GAUSSIAN, _cabi.FLAG_BWD_HOME):
+                if hit[0] & f:
+                    return f
+    return _cabi.FLAG_BWD_TILE if _tile_backward(n_pixels, n_gaussians) else _cabi.FLAG_BWD_GAUSSIAN
 
 
 def _tile_backward(n_pixels: int, n_gaussians: int, shape=None) -> bool:
@@ -167,14 +183,16 @@ def _forward_flag(scale, H: int, W: int) -> int:
     return _cabi.FLAG_FWD_WIDE if scale >= 5.0 and H * W >= 2 * 1024 * 1024 else 0
 
 
-def _plan_flags(needs_grad: bool, tile: bool) -> int:
+def _plan_flags(needs_grad: bool, kernel) -> int:
     """flags of a fused step's plan: the backward kernel is chosen HERE, explicitly (the library's own default would
     otherwise plan slots for large images that this module then never uses); planar gradient in, forward-only plans
-    for inference"""
+    for inference.  `kernel`: the C flag from _backward_kernel (or True / False = tile / Gaussian-stationary)"""
     from . import _cabi
     if not needs_grad:
         return _cabi.FLAG_FORWARD_ONLY
-    return _cabi.FLAG_CHW_GRAD | (_cabi.FLAG_BWD_TILE if tile else _cabi.FLAG_BWD_GAUSSIAN)
+    if isinstance(kernel, bool):
+        kernel = _cabi.FLAG_BWD_TILE if kernel else _cabi.FLAG_BWD_GAUSSIAN
+    return _cabi.FLAG_CHW_GRAD | int(kernel)
 
 
 class _FusedStep(torch.autograd.Function):
@@ -193,7 +211,7 @@ class _FusedStep(torch.autograd.Function):
         # the planar gradient autograd hands back goes to the C call as it is (GSASR_FLAG_CHW_GRAD): the
         # tile-stationary backward stages the planes directly, the Gaussian-stationary one behind one interleaving
         # kernel inside the same call -- no torch permute / allocation on the host path either way
-        flags = _plan_flags(ctx.needs_input_grad[0], _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dmax))) | int(extra_flags)
+        flags = _plan_flags(ctx.needs_input_grad[0], _backward_kernel(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dmax))) | int(extra_flags)
         img, plan = _cabi.step_forward(gs_parameters, step, H, W, dmax, flags, scale_modify, default_step)   # one C call: prologue + plan + splat
         ctx.save_for_backward(gs_parameters, step)
         ctx.plan = plan
@@ -325,7 +343,7 @@ def _fused_step(gs_parameters, step, H, W, dm, scale_modify=None, default_step=1
     if _cpp_node.load() is None:
         return _FusedStep.apply(gs_parameters, step, H, W, dm, scale_modify, default_step, extra_flags)
     needs_grad = gs_parameters.requires_grad and torch.is_grad_enabled()
-    flags = _plan_flags(needs_grad, _tile_backward(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dm))) | int(extra_flags)
+    flags = _plan_flags(needs_grad, _backward_kernel(H * W, gs_parameters.shape[0], _step_shape(gs_parameters.shape[0], H, W, dm))) | int(extra_flags)
     return _cpp_node.fused_step_apply(gs_parameters, step, H, W, dm, flags, scale_modify, default_step)
 
 
@@ -335,8 +353,8 @@ def _fused_batch(gs_parameters, steps, sizes, dm, scale_modify=None, default_ste
     if _cpp_node.load() is None:
         return _FusedBatch.apply(gs_parameters, steps, sizes, dm, scale_modify, default_step)
     needs_grad = gs_parameters.requires_grad and torch.is_grad_enabled()
-    tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1],
-                          _batch_shape(gs_parameters.shape[1], sizes, dm))
+    tile = _backward_kernel(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1],
+                            _batch_shape(gs_parameters.shape[1], sizes, dm))
     return _cpp_node.fused_step_apply(gs_parameters, steps, 0, 0, dm, _plan_flags(needs_grad, tile), scale_modify, default_step, sizes=sizes)
 
 
@@ -521,8 +539,8 @@ class _FusedBatch(torch.autograd.Function):
     @fp32_boundary_fwd
     def forward(ctx, gs_parameters, steps, sizes, dmax, scale_modify=None, default_step=1.2):
         from . import _cabi
-        tile = _tile_backward(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1],
-                              _batch_shape(gs_parameters.shape[1], sizes, dmax))
+        tile = _backward_kernel(sum(h * w for h, w in sizes), gs_parameters.shape[0] * gs_parameters.shape[1],
+                                _batch_shape(gs_parameters.shape[1], sizes, dmax))
         flags = _plan_flags(ctx.needs_input_grad[0], tile)
         img, plan = _cabi.batch_forward(gs_parameters, steps, sizes, dmax, flags, scale_modify, default_step)
         ctx.save_for_backward(gs_parameters, steps)

@@ -5,7 +5,7 @@ that really decide live on the device and no entry point synchronises to read th
 synthetic Gaussians ("about one LR pixel": gsasr_amd/synthetic.py).  On other size distributions another combination of
 
     forward  : 8 x 16 or 16 x 16-px sub-tiles           (FLAG_FWD_NARROW / FLAG_FWD_WIDE)
-    backward : Gaussian- or tile-stationary             (FLAG_BWD_GAUSSIAN / FLAG_BWD_TILE)
+    backward : Gaussian-, tile-stationary or home-tile   (FLAG_BWD_GAUSSIAN / FLAG_BWD_TILE / FLAG_BWD_HOME)
     lists    : the plan's tile lists, or the search     (list_cap > 0 / < 0)
 
 can be 5..45% faster (profiles/r05_policy_regret.txt).  `tune()` times the combinations on the tensors it is given --
@@ -64,7 +64,7 @@ def candidates(s: int, w: int, rows: int, backward: bool):
     """(name, flags, list_cap) of every combination, the library's own choice first"""
     out = [("default", 0, 0)]
     for fw, ff in (("narrow", _cabi.FLAG_FWD_NARROW), ("wide", _cabi.FLAG_FWD_WIDE)):
-        for bw, bf in ((("gaussian", _cabi.FLAG_BWD_GAUSSIAN), ("tile", _cabi.FLAG_BWD_TILE)) if backward else (("", 0),)):
+        for bw, bf in ((("gaussian", _cabi.FLAG_BWD_GAUSSIAN), ("tile", _cabi.FLAG_BWD_TILE), ("home", _cabi.FLAG_BWD_HOME)) if backward else (("", 0),)):
             for lists in (False, True):
                 cap = default_list_capacity(s, w, rows, fw == "wide") if lists else -1
                 out.append(("-".join(x for x in (fw, bw, "lists" if lists else "search") if x), ff | bf, cap))
@@ -128,6 +128,14 @@ def tune(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
     stream capture."""
     if not sigmas.is_cuda:
         raise RuntimeError("tune() measures on the GPU: CUDA tensors required")
+    # (the timing events must be recorded on the stream the kernels run on: the tensors' device, not whatever is current)
+    with torch.cuda.device(sigmas.device):
+        return _tune_on_device(sigmas, coords, colors, h, w, dmax, backward, rows, cutoff, iters, register, grad,
+                               forward_only_plan, rounds)
+
+
+def _tune_on_device(sigmas, coords, colors, h, w, dmax, backward, rows, cutoff, iters, register, grad, forward_only_plan,
+                    rounds) -> TuneResult:
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("tune() synchronises: not during stream capture")
     s = int(sigmas.shape[0])
@@ -161,7 +169,10 @@ def tune(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
         _cabi.set_kernel_choice(shape, *prev)
     _pick(res, cands)
     if register:
-        _cabi.set_kernel_choice(shape, res.flags, res.list_cap)
+        # The library's own rule won: nothing to register (the C table holds 256 shapes; ragged crop sizes reach that soon),
+        # an earlier registration of the shape is reset to "no choice".
+        if res.name != cands[0][0] or prev is not None:
+            _cabi.set_kernel_choice(shape, res.flags, res.list_cap)
         res.registered = True
     _SEEN.add(_shape_key(s, h, w, dmax, rows, cutoff, forward_only_plan))
     return res
@@ -170,10 +181,10 @@ def tune(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tensor, h: in
 def _fused_candidates(s: int, w: int, rows: int, default_tile: bool):
     """backward kernel x lists for the fused entry points (their forward is the 8 x 16 kernel or, on single images, the library's
     own choice): the first entry is what gsasr_amd.gaussian_splatting does untuned"""
-    T, G = _cabi.FLAG_BWD_TILE, _cabi.FLAG_BWD_GAUSSIAN
+    T, G, Hm = _cabi.FLAG_BWD_TILE, _cabi.FLAG_BWD_GAUSSIAN, _cabi.FLAG_BWD_HOME
     cap = default_list_capacity(s, w, rows, False)
     return [("default", T if default_tile else G, 0), ("gaussian-search", G, -1), ("gaussian-lists", G, cap),
-            ("tile-search", T, -1), ("tile-lists", T, cap)]
+            ("tile-search", T, -1), ("tile-lists", T, cap), ("home-search", Hm, -1), ("home-lists", Hm, cap)]
 
 
 def _tune_fused(shape, cands, run, iters, rounds, register) -> TuneResult:
@@ -247,7 +258,11 @@ def autotune_hook(sigmas: torch.Tensor, coords: torch.Tensor, colors: torch.Tens
     if not sigmas.is_cuda or sigmas.shape[0] == 0 or torch.cuda.is_current_stream_capturing():
         return
     _SEEN.add(key)
-    tune(sigmas.detach(), coords.detach(), colors.detach(), h, w, dmax, backward=backward, forward_only_plan=False)
+    try:
+        tune(sigmas.detach(), coords.detach(), colors.detach(), h, w, dmax, backward=backward, forward_only_plan=False)
+    except RuntimeError as e:      # never raise into the user's forward: the library's rule serves an untuned shape
+        import warnings
+        warnings.warn(f"gsasr_amd autotune skipped a shape: {e}")
 
 
 def reset() -> None:

@@ -266,3 +266,27 @@ def test_default_backward_rule_by_workspace_size():
     assert not slots(512 * 512, 1024, 1024, rows=(0, 512))      # a row band: the caller decides (shard.py sets the flag)
     assert not slots(512 * 512, 1024, 1024, list_cap=-1)        # no lists, no tile kernel at this density
     assert slots(1024 * 1024, 8192, 8192)                # config 4
+
+
+def test_deferred_assert_exit_runs_later_handlers_once():
+    """A deferred check that fails at interpreter exit fails the PROCESS (exit status 1) after every atexit handler registered
+    later than the package's import has run exactly once (round 5 re-ran atexit's list from inside the handler: ADVICE r5)."""
+    import subprocess
+    import sys
+    code = (
+        "import atexit, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from gsasr_amd import _deferred\n"
+        "def boom():\n"
+        "    raise AssertionError('scale_modify is not the same')\n"
+        "_deferred.deferred_asserts.flush = boom\n"
+        "atexit.register(lambda: print('later-handler', flush=True))\n"
+        "print('main-done', flush=True)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stdout, r.stderr)
+    assert r.stdout.count("later-handler") == 1 and "main-done" in r.stdout
+    assert "deferred check failed at exit" in r.stderr
+    env = dict(os.environ, GSASR_AMD_DEFERRED_EXIT="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.count("later-handler") == 1

@@ -50,9 +50,44 @@ def test_registry_refuses_other_flags():
     assert _cabi.get_kernel_choice(d) is None
 
 
+def test_registry_full_table_replaces_its_oldest_entry():
+    """300 shapes: no error (round 5 raised from the 257th on -- inside the user's forward under GSASR_AMD_AUTOTUNE, ADVICE r5);
+    the oldest registrations are gone, the newest are in force, and "no choice" for an unknown shape stores nothing"""
+    for k in range(300):
+        _cabi.set_kernel_choice(_cabi.make_dims(1000 + k, 64, 64, 0.1), _cabi.FLAG_BWD_TILE, 0)
+    assert _cabi.get_kernel_choice(_cabi.make_dims(1299, 64, 64, 0.1)) == (_cabi.FLAG_BWD_TILE, 0)
+    assert _cabi.get_kernel_choice(_cabi.make_dims(1000, 64, 64, 0.1)) is None
+    _cabi.set_kernel_choice(_cabi.make_dims(5000, 64, 64, 0.1), 0, 0)
+    assert _cabi.get_kernel_choice(_cabi.make_dims(5000, 64, 64, 0.1)) is None
+
+
+@pytest.mark.gpu
+def test_a_plan_keeps_the_list_capacity_it_was_made_with():
+    """the capacity of a plan's tile lists (the stride of its entries) comes from the registry at PLAN time; a
+    registration changed or cleared between the plan and its forward / backward must not change how they read the workspace"""
+    dev = torch.device("cuda:0")
+    sig, xy, col, H, W = synthetic.kernel_inputs(32, 32, 4, seed=11, gpp=16, device=dev)
+    g = synthetic.grad_image(H, W, seed=12, device=dev)
+    ref = _grads(sig, xy, col, H, W, 0.1, g)
+    shape = _cabi.make_dims(sig.shape[0], H, W, 0.1)
+    for first, then in ((1024, 4096), (4096, 256), (2048, None)):
+        _cabi.set_kernel_choice(shape, _cabi.FLAG_BWD_TILE, first)
+        p = _cabi.plan(sig, xy, col, H, W, 0.1)
+        if then is None:
+            _cabi.clear_kernel_choices()
+        else:
+            _cabi.set_kernel_choice(shape, _cabi.FLAG_BWD_TILE, then)      # another stride for plans made from now on
+        img = torch.empty(H, W, 3, device=dev)
+        _cabi.forward(p, img, overwrite=True)
+        out = (img, *_cabi.backward_new(p, sig, xy, col, g))
+        for a, b, what in zip(out, ref, ("image", "d sigmas", "d coords", "d colors")):
+            top = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-5 * max(top, 1.0), (first, then, what)
+
+
 def test_candidates_cover_every_combination():
     names = [n for n, _, _ in tune.candidates(65536, 1024, 1024, True)]
-    assert names[0] == "default" and len(names) == 9 and len(set(names)) == 9
+    assert names[0] == "default" and len(names) == 13 and len(set(names)) == 13      # {narrow, wide} x {gaussian, tile, home} x {lists, search}
     assert len(tune.candidates(65536, 1024, 1024, False)) == 5
     for _, flags, cap in tune.candidates(65536, 1024, 1024, True)[1:]:
         assert flags & ~_cabi.CHOICE_FLAGS == 0 and cap != 0
@@ -94,7 +129,8 @@ def test_tune_registers_a_measured_choice_and_the_dropin_follows_it():
     res = tune.tune(sig, xy, col, H, W, 0.1)
     assert res.registered and "default" in res.ms and len(res.ms) >= 5 and res.ms[res.name] <= res.ms["default"]
     shape = _cabi.make_dims(sig.shape[0], H, W, 0.1)
-    assert _cabi.get_kernel_choice(shape) == (res.flags, res.list_cap)
+    # (the library's own rule winning registers nothing: the C table is finite)
+    assert _cabi.get_kernel_choice(shape) == (None if res.name == "default" else (res.flags, res.list_cap))
     # the drop-in (whichever node serves it) now runs the registered combination and computes what the default computed
     s2, x2, c2 = (t.clone().requires_grad_(True) for t in (sig, xy, col))
     img = GSCUDA.apply(s2, x2, c2, torch.zeros(H, W, 3, device=dev), 0.1)
@@ -104,7 +140,8 @@ def test_tune_registers_a_measured_choice_and_the_dropin_follows_it():
         assert float((a - b).abs().max()) <= 2e-5 * max(top, 1.0), what
     # an inference shape: forward-only plans have their own registration
     res_f = tune.tune(sig, xy, col, H, W, 0.1, backward=False)
-    assert _cabi.get_kernel_choice(_cabi.make_dims(sig.shape[0], H, W, 0.1, flags=_cabi.FLAG_FORWARD_ONLY)) == (res_f.flags, res_f.list_cap)
+    assert _cabi.get_kernel_choice(_cabi.make_dims(sig.shape[0], H, W, 0.1, flags=_cabi.FLAG_FORWARD_ONLY)) == \
+        (None if res_f.name == "default" else (res_f.flags, res_f.list_cap))
     assert len(res_f.ms) >= 3
 
 
@@ -122,7 +159,7 @@ def test_autotune_hook_tunes_a_shape_once(monkeypatch):
     a = gaussiansplatting_render(sig, xy, col, (H, W), 0.1)
     b = gaussiansplatting_render(sig, xy, col, (H, W), 0.1)
     assert len(calls) == 1
-    assert _cabi.get_kernel_choice(_cabi.make_dims(sig.shape[0], H, W, 0.1)) is not None
+    assert tune._shape_key(sig.shape[0], H, W, 0.1, None, 0.0, False) in tune._SEEN
     # (the same combination both times; list order -- hence fp32 summation order -- may differ between two plans)
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
 
