@@ -31,8 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, band8_leg, pair_ceiling, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
-                      exact_runs, live_hbm_traffic, flush_c_stdio, published_leg, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
+from benchlib import (CONFIGS, HBM_PEAK_GBS, PAIR_CEILING, Step, band8_leg, bound_label, pair_ceiling, copy_bandwidth, cpu_baseline, dropin_run, effective_tau, emit,  # noqa: E402
+                      exact_runs, live_counters, flush_c_stdio, published_leg, run_c5e2e, single_gpu_leg, stage_times, strong_c4_leg, window_pairs)
 
 
 def parse():
@@ -175,6 +175,8 @@ def main():
 
     if step.ex is not None:
         step.ex.check()      # the timed steps dropped nothing (capacity) -- raises otherwise
+    if "GSASR_BENCH_CHILD" in os.environ:      # a counter pass of live_counters: the steps above are all it is for
+        return
 
     ms = dt / args.steps * 1e3
     mpix = step.H * step.W / (dt / args.steps) / 1e6        # whole-job HR pixels per second (all ranks)
@@ -182,21 +184,20 @@ def main():
     # per-kernel device time, measured live (not part of the timed region)
     kern = stage_times(step, dev, iters=30)
     dom = max((k for k in kern if k != "plan"), key=lambda k: kern[k]["avg_ms"])
-    traffic, traffic_source = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+    traffic, traffic_source, live = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")   # (committed passes: the fallback when rocprofv3 is missing)
     dom_kernel = {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom]
-    if world == 1 and rank == 0 and not args.no_live_pmc and not args.force_dist and not getattr(step, "batched", False) \
-            and "GSASR_BENCH_CHILD" not in os.environ:
-        # counted NOW, on this box, for this build: two child runs of the same workload under rocprofv3 --pmc
+    if world == 1 and rank == 0 and not args.no_live_pmc and not args.force_dist:
+        # counted NOW, on this box, for this build: three child runs of the same workload under rocprofv3 --pmc
         extra = ["--config", args.config, "--dmax", str(args.dmax), "--cutoff", str(args.cutoff)] + (["--fwd-only"] if args.fwd_only else [])
         try:
-            live, note = live_hbm_traffic(extra, [dom_kernel])
+            live, note = live_counters(extra)
         except Exception as e:      # the counters must never take the line with them
             live, note = None, repr(e)
-        if live and live.get(dom_kernel):
-            traffic, traffic_source = live[dom_kernel], note
+        if live and live.get(dom, {}).get("hbm_bytes"):
+            traffic, traffic_source = live[dom]["hbm_bytes"], note
         else:
-            print(f"[bench] live HBM counters unavailable ({note}); replaying profiles/pmc_latest.json", file=sys.stderr)
+            print(f"[bench] live counters unavailable ({note}); replaying profiles/pmc_latest.json", file=sys.stderr)
     if traffic is None and os.path.exists(pmc) and args.config == "c2" and world == 1:
         try:
             traffic = json.load(open(pmc)).get(dom_kernel, {}).get("hbm_bytes")
@@ -206,16 +207,23 @@ def main():
             traffic = None
     kname = {"forward": "k_sample_fwd", "backward": "k_sample_bwd"} if getattr(step, "sampled", False) else \
         {"forward": "k_render_fwd", "backward": "k_render_bwd"}
-    roofline = {"bound": "hbm", "kernel": kname[dom],
+    valu_busy_live = {k: v.get("valu_busy") for k, v in (live or {}).items()}
+    roofline = {"bound": "hbm", "kernel": ", ".join((live or {}).get(dom, {}).get("kernels", [])) or kname[dom],
                 "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_over_algorithmic": round(traffic / kern[dom]["algorithmic_bytes"], 2) if traffic and kern[dom].get("algorithmic_bytes") else None,
                 "traffic_source": traffic_source if traffic is not None else None,
+                "binding_resource": bound_label(valu_busy_live.get(dom)),
+                "bound_note": "`bound` = the roof `frac` is measured against (HBM: SURVEY 8(d)'s algorithmic bytes / stage time / 8 TB/s); the kernel is NOT "
+                              "HBM-bound: `binding_resource` is what the live SQ counters say binds it (valu_busy = VALU issue occupancy)",
+                "valu_busy": valu_busy_live, "counters": live,
                 "note": "stage times from events on the launch stream; outputs are stored, not accumulated (no memsets)"}
     # The binding unit is the fp32 VALU / v_exp_f32 pipe, not HBM: report pair rates and the VALU
     # occupancy next to the HBM fraction.
     if rank == 0:
         try:
             roofline["hbm_copy_GBps_measured"] = round(copy_bandwidth(dev), 1)
+            roofline["frac_of_measured_copy"] = kern[dom]["GBps"] / roofline["hbm_copy_GBps_measured"]
         except Exception as e:
             roofline["hbm_copy_GBps_measured"] = None
             print(f"[bench] copy bandwidth probe failed: {e!r}", file=sys.stderr)
@@ -232,12 +240,14 @@ def main():
                                     "(tools/valu_rate.hip); one packed trip = 128 pairs")
             roofline["valu_frac"] = {k: swept / (kern[k]["avg_ms"] * 1e-3) / pair_ceiling(step, k)["pairs_per_s"]
                                      for k in kern if k in PAIR_CEILING}
-            if os.path.exists(pmc) and args.config == "c2" and world == 1:
+            if valu_busy_live:
+                valu["valu_busy_rocprof"] = dict(valu_busy_live, source="counted live in this run (roofline.counters)")
+            elif os.path.exists(pmc) and args.config == "c2" and world == 1:
                 try:
                     j = json.load(open(pmc))
                     valu["valu_busy_rocprof"] = {"forward": j["k_render_fwd"].get("valu_busy"),
                                                  "backward": j["k_render_bwd"].get("valu_busy"),
-                                                 "source": "profiles/pmc_latest.json (SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES)"}
+                                                 "source": "profiles/pmc_latest.json (REPLAYED: SQ_INSTS_VALU, SQ_BUSY_CYCLES of the committed passes)"}
                 except Exception:
                     pass
             roofline["valu"] = valu
@@ -314,6 +324,7 @@ def main():
             step = None             # (its buffers make room for the 8192^2 leg)
             torch.cuda.empty_cache()
             out["configs"] = {}
+            args.copy_GBps = roofline.get("hbm_copy_GBps_measured")
             for name in ("c3", "c4", "c2x16", "c5"):
                 try:
                     out["configs"][name] = single_gpu_leg(args, dev, name)

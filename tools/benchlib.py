@@ -343,54 +343,90 @@ def window_pairs(sig, xy, H, W, dmax, tau, rows):
     return out
 
 
-def live_hbm_traffic(argv_extra, kernel_substrings, timeout=150):
-    """HBM bytes per launch of the kernels whose names contain one of `kernel_substrings`, COUNTED IN THIS RUN: two short
-    child runs of bench.py under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters + kernel trace
-    only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), corrected as the guide says: FETCH_SIZE counts half of a
-    wide read stream on gfx950 (x 2); WRITE_SIZE calibrated on the forward's image store.  Returns ({substring: bytes}, note)
-    or (None, why-not)."""
+# kernels of a stage, by substring of the rocprofv3 kernel name (the tile-stationary backward counts its gather)
+STAGE_KERNELS = {"forward": ["k_render_fwd"], "backward": ["k_render_bwd", "k_bwd_gather", "k_prologue_bwd_gather"]}
+SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES")
+
+
+def live_counters(argv_extra, groups=None, sq=True, timeout=240):
+    """Counters of the kernels of each stage, COUNTED IN THIS RUN: short child runs of bench.py (the same workload, five steps,
+    nothing else) under `rocprofv3 --pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and (sq) `--pmc SQ_INSTS_VALU SQ_BUSY_CYCLES` --
+    separate passes, counters + kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes.  Per stage:
+      hbm_bytes  = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch (the guide's gfx950 correction: FETCH_SIZE counts half of a wide
+                   read stream; WRITE_SIZE calibrated on the forward's image store), summed over the stage's kernels;
+      valu_busy  = SQ_INSTS_VALU x 32 SE x 4 cycles / (1024 SIMDs x SQ_BUSY_CYCLES): the VALU issue occupancy (a lower bound:
+                   v_exp_f32 holds the port for 8 cycles) -- the counters are per-SE averages.
+    Returns ({stage: {...}}, note) or (None, why-not)."""
     import shutil
     import sqlite3
     import subprocess
     import tempfile
+    groups = groups or STAGE_KERNELS
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if prof is None:
         return None, "rocprofv3 not found"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    passes = [("FETCH_SIZE",), ("WRITE_SIZE",)] + ([SQ_COUNTERS] if sq else [])
+    for ctrs in passes:
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             env = dict(os.environ, TMPDIR="/tmp", GSASR_BENCH_CHILD="1")
-            cmd = [prof, "--pmc", ctr, "--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.join(root, "bench.py"),
+            cmd = [prof, "--pmc", *ctrs, "--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.join(root, "bench.py"),
                    "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-graph", "--no-extras", "--no-live-pmc", *argv_extra]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             except (subprocess.TimeoutExpired, OSError) as e:
-                return None, f"{ctr} pass: {e!r}"
+                return None, f"{ctrs[0]} pass: {e!r}"
             db = None
             for dirpath, _, files in os.walk(tmp):
                 for f in files:
                     if f.endswith("_results.db"):
                         db = os.path.join(dirpath, f)
             if r.returncode != 0 or db is None:
-                return None, f"{ctr} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
+                return None, f"{ctrs[0]} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
             con = sqlite3.connect(db)
             pcols = [c[1] for c in con.execute("pragma table_info(pmc_events)")]
             kcol = "name" if "name" in pcols else "kernel_name"
             ccol = "counter_name" if "counter_name" in pcols else "pmc_name"
             vcol = "value" if "value" in pcols else "counter_value"
-            for name, val in con.execute(f"select {kcol}, avg({vcol}) from pmc_events where {ccol} = ? group by {kcol}", (ctr,)):
-                for sub in kernel_substrings:
-                    if name and sub in name:
-                        got.setdefault(sub, {}).setdefault(ctr, 0.0)
-                        got[sub][ctr] += float(val)
+            for ctr in ctrs:
+                for name, val in con.execute(f"select {kcol}, avg({vcol}) from pmc_events where {ccol} = ? group by {kcol}", (ctr,)):
+                    for stage, subs in groups.items():
+                        if name and any(sub in name for sub in subs):
+                            got.setdefault(stage, {}).setdefault(ctr, 0.0)
+                            got[stage][ctr] += float(val)
+                            got[stage].setdefault("kernels", set()).add(name.replace("(anonymous namespace)::", "").split("(")[0][:60])
             con.close()
-    out = {sub: int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for sub, v in got.items()}
+    out = {}
+    for stage, v in got.items():
+        e = {"hbm_bytes": int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024),
+             "fetch_KiB": round(v.get("FETCH_SIZE", 0.0), 1), "write_KiB": round(v.get("WRITE_SIZE", 0.0), 1),
+             "kernels": sorted(v.get("kernels", ()))}
+        if v.get("SQ_BUSY_CYCLES"):
+            e["valu_busy"] = round(v.get("SQ_INSTS_VALU", 0.0) * 32.0 * 4.0 / (1024.0 * v["SQ_BUSY_CYCLES"]), 4)
+            e["valu_insts"] = int(v.get("SQ_INSTS_VALU", 0.0) * 32)
+        out[stage] = e
     if not out:
         return None, "no matching kernels in the counter passes"
-    return out, ("LIVE: counted in this run by two child runs of this command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
-                 "(separate passes, counters + kernel trace only); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch -- the gfx950 "
-                 "FETCH_SIZE correction of MI355X_MICROARCH.md")
+    return out, ("LIVE: counted in this run by child runs of this command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc "
+                 "SQ_INSTS_VALU SQ_BUSY_CYCLES (separate passes, counters + kernel trace only); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB "
+                 "per launch -- the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md; valu_busy = SQ_INSTS_VALU x 32 x 4 / (1024 x SQ_BUSY_CYCLES)")
+
+
+def bound_label(valu_busy):
+    """which resource the counters say binds a render kernel: the VALU issue port from 0.7 of its cycles up (v_exp_f32 holds it
+    twice as long as the formula counts), else the wave's chain of dependent round trips; never HBM on this path (frac says how far)"""
+    if valu_busy is None:
+        return "valu-issue/latency (no SQ counters in this run)"
+    return "valu-issue" if valu_busy >= 0.7 else "latency (dependent round trips at low occupancy)"
+
+
+def live_hbm_traffic(argv_extra, kernel_substrings, timeout=150):
+    """(round 4 interface) HBM bytes per launch of the kernels whose names contain one of `kernel_substrings`"""
+    res, note = live_counters(argv_extra, {k: [k] for k in kernel_substrings}, sq=False, timeout=timeout)
+    if res is None:
+        return None, note
+    return {k: v["hbm_bytes"] for k, v in res.items()}, note
 
 
 def copy_bandwidth(dev):
@@ -851,13 +887,28 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
         in_box, swept, vfrac = pair_rates(st, kern, a.cutoff)
     tau_eff, k_box = effective_tau(st, a.cutoff)
     h_lr, w_lr, scale, desc = CONFIGS[config]
-    traffic, pmc = None, {}
-    try:   # HBM bytes per launch of the dominant stage's kernels, replayed from the committed counter passes of this config
-        import json
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")))
-        traffic = pmc.get("configs", {}).get(config, {}).get(dom)
-    except (OSError, ValueError):
-        traffic = None
+    if st.batched and not st.sampled:      # pair counts of the batched canvas: the kernel-frame tensors of every sample, through the package's own prologue
+        try:
+            from gsasr_amd import gaussian_splatting as gsp
+            hs = ws = int(h_lr * scale)
+            in_box = swept = 0
+            for b_ in range(st.B):
+                sx, sy, rho, xy_, col_ = gsp._activate(st.p[b_].cpu())
+                sg, xk, _, _, _ = gsp._to_kernel_frame(sx, sy, rho, xy_, col_, (hs, ws), 1.2 / scale)
+                ib, sw = window_pairs(sg, xk, hs, ws, st.dmax, tau_eff, (0, hs))
+                in_box, swept = in_box + ib, swept + sw
+            vfrac = {k: swept / (kern[k]["avg_ms"] * 1e-3) / PAIR_CEILING[k]["pairs_per_s"] for k in kern if k in PAIR_CEILING}
+        except Exception as e:
+            print(f"[bench] pair counts of the batched canvas failed: {e!r}", file=sys.stderr)
+    # counters of the stages' kernels, COUNTED NOW for this config on this box and build (three short child runs)
+    live, live_note = None, "skipped (--no-live-pmc)"
+    if not getattr(args, "no_live_pmc", False) and "GSASR_BENCH_CHILD" not in os.environ:
+        try:
+            live, live_note = live_counters(["--config", config, "--cutoff", str(a.cutoff), "--dmax", str(a.dmax)] + (["--fwd-only"] if a.fwd_only else []))
+        except Exception as e:
+            live, live_note = None, repr(e)
+    traffic = (live or {}).get(dom, {}).get("hbm_bytes")
+    valu_busy = {k: v.get("valu_busy") for k, v in (live or {}).items()}
     out = {"workload": desc, "H": st.H, "W": st.W, "gaussians": st.n, "dmax": st.dmax if st.dmax is not None else -1,
            "cutoff_tau": round(tau_eff, 3), "cutoff_k_box": k_box,
            "cutoff_tau_conservative": round(st.cabi.resolve_cutoff(a.cutoff, st.plan.dims.s), 3),
@@ -865,13 +916,14 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
            "forward_subtile_px": None if st.batched else st.cabi.forward_subtile_width(st.plan),    # 16 = the wide forward (x5 and up), 8 = the 8 x 16 kernels
            "steps": n, "ms_per_step": ms, "value": st.H * st.W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
            "kernels": kern,
-           "roofline": {"bound": "hbm", "kernel": {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
+           "roofline": {"bound": bound_label(valu_busy.get(dom)), "kernel": ", ".join((live or {}).get(dom, {}).get("kernels", [])) or {"forward": "k_render_fwd", "backward": "k_render_bwd"}[dom],
                         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
-                        "traffic": traffic,
-                        "traffic_source": (f"profiles/pmc_latest.json (REPLAYED from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                           f"{pmc.get('_tag', '?')} of this config, collected on build {pmc.get('_build', '?')}, all kernels of the "
-                                           "stage; not counted in this run)" if traffic is not None else None),
-                        "valu_frac": vfrac, "pairs_in_swept_window": swept, "pairs_in_dmax_box": in_box}}
+                        "frac_of_measured_copy": (kern[dom]["GBps"] / args.copy_GBps if getattr(args, "copy_GBps", None) else None),
+                        "frac_note": "frac = achieved / peak is the HBM fraction SURVEY 8(d) defines (algorithmic bytes / stage time / 8 TB/s); "
+                                     "`bound` names the resource the live counters say binds the kernel",
+                        "traffic": traffic, "traffic_over_algorithmic": (round(traffic / kern[dom]["algorithmic_bytes"], 2) if traffic else None),
+                        "traffic_source": live_note, "counters": live,
+                        "valu_busy": valu_busy, "valu_frac": vfrac, "pairs_in_swept_window": swept, "pairs_in_dmax_box": in_box}}
     del st
     torch.cuda.empty_cache()
     return out
