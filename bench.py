@@ -252,7 +252,14 @@ def main():
                     pass
             roofline["valu"] = valu
 
-    c4_strong = c4_strong_halo = c4_strong_halo_overlap = None
+    c4_strong = c4_strong_halo = c4_strong_halo_overlap = other_exchange = None
+    if (world > 1 or args.force_dist) and args.config == "c2" and not step.batched:
+        # the headline's own weak-scaled workload over the OTHER exchange, beside it in the same line (halo first, the north
+        # star's broadcast + reduce-scatter next to it), with its own rccl block
+        try:
+            other_exchange = strong_c4_leg(args, dev, rank, world, exchange="broadcast" if args.exchange == "halo" else "halo", config="c2")
+        except Exception as e:
+            other_exchange = {"error": repr(e)}
     if (world > 1 or args.force_dist) and args.config in ("c2", "c4") and not step.batched:
         # BASELINE config 4's own pattern -- strong-scaled 8192^2, packed broadcast + in-place reduce-scatter -- as a leg of
         # EVERY multi-rank line, whatever exchange the headline used
@@ -349,6 +356,8 @@ def main():
                 out["published"] = published_leg(args, dev)
             except Exception as e:
                 out["published"] = {"error": repr(e)}
+        if other_exchange is not None:
+            out["weak_other_exchange"] = other_exchange
         if c4_strong is not None:
             out["c4_strong"] = c4_strong
         if c4_strong_halo is not None:

@@ -53,3 +53,35 @@ def test_bench_two_ranks_functional(launcher, extra):
     ov = d["c4_strong_halo_overlap"]
     assert "error" not in ov and "note" not in ov, ov
     assert ov["overlap"] is True and ov["transport"] == halo["transport"] and ov["value"] > 0 and ov["rows_per_rank"] == 4096
+
+
+@pytest.mark.gpu
+def test_rccl_world_size_one_runs_every_collective_of_the_shard():
+    """no multi-GPU box has run this path yet, so the first contact with RCCL happens HERE -- a one-rank
+    "nccl" group on the test GPU, every collective the shard issues called once in the shard's own form (tools/rccl_world1.py)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1.py")], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d.pop("backend") == "nccl" and d.pop("ranks") == 1
+    assert len(d) == 8 and all(v == "ok" for v in d.values()), d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["halo", "broadcast"])
+def test_bench_force_dist_over_rccl(exchange):
+    """`bench.py --force-dist --backend nccl`: the multi-rank code path of the bench -- process group, exchange, barriers, the
+    rccl blocks of the line -- on a one-rank RCCL group; the halo form and the north star's broadcast form side by side"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--backend", "nccl", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--exchange", exchange]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["rccl"]["backend"] == "nccl" and d["config"]["rccl"]["ranks"] == 1
+    other = d["weak_other_exchange"]
+    assert "error" not in other, other
+    assert other["exchange"] == ("broadcast" if exchange == "halo" else "halo") and other["rccl"]["ranks"] == 1 and other["value"] > 0
+    for leg in ("c4_strong", "c4_strong_halo", "c4_strong_halo_overlap"):
+        assert "error" not in d[leg], (leg, d[leg])
+        assert d[leg]["rccl"]["backend"] == "nccl" and d[leg]["rccl"]["ranks"] == 1 and d[leg]["value"] > 0

@@ -929,7 +929,7 @@ def single_gpu_leg(args, dev, config, steps=None, **override):
     return out
 
 
-def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast", overlap=False):
+def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast", overlap=False, config="c4"):
     """BASELINE config 4 on whatever group this run has: the 8192^2 image strong-scaled over the ranks' row bands.
     exchange = "broadcast": as the north star states it -- Gaussians broadcast once per step as ONE packed [N,8] buffer,
     per-Gaussian gradients reduce-scattered in place (64 MB per rank and step over xGMI whatever the band height);
@@ -939,7 +939,8 @@ def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast", overlap
     import copy
     import torch.distributed as dist
     a = copy.copy(args)
-    a.config, a.exchange, a.fwd_only, a.force_dist, a.overlap = "c4", exchange, False, True, overlap
+    # (config = the headline's own weak-scaled config: the same leg serves as "the other exchange beside the headline")
+    a.config, a.exchange, a.fwd_only, a.force_dist, a.overlap = config, exchange, False, True, overlap
     st = Step(a, dev, rank, world)
 
     def barrier():
@@ -961,7 +962,7 @@ def strong_c4_leg(args, dev, rank, world, steps=5, exchange="broadcast", overlap
         dt = float(t.item())
     ms = dt / steps * 1e3
     kern = stage_times(st, dev, iters=5) if not (st.halo and overlap) else {}
-    out = {"workload": CONFIGS["c4"][3], "scaling": "strong", "overlap": bool(st.halo and overlap), "transport": (st.ex.transport if st.halo else "collectives"), "n_gpus": world, "steps": steps, "ms_per_step": ms,
+    out = {"workload": CONFIGS[config][3], "scaling": "strong" if st.strong else "weak", "exchange": "halo" if st.halo else "broadcast", "overlap": bool(st.halo and overlap), "transport": (st.ex.transport if st.halo else "collectives"), "n_gpus": world, "steps": steps, "ms_per_step": ms,
            "value": st.H * st.W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s", "rows_per_rank": st.rows[1] - st.rows[0],
            "kernels_rank0": kern,
            "rccl": {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
