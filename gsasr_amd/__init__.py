@@ -7,7 +7,8 @@ ChrisDud0257/GSASR, behind the reference's own autograd/operator surface).
     import gsasr_amd.gscuda                                                        # pybind module `gscuda`
     from gsasr_amd.shard import splat_band                                         # multi-GPU row-band shard
 
-The compute lives in gsasr_amd/csrc/gsasr_splat.hip (hand-written HIP for gfx950) behind the C ABI of
+The compute lives in gsasr_amd/csrc/splat_{plan,forward,backward,backward_home,step,sampled,shard,api}.hip (hand-written HIP
+for gfx950; csrc/gsasr_splat.hip is the same code as one translation unit for the micro-benchmark) behind the C ABI of
 include/gsasr_splat.h; Python only moves pointers.  Build with `python -m gsasr_amd.build`.
 """
 __version__ = "0.1.0"

@@ -3,7 +3,7 @@
 // Why: the reference's calling convention is one autograd node per rendered image (utils/gs_cuda_dmax/gswrapper.py:22-44,
 // sixteen per training step in basicsr/models/gsasr_model.py:191-233).  A PYTHON torch.autograd.Function makes the
 // engine's worker thread take the GIL to run `backward`; a C++ node is called from the engine directly: measured 54 vs 66 us
-// for a null node (profiles/r03_bwd_experiments.txt (4)).  What it does is exactly what gsasr_amd/gs_cuda*/gswrapper.py
+// for a null node (profiles/history/r03_bwd_experiments.txt (4)).  What it does is exactly what gsasr_amd/gs_cuda*/gswrapper.py
 // does through ctypes: plan + splat in forward (reference contract: `rendered_img` is accumulated into and returned),
 // one backward into three fresh gradient tensors, `None` for `rendered_img` and `dmax`.
 //

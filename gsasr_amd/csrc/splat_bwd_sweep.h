@@ -187,7 +187,7 @@ __device__ __forceinline__ void bwd_sweep(int c0, int bw, int r0, int r1, int la
                 // register sets used alternately: no copies).  Left to the compiler every trip was a dependent round trip
                 // -- issue, wait, sum -- and a wave's life at x4 is six of them: -5% at config 2, -4% on the config-5 crops,
                 // at 71 VGPRs (seven waves per SIMD kept).  Two trips ahead spills (72-VGPR budget): +8%; the same rotation
-                // in the unrolled instantiation: no gain (profiles/r03_bwd_experiments.txt).
+                // in the unrolled instantiation: no gain (profiles/history/r03_bwd_experiments.txt).
 #define GSASR_TRIP(G) { const v2f n0 = {sp[0], sp[RPI]}; const v2f w0 = TEST ? (v2f){sp[64], sp[64 + RPI]} : n0; \
                         bwd_trip<TEST, false>(R, G, n0, w0, true, true, K0, nK1, rho_u, cr, cg, cb, P.dmax); sp += 2 * RPI; }
                 Grad6 ga = bwd_load(rsrc, voff, voff_b, soff);

@@ -52,7 +52,7 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #endif
 #ifndef FWD_WIDE_MIN
 #define FWD_WIDE_MIN 25.0    // HR pixels per Gaussian from which the wide forward (16 x 16 sub-tiles, k_render_fwd16) is used:
-                             // x5 -3..-7%, x8 -4..-10%, x12 -13..-15%, x16 -20%, x32 -25%; x4: +8% (profiles/r04_fwd_wide.txt)
+                             // x5 -3..-7%, x8 -4..-10%, x12 -13..-15%, x16 -20%, x32 -25%; x4: +8% (profiles/history/r04_fwd_wide.txt)
 #endif
 #ifndef TL_MIN_SUB
 #define TL_MIN_SUB 2048      // sub-tiles (8 x 16 px) from which a dense plan carries tile lists by default: 512^2 and up.  Measured at 16
@@ -317,7 +317,7 @@ inline bool bwd_wants_tile(const gsasr_dims *d)
 // Tile height of the tile-stationary backward: 32 rows from 64 whole-grid HR pixels per Gaussian (x8 and up: windows of
 // 45 px and more) on single images -- the per-tile search is shared by twice the pixels and a window meets 40% fewer tiles
 // (slots written, and read by the gather): x8 -2% (the gather 94 -> 68 us, the tile kernel level; HBM traffic 1.72 -> 1.56 GB),
-// x12 -2%, x16 -9%, x24 -17%; nothing at x6 (profiles/r04_bwd_experiments.txt (6)).  16 rows below that and on the batched
+// x12 -2%, x16 -9%, x24 -17%; nothing at x6 (profiles/history/r04_bwd_experiments.txt (6)).  16 rows below that and on the batched
 // canvas (slots are multiples of 16 rows).
 // development switch: GSASR_SPLAT_BT_TALL=0 / 1
 inline bool bt_tall(const gsasr_dims *d)

@@ -143,7 +143,7 @@ def _backward_kernel(n_pixels: int, n_gaussians: int, shape=None) -> int:
 
 
 def _tile_backward(n_pixels: int, n_gaussians: int, shape=None) -> bool:
-    """Measured through this API on MI355X (tools/e2e_modes.py, profiles/r02_e2e_modes.txt): with >= 4 HR pixels per
+    """Measured through this API on MI355X (tools/e2e_modes.py, profiles/history/r02_e2e_modes.txt): with >= 4 HR pixels per
     Gaussian (one Gaussian per LR pixel at x2 and up) the tile-stationary backward is level or ahead end to end -- it reads
     the planar gradient in place, where the Gaussian-stationary kernel needs it interleaved first -- and it is
     deterministic; at 16 Gaussians per LR pixel (the training crops: ~1 pixel per Gaussian) a tile holds thousands of

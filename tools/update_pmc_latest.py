@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Refresh profiles/pmc_latest.json from profiles/r01_pmc_fetch.txt / r01_pmc_write.txt (see its _method field).
+"""Refresh profiles/pmc_latest.json from profiles/<tag>_pmc_fetch.txt / <tag>_pmc_write.txt (rounds 1-4: profiles/history/) (see its _method field).
 
     python tools/update_pmc_latest.py [tag]        # tag defaults to r01
 """
