@@ -551,6 +551,9 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd2(Params P, PlanView 
 // own sub-tile.  Against this stands the coarser cull ((w + 16)(h + 16) instead of (w + 8)(h + 16) evaluated pixels per
 // window): it pays from ~40-px windows up.
 constexpr int WIDE = 16;   // sub-tile side
+#ifndef FWD8_DEFAULT
+#define FWD8_DEFAULT 0     // 1: the fine forward (k_render_fwd8) is the default for sparse single images
+#endif
 
 __device__ __forceinline__ void fwd_store_px(const Params &P, float *__restrict__ img, int X, int Y, float r, float g, float b)
 {
@@ -566,6 +569,208 @@ __device__ __forceinline__ void fwd_store_px(const Params &P, float *__restrict_
     float *o = img + ((size_t)(Y - P.row0) * P.w + X) * 3;
     if (store) { o[0] = r; o[1] = g; o[2] = b; }
     else { o[0] += r; o[1] += g; o[2] += b; }
+}
+
+// FINE forward (round 6): the two-level walk of fwd_block with EIGHT waves per 32 x 16-px tile, each an 8 x 8-px sub-tile, ONE
+// pixel per lane, the evaluation packed over record PAIRS.  Why: the forward is bound by VALU issue and at x4 its instructions
+// are evaluations -- a ~20-px window is evaluated on every 8 x 16 sub-tile it touches, 57 hits per sub-tile = 57 evaluations per
+// pixel where the windows hold 31.  On 8 x 8 sub-tiles a pixel sees 41 (-28%), and with one pixel per lane the packing goes
+// over two records, whose column arithmetic packs as well: 10 packed + 2 v_exp_f32 per record pair and 64 pixels = 14 issue
+// slots per 128 pairs against 16.  Against this stand twice the waves running level 2 over the tile's survivors.  The pair
+// stage holds 6 accumulator registers here (the 8 x 16 pair kernel: 12, and 86 VGPRs), so eight waves per SIMD stay.
+// Single images; sparse plans (the dense ones render from lists).
+// MEASURED (profiles/r06_fwd8.txt) and NOT the default: parity-green (172 GPU tests under GSASR_SPLAT_FWD8=1) and SLOWER --
+// config 2 forward 29.4 against 25.1 us, 2048^2 x4 98.6 against 74.4, x2 level.  The evaluation became LDS-bound: a record pair
+// is four broadcast ds_read_b128 (16 LDS cycles, one LDS per CU) for 14 issue slots = 56 cycles on each of four SIMDs -- 64 LDS
+// cycles per 56; the 8 x 16 kernels read two per record for 64 cycles (50%).  Every record has to reach all 64 lanes of every
+// wave that evaluates it, so a sub-tile of half the pixels doubles the LDS reads per evaluated pixel; the instruction model
+// that promised -21% did not count them.  Kept behind the development switch.
+template <bool TEST>
+__device__ __forceinline__ void fwd_eval_pair1(const float4 q0, const float4 q1, const float4 q2, const float4 q3, float px, float py,
+                                               float dmax, v2f (&acc)[3])
+{
+    // q0 = {x0,x1,y0,y1}, q1 = {IX0,IX1,NR0,NR1}, q2 = {IY0,IY1,r0,r1}, q3 = {g0,g1,b0,b1} (stage_put_pair)
+    const v2f x = {q0.x, q0.y}, y = {q0.z, q0.w}, ix = {q1.x, q1.y}, nr = {q1.z, q1.w}, iy = {q2.x, q2.y};
+    const v2f cr = {q2.z, q2.w}, cg = {q3.x, q3.y}, cb = {q3.z, q3.w};
+    const v2f dx = px - x, dy = py - y;
+    const v2f u = ix * dx;
+    const v2f k0 = -u * u, ru = nr * u;
+    const v2f bq = iy * dy + ru;
+    const v2f pw = k0 - bq * bq;
+    v2f v = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+    if (TEST) {
+        v.x = (fabsf(dx.x) <= dmax && fabsf(dy.x) <= dmax) ? v.x : 0.f;
+        v.y = (fabsf(dx.y) <= dmax && fabsf(dy.y) <= dmax) ? v.y : 0.f;
+    }
+    acc[0] += v * cr;
+    acc[1] += v * cg;
+    acc[2] += v * cb;
+}
+
+template <bool TEST>
+__device__ __forceinline__ void fwd_eval_lds_pairs1(const float4 *__restrict__ st, int beg, int end, float px, float py, float dmax,
+                                                    v2f (&acc)[3])
+{
+    int i = beg;
+    for (; i + 1 < end; i += 2) {   // two pairs per iteration so their dependent chains interleave
+        const float4 a0 = st[4 * i], a1 = st[4 * i + 1], a2 = st[4 * i + 2], a3 = st[4 * i + 3];
+        const float4 b0 = st[4 * i + 4], b1 = st[4 * i + 5], b2 = st[4 * i + 6], b3 = st[4 * i + 7];
+        fwd_eval_pair1<TEST>(a0, a1, a2, a3, px, py, dmax, acc);
+        fwd_eval_pair1<TEST>(b0, b1, b2, b3, px, py, dmax, acc);
+    }
+    if (i < end) fwd_eval_pair1<TEST>(st[4 * i], st[4 * i + 1], st[4 * i + 2], st[4 * i + 3], px, py, dmax, acc);
+}
+
+// one chunk of a wave's walk (cf. fwd_stage_eval, PAIR): the hits' records go to the wave's stage as interleaved pairs, the
+// tested ones behind the others, each list padded to whole pairs with a zero record
+template <bool BOUNDED>
+__device__ __forceinline__ void fwd_stage_eval1(float4 *stage, bool hit, bool needs, const float4 ra, const float4 rb, int lane, float px,
+                                                float py, float dmax, v2f (&acc)[3])
+{
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long m0 = __ballot(hit && !needs), m1 = BOUNDED ? __ballot(hit && needs) : 0ull;
+    const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
+    if (n0 + n1 == 0) return;
+    const int b1 = (n0 + 1) & ~1;
+    __builtin_amdgcn_wave_barrier();
+    if (hit) {
+        const int r = needs ? __builtin_popcountll(m1 & below) : __builtin_popcountll(m0 & below);
+        const int slot = needs ? b1 + r : r;
+        stage_put_pair(stage, slot, ra, rb);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (((needs ? n1 : n0) & 1) && r == (needs ? n1 : n0) - 1) stage_put_pair(stage, slot + 1, z, z);
+    }
+    __builtin_amdgcn_wave_barrier();
+    fwd_eval_lds_pairs1<false>(stage, 0, (n0 + 1) >> 1, px, py, dmax, acc);
+    if (BOUNDED) fwd_eval_lds_pairs1<true>(stage, b1 >> 1, (b1 + n1 + 1) >> 1, px, py, dmax, acc);
+}
+
+template <bool BOUNDED>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_fwd8(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+{
+    constexpr int FW = 8;                         // waves per tile
+    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float4 s_stage[FW][STAGE_F4];
+    __shared__ unsigned s_list[2 * COARSE_LIST];
+    __shared__ unsigned s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int bx0 = (int)(t % (unsigned)tiles_x) * 4 * SUBX, by0 = P.row0 + (int)(t / (unsigned)tiles_x) * SUBY;
+    const int bx1 = min(bx0 + 4 * SUBX - 1, P.w - 1), by1 = min(by0 + SUBY - 1, P.row1 - 1);
+    const int sx0 = bx0 + (wv & 3) * SUBX, sy0 = by0 + (wv >> 2) * 8;
+    const bool live = sx0 < P.w && sy0 < P.row1;                  // wave-uniform
+    const int sx1 = min(sx0 + SUBX - 1, P.w - 1), sy1 = min(sy0 + 7, P.row1 - 1);
+    const int X = sx0 + (lane & 7), Y = sy0 + (lane >> 3);
+    const float px = V.px[min(X, P.w - 1)], py = V.py[min(Y, P.h - 1)];
+    float4 *stage = s_stage[wv];
+    const float4 *__restrict__ rec = V.rec;
+    const uint4 *__restrict__ bbox = V.bbox;
+    const unsigned *__restrict__ cs = V.cell_start;
+    const int wtx = sx0 >> SUBX_SHIFT, wty = (by0 - P.row0) >> SUBY_SHIFT;     // in the units of k_bin's spans (8 columns, 16 rows)
+
+    // segment table of the 32x16 tile (every wave builds the same one; cf. fwd_block)
+    const int rx = (int)V.hdr[8], ry = (int)V.hdr[9];
+    int nseg = 0;
+    unsigned sbeg = 0, send = 0;
+    if (rx > 0) {
+        const int cx0 = max(bx0 - rx, 0) >> CELL_SHIFT, cx1 = min((bx1 + rx) >> CELL_SHIFT, P.ncx - 1);
+        const int cy0 = max(by0 - ry, 0) >> CELL_SHIFT, cy1 = min((by1 + ry) >> CELL_SHIFT, P.ncy - 1);
+        nseg = cy1 - cy0 + 1;
+        if (lane < nseg) {
+            sbeg = cs[(cy0 + lane) * P.ncx + cx0];
+            send = cs[(cy0 + lane) * P.ncx + cx1 + 1];
+        }
+    }
+    if (lane == nseg) {
+        sbeg = cs[P.ncells];
+        send = cs[P.ncells + 1];
+    }
+    ++nseg;
+    const unsigned len = send - sbeg;
+    unsigned pin = len;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)pin, o);
+        if (lane >= o) pin += v;
+    }
+    const unsigned pex = pin - len;
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pin, nseg - 1);
+    const unsigned nchunks = (total + 63u) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rseg = 0;
+    v2f acc[3] = {(v2f){0.f, 0.f}, (v2f){0.f, 0.f}, (v2f){0.f, 0.f}};
+
+    for (unsigned base = 0, round = 0; base < nchunks; base += (unsigned)(FW * COARSE_CHUNKS), ++round) {
+        unsigned *cnt = s_cnt + (round & 1u);
+        // ---- phase A: this wave's share of the round's chunks against the whole tile (window only, 8 bytes per candidate) ----
+        unsigned cj[COARSE_CHUNKS];
+        uint2 cw[COARSE_CHUNKS];
+#pragma unroll
+        for (int k = 0; k < COARSE_CHUNKS; ++k) {
+            const unsigned c = base + (unsigned)wv + (unsigned)(FW * k);
+            cj[k] = c < nchunks ? fwd_candidate(c, lane, nseg, rseg, sbeg, pex, pin) : 0xffffffffu;
+            cw[k] = make_uint2(0x7fffu, 0x7fffu);
+            if (cj[k] != 0xffffffffu) cw[k] = V.win[cj[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < COARSE_CHUNKS; ++k) {
+            const int c0 = (int)(cw[k].x & 0x7fffu), c1 = (int)(cw[k].x >> 16);
+            const int r0 = (int)(cw[k].y & 0x7fffu), r1 = (int)(cw[k].y >> 16);
+            const bool hit = (c0 <= bx1) & (c1 >= bx0) & (r0 <= by1) & (r1 >= by0);
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                unsigned at = 0;
+                if (lane == 0) at = atomicAdd(cnt, (unsigned)__builtin_popcountll(m));
+                at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+                if (hit) s_list[at + (unsigned)__builtin_popcountll(m & below)] = cj[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0u;   // nobody touches the other counter before the next barrier
+        const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)*cnt);
+        // ---- phase B: the full test of the tile's survivors against this wave's 8 x 8 sub-tile ----------------------
+        if (live) {
+            unsigned j = (unsigned)lane < n ? s_list[lane] : 0xffffffffu;
+            const uint4 dead = make_uint4(0x7fffu, 0x7fffu, 0u, 0u);
+            uint4 bb = dead;
+            uint2 bs = make_uint2(0u, 0u);
+            if (j != 0xffffffffu) {
+                bb = bbox[2 * (size_t)j];
+                bs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)j + 1);
+            }
+            for (unsigned q = 0; q < n; q += 64u) {
+                const unsigned nq = q + 64u + (unsigned)lane;
+                const unsigned nj = nq < n ? s_list[nq] : 0xffffffffu;
+                uint4 nbb = dead;
+                uint2 nbs = make_uint2(0u, 0u);
+                if (nj != 0xffffffffu) {
+                    nbb = bbox[2 * (size_t)nj];
+                    nbs = *reinterpret_cast<const uint2 *>(bbox + 2 * (size_t)nj + 1);
+                }
+                const int c0 = (int)(bb.x & 0x7fffu), c1 = (int)(bb.x >> 16);
+                const int r0 = (int)(bb.y & 0x7fffu), r1 = (int)(bb.y >> 16);
+                bool hit = (c0 <= sx1) & (c1 >= sx0) & (r0 <= sy1) & (r1 >= sy0);
+                if (bb.y & 0x8000u) {  // per-16-row-band column spans (k_bin)
+                    const unsigned tb = (unsigned)(wty - ((r0 - P.row0) >> SUBY_SHIFT)) & 7u, sh = (tb & 3u) * 8u;
+                    const unsigned lo = tb < 4u ? bb.z : bs.x, hi = tb < 4u ? bb.w : bs.y;
+                    const int txr = wtx - (c0 >> SUBX_SHIFT);
+                    hit &= (txr >= (int)((lo >> sh) & 0xffu)) & (txr <= (int)((hi >> sh) & 0xffu));
+                }
+                const bool needs = BOUNDED && (bb.x & 0x8000u) != 0u;
+                float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+                if (hit) {
+                    const float4 *src = rec + 2 * (size_t)j;
+                    ra = src[0];
+                    rb = src[1];
+                }
+                fwd_stage_eval1<BOUNDED>(stage, hit, needs, ra, rb, lane, px, py, P.dmax, acc);
+                j = nj; bb = nbb; bs = nbs;
+            }
+        }
+        __syncthreads();   // the list is rewritten in the next round
+    }
+    if (live && X < P.w) fwd_store_px(P, img, X, Y, acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y);
 }
 
 template <bool BOUNDED>
@@ -1048,6 +1253,15 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         static const int parts_env = dev_switch("GSASR_SPLAT_FWD_PARTS") ? atoi(dev_switch("GSASR_SPLAT_FWD_PARTS")) : 0;   // development: 1 | 2 waves per sub-tile
         const bool lists = L.tl_ok && L.tl_hlog == 4;
         const bool two = parts_env ? parts_env == 2 : nsub < (lists ? 6144 : 4096);
+        // the fine forward (8 x 8-px sub-tiles, record pairs): sparse single images without lists.  development: GSASR_SPLAT_FWD8=0|1
+        static const int fwd8_env = dev_switch("GSASR_SPLAT_FWD8") ? atoi(dev_switch("GSASR_SPLAT_FWD8")) : -1;
+        if (!lists && dims->batch <= 1 && (fwd8_env >= 0 ? fwd8_env == 1 : FWD8_DEFAULT && !pair)) {
+            const dim3 grid8((unsigned)tx4 * (unsigned)tiles_y), block8(512);
+            if (P.bounded) hipLaunchKernelGGL(k_render_fwd8<true>, grid8, block8, 0, st, P, V, img, tx4);
+            else hipLaunchKernelGGL(k_render_fwd8<false>, grid8, block8, 0, st, P, V, img, tx4);
+            HIP_TRY(hipGetLastError());
+            return GSASR_OK;
+        }
         const dim3 grid((unsigned)tx4 * (unsigned)tiles_y), block(two ? 512 : 256);
 #define GSASR_F3(K, B, T) do { if (pair) hipLaunchKernelGGL((K<B, T, true>), grid, block, 0, st, P, V, img, tx4); \
                                else hipLaunchKernelGGL((K<B, T, false>), grid, block, 0, st, P, V, img, tx4); } while (0)
