@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export GSASR_SPLAT_DEV=1   # the GSASR_SPLAT_* A/B switches below are read only with it
-BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extras"
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extras --no-live-pmc"
 sq="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU"
 pass() {   # pass <name> "<counters>" <command...>: one counters-only run -> $OUT/<name>.txt
   local name=$1 ctr=$2; shift 2
