@@ -532,7 +532,37 @@ def dropin_run(args, dev):
         img = G0.apply(a, b, c, z) if dmax is None else G1.apply(a, b, c, z, dmax)
         img.backward(wgt)
 
-    ms = wall_ms(step, 30, dev, warm=5)
+    ms = wall_ms(step, 100, dev, warm=20)
+    # What PyTorch's own engine costs under this calling convention on this host, whatever the node does: a Function whose
+    # forward and backward launch nothing.  `.backward()` hands the node to the device's autograd worker thread; with
+    # torch.autograd.set_multithreading_enabled(False) -- a caller's choice, one line around the training loop -- the engine runs
+    # it on the calling thread.  Both forms are timed for the null node and for the drop-in.
+    class _Null(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a_, b_, c_, img_):
+            ctx.save_for_backward(a_, b_, c_)
+            return img_
+
+        @staticmethod
+        @torch.autograd.function.once_differentiable
+        def backward(ctx, g_):
+            a_, b_, c_ = ctx.saved_tensors
+            return torch.empty_like(a_), torch.empty_like(b_), torch.empty_like(c_), None
+
+    z0 = torch.zeros(H, W, 3, device=dev)
+
+    def null_step():
+        a.grad = b.grad = c.grad = None
+        _Null.apply(a, b, c, z0).backward(wgt)
+
+    floor = wall_ms(null_step, 200, dev, warm=20)
+    ms_st = floor_st = None
+    try:
+        with torch.autograd.set_multithreading_enabled(False):
+            floor_st = wall_ms(null_step, 200, dev, warm=20)
+            ms_st = wall_ms(step, 100, dev, warm=20)
+    except Exception as e:      # (an older torch without the switch)
+        print(f"[bench] single-threaded autograd engine unavailable: {e!r}", file=sys.stderr)
     # ... and the pybind-shaped module underneath it (`gscuda.gs_render` / `gs_render_backward`, reference
     # gswrapper.cpp:9-73 -> the C launchers gsasr_gs_render_dmax / _backward_dmax: scratch allocated stream-ordered and the
     # Gaussians binned in BOTH calls, as a maintainer who rebinds only the two launchers would get it)
@@ -553,6 +583,9 @@ def dropin_run(args, dev):
 
     ms_l = wall_ms(launchers, 30, dev, warm=5)
     return {"ms_per_step": ms, "value": H * W / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+            "engine_floor_ms": floor, "engine_floor_note": "a null autograd Function (no launches) through the same apply + .backward(grad): PyTorch's own host cost per step on this box",
+            "ms_per_step_engine_on_calling_thread": ms_st, "engine_floor_on_calling_thread_ms": floor_st,
+            "engine_on_calling_thread_note": "the same loops inside torch.autograd.set_multithreading_enabled(False): no hand-off to the device's autograd worker thread",
             "launchers_ms_per_step": ms_l, "launchers_value": H * W / (ms_l * 1e-3) / 1e6,
             "what": "GSCUDA.apply(sigmas, coords, colors, torch.zeros(H,W,3)[, dmax]) + .backward(grad) through torch autograd, "
                     "wall clock incl. host launch overhead, allocations and the accumulate-into (+=) image"}
