@@ -208,3 +208,69 @@ def test_packed_records_home_backward(dev):
     n = rec.shape[0]
     for cols, w_, name in ((slice(0, 3), want[0], "sigmas"), (slice(3, 5), want[1], "coords"), (slice(5, 8), want[2], "colors")):
         per_gaussian_ok(got[:n, cols], w_, name, rho=sig.numpy()[:, 2])
+
+
+def test_fused_step_home_backward_through_host_api(dev):
+    """generate_2D_gaussian_splatting_step with BACKWARD_KERNEL = 'home': the planar gradient autograd hands back is interleaved
+    inside the C call and the home-tile kernel sweeps it; against the oracle composed with the torch prologue"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    from oracle import gs_oracle
+    h_lr, w_lr, scale = 30, 26, 4.0
+    H, W = int(h_lr * scale), int(w_lr * scale)
+    p = synthetic.gs_parameters(h_lr, w_lr, seed=70)
+    wgt = synthetic.grad_image(H, W, 71)
+    old = gsp.BACKWARD_KERNEL
+    res = {}
+    try:
+        for mode in ("gaussian", "home"):
+            gsp.BACKWARD_KERNEL = mode
+            pa = p.to(dev).requires_grad_(True)
+            out = gsp.generate_2D_gaussian_splatting_step((H, W), pa, scale, torch.tensor([scale, scale]), dmax=0.3)
+            (out * wgt.to(dev).permute(2, 0, 1)).sum().backward()
+            res[mode] = (out.detach().cpu().numpy(), pa.grad.cpu().numpy())
+    finally:
+        gsp.BACKWARD_KERNEL = old
+    pc = p.clone().requires_grad_(True)
+    sx, sy, rho, xy, col = gsp._activate(pc)
+    sig_k, xy_k, col_k, _, _ = gsp._to_kernel_frame(sx, sy, rho, xy, col, (H, W), 1.2 / scale)
+    g = gs_oracle.backward_f64(sig_k.detach().numpy(), xy_k.detach().numpy(), col_k.detach().numpy(), wgt.numpy(), 0.3)
+    torch.autograd.backward([sig_k, xy_k, col_k], [torch.from_numpy(x).float() for x in g])
+    want = pc.grad.numpy()
+    for mode in ("gaussian", "home"):
+        per_gaussian_ok(res[mode][1], want, "gs_parameters/" + mode)
+
+
+@pytest.mark.parametrize("gpp", [2, 16], ids=["gpp2", "gpp16"])
+def test_batched_canvas_home_backward(gpp, dev):
+    """a ragged batch through generate_2D_gaussian_splatting_batch with the home-tile backward: tiles are counted per slot (a
+    32-row tile never straddles two samples; slots here are 64 rows with sample heights 40 / 64 / 50), every sample against the
+    per-sample loop of single-image steps (the reference's structure) and against the Gaussian-stationary kernel"""
+    from gsasr_amd import gaussian_splatting as gsp, synthetic
+    sizes = [(40, 56), (64, 37), (50, 50)]
+    h_lr, w_lr = 10, 12
+    p = torch.stack([synthetic.gs_parameters(h_lr, w_lr, seed=80 + b, gpp=gpp) for b in range(3)]).to(dev)
+    scales = [4.0, 5.3, 4.4]
+    sms = [torch.tensor([s, s]) for s in scales]
+    hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    wgt = torch.rand(3, 3, hm, wm, generator=torch.Generator().manual_seed(5)).to(dev)
+    old = gsp.BACKWARD_KERNEL
+    res = {}
+    try:
+        for mode in ("gaussian", "home"):
+            gsp.BACKWARD_KERNEL = mode
+            pa = p.clone().requires_grad_(True)
+            out = gsp.generate_2D_gaussian_splatting_batch(sizes, pa, scales, sms, dmax=0.4)
+            (out * wgt).sum().backward()
+            res[mode] = pa.grad.cpu().numpy()
+    finally:
+        gsp.BACKWARD_KERNEL = old
+    for b in range(3):
+        per_gaussian_ok(res["home"][b], res["gaussian"][b], f"sample {b}")
+    pa = p.clone().requires_grad_(True)
+    tot = 0
+    for b in range(3):
+        o = gsp.generate_2D_gaussian_splatting_step(sizes[b], pa[b], scales[b], sms[b], dmax=0.4)
+        tot = tot + (o * wgt[b, :, :sizes[b][0], :sizes[b][1]]).sum()
+    tot.backward()
+    for b in range(3):
+        per_gaussian_ok(res["home"][b], pa.grad[b].cpu().numpy(), f"sample {b} vs loop")
