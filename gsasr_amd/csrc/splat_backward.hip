@@ -309,7 +309,7 @@ __device__ __forceinline__ void bt_eval(const PlanView &V, unsigned j, float dm,
 // WV = waves per tile: two per 16 rows (BT_WAVES); FOUR on 32 x 16-px tiles of dense plans read from lists (round 5) -- at 16
 // Gaussians per LR pixel a tile's list holds ~2 000 entries = 75 item chunks, and 2 048 tiles x 2 waves leave the chip one
 // generation of four waves per SIMD with nothing to balance: config-5 canvas 320 -> 266 us, 1024^2 at 16 per LR pixel 459 -> 424
-// (profiles/r05_bt_variants.txt; the same four waves on x8's 32 x 32-px tiles lose: 1 210 -> 1 648 us at config 4).
+// (profiles/history/r05_bt_variants.txt; the same four waves on x8's 32 x 32-px tiles lose: 1 210 -> 1 648 us at config 4).
 template <bool BOUNDED, int BT_CHUNKS, int HLOG, bool LISTS, int WV = (BT_WAVES << (HLOG - 4))>
 __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu((BT_CHUNKS * WV) <= 4 ? 5 : 4, 5))) void k_render_bwd_tile(
     Params P, PlanView V, const float *__restrict__ grad, int tiles_x, int use_atomics)
@@ -669,7 +669,7 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         }
         // Eight Gaussians per wave (k_render_bwd8): built in round 5, parity-green, and SLOWER than one wave per Gaussian --
         // config 2 39.4 vs 30.7 us, 16 Gaussians per LR pixel 475 vs 401, the config-5 canvas 271 vs 235
-        // (profiles/r05_bwd8.txt): the eight windows of a wave differ (a wave runs max strips x max row pairs: 52 trips for a
+        // (profiles/history/r05_bwd8.txt): the eight windows of a wave differ (a wave runs max strips x max row pairs: 52 trips for a
         // mean of 30) and its trips are dependent round trips.  Kept behind the development switch GSASR_SPLAT_BWD8=1 (slabs
         // whose byte offsets fit 32 bits), exercised by tests/test_rows_vs_oracle.py.
         static const int bwd8_env = dev_switch("GSASR_SPLAT_BWD8") ? atoi(dev_switch("GSASR_SPLAT_BWD8")) : -1;

@@ -56,7 +56,7 @@ constexpr int RCAP_PX = 128;    // half-extent (px) above which a Gaussian is bi
 #endif
 #ifndef TL_MIN_SUB
 #define TL_MIN_SUB 2048      // sub-tiles (8 x 16 px) from which a dense plan carries tile lists by default: 512^2 and up.  Measured at 16
-                             // Gaussians per LR pixel (profiles/r05_small_dense.txt): 512^2 forward 134 -> 72 us for +8 us of plan, 640^2
+                             // Gaussians per LR pixel (profiles/history/r05_small_dense.txt): 512^2 forward 134 -> 72 us for +8 us of plan, 640^2
                              // 207 -> 126; 384^2 level (+7 us of plan, nothing off the forward), 256^2 and below the split search kernel
                              // wins (33 against 48 us; four waves per sub-tile instead of two: 42)
 #endif
@@ -305,7 +305,7 @@ inline bool bwd_wants_tile(const gsasr_dims *d)
     // Round 5: one Gaussian per 2..4 pixels on a megapixel and more (x2 at one per LR pixel, x4 at four) -- a dense plan, whose
     // tile lists this kernel then reads (same 32 x 16-px tiles as the 8 x 16 forward): 1024^2 x2 -16% per step, 2048^2 x2 -21%,
     // 1024^2 x4 at 4 per LR pixel -4%, level at x8 / 16 per LR pixel; 512^2 images lose 4..15% and keep the Gaussian-stationary
-    // kernel, as do denser plans (16 per LR pixel at x4: level to +1%).  profiles/r05_pxg4.txt; the fused host path has drawn
+    // kernel, as do denser plans (16 per LR pixel at x4: level to +1%).  profiles/history/r05_pxg4.txt; the fused host path has drawn
     // the same line since round 2 (gaussian_splatting._tile_backward).
     if (px_per_gaussian >= 2.0 && px_per_gaussian <= 4.0 && (double)d->h * (double)d->w >= 1048576.0 && list_cap_of(d) >= 0 && lists_env() != 0)
         return true;
@@ -365,7 +365,7 @@ inline int lists_env()
 // dense plan: at least one Gaussian per four pixels of the rows rendered (GSASR's 16 per LR pixel at x4 and below).  The 64
 // Gaussians of a k_bin wave then share a handful of tiles, so their cursor atomics aggregate (tl_emit) and the lists cost less
 // than the search they replace: 16 Gaussians per LR pixel at 1024^2 -5.8% per step, the config-5 canvas -5.2%.  At one
-// Gaussian per LR pixel the atomics outweigh the search: config 2 +5%, config 3 +20% (profiles/r05_lists_ab.txt).
+// Gaussian per LR pixel the atomics outweigh the search: config 2 +5%, config 3 +20% (profiles/history/r05_lists_ab.txt).
 inline bool tl_dense(const gsasr_dims *d)
 {
     const double rows = (double)(d->row1 - d->row0 > 0 ? d->row1 - d->row0 : 1);
@@ -385,7 +385,7 @@ inline int tl_hlog_for(const gsasr_dims *d)
     // tiles (x8 and up: config 4, the shard's bands): two consumers pay for k_bin's atomics; an explicit capacity (or the
     // development switch) asks for them anywhere
     // (up to ~x10: at x12 a window meets 16 and more 32 x 32-px tiles and k_bin's appends cost more than the two kernels save --
-    // 3072^2 x12 fwd+bwd: plan +33 us for -13 us of forward, profiles/r05_policy_sweep.txt)
+    // 3072^2 x12 fwd+bwd: plan +33 us for -13 us of forward, profiles/history/r05_policy_sweep.txt)
     const bool both = !(d->flags & GSASR_FLAG_FORWARD_ONLY) && bwd_wants_tile(d) && fwd_wants_wide(d) == bt_tall(d) &&
                       (double)d->h * (double)d->w < 100.0 * (double)d->s;
     if (list_cap == 0 && lists_env() != 1 && !tl_dense(d) && !both) return 0;

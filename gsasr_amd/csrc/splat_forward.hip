@@ -134,7 +134,7 @@ __device__ __forceinline__ void fwd_eval_lds(const float4 *__restrict__ st, int 
 // the even and the odd records of a list are kept apart (two accumulators per channel and row) and added at the end; a list
 // of odd length ends in a zero record (colour 0).
 // Which plans: the dense ones (tl_dense: at least one Gaussian per four pixels -- GSASR's 16 per LR pixel, the reference's published
-// workload) -- measured (profiles/r05_whatif.txt, r05_lists_ab.txt): 16 Gaussians per LR pixel -5% on the forward, the published
+// workload) -- measured (profiles/history/r05_whatif.txt, r05_lists_ab.txt): 16 Gaussians per LR pixel -5% on the forward, the published
 // workload -11%; at one Gaussian per LR pixel (config 2: 40 hits per sub-tile) the 30 extra VGPRs cost two waves per SIMD and
 // the forward +6%, so those keep the pixel-packed evaluation.  -DFWD_PAIR=0 / 1 forces one of them everywhere (what-if builds).
 constexpr int STAGE_F4 = 136;    // float4 per wave's stage: 64 records + a zero record behind each of the two lists (pairs)
@@ -1234,7 +1234,7 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
         // pixel: thousands of candidates per sub-tile): split each sub-tile's Gaussian list over 2..16 waves so that about one
         // full set of waves is in flight.  Sparse small images (one Gaussian per LR pixel: a sub-tile has a few dozen hits, and
         // sixteen waves would each search all the candidates for them) take the two-level kernel below, two waves per sub-tile:
-        // 512^2 x4 forward 21.6 -> 11.8 us, 640^2 31.1 -> 15.8, 256^2 level (profiles/r05_split_vs_twolevel.txt)
+        // 512^2 x4 forward 21.6 -> 11.8 us, 640^2 31.1 -> 15.8, 256^2 level (profiles/history/r05_split_vs_twolevel.txt)
         int nw = 2;
         while (nw < 16 && nsub * nw < 8192) nw *= 2;
         const dim3 grid((unsigned)nsub), block((unsigned)nw * 64u);
@@ -1246,7 +1246,7 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
     } else {
         // the plan's tile lists (32 x 16-px tiles: the same workgroup tile as the two-level walk, and its two shapes), else the
         // two-level walk; images with fewer than 4096 sub-tiles (half the chip's wave slots) get two waves per sub-tile: 512^2
-        // -8..-11%, 640^2 level, 768^2..896^2 +3..4%, above that +5..11% (profiles/r05_fwd_parts.txt; until the lists of round 5
+        // -8..-11%, 640^2 level, 768^2..896^2 +3..4%, above that +5..11% (profiles/history/r05_fwd_parts.txt; until the lists of round 5
         // the line was at 8192: the search of a 4608-sub-tile canvas gained 13% from the second wave).  From lists the second wave
         // pays a little longer -- 768^2 at 16 per LR pixel -1%, the 4608-sub-tile canvas of config 5 -3%, 896^2 +1%: 6144 there
         const int tx4 = (subs_x + 3) / 4;

@@ -356,7 +356,7 @@ __device__ __forceinline__ unsigned tl_mask(int tx, int ty, const uint4 bb, cons
 // The cursors are bumped with ONE returning atomic per (wave, round slot, distinct tile), all of a slot's issued in one
 // instruction (cf. k_classify's ranks): raster-ordered decoder output puts the 64 Gaussians of a wave into a handful of tiles,
 // and atomics on one word -- on one cache LINE -- serialise at ~12 ns each whichever wave they come from.
-// (Measured and dropped, profiles/r05_lists_ab.txt run r05d: per-lane atomics without the match-any loops, six tiles per round --
+// (Measured and dropped, profiles/history/r05_lists_ab.txt run r05d: per-lane atomics without the match-any loops, six tiles per round --
 // config 2's k_bin +10.5 us instead of +6, config 4's plan +165 us instead of +81: the atomics, not the loops, are what costs.)
 constexpr int TLB = 4;
 

@@ -171,7 +171,7 @@ def _batch_shape(n_per, sizes, dm):
 
 # The caller's scale factor as a HINT for the forward kernel (never for the numbers).  The C library sees pixels per Gaussian, which
 # says "x2-sized windows" for x8 at Fea2GS's 16 Gaussians per LR pixel (4 px per Gaussian) -- the windows there are x8's, and the
-# wide forward (16 x 16-px sub-tiles) is 5..8% ahead (profiles/r05_inference_sweep.txt: x8d16_2048).  This module knows the scale.
+# wide forward (16 x 16-px sub-tiles) is 5..8% ahead (profiles/history/r05_inference_sweep.txt: x8d16_2048).  This module knows the scale.
 SCALE_HINT = True
 
 

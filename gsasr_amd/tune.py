@@ -8,7 +8,7 @@ synthetic Gaussians ("about one LR pixel": gsasr_amd/synthetic.py).  On other si
     backward : Gaussian-, tile-stationary or home-tile   (FLAG_BWD_GAUSSIAN / FLAG_BWD_TILE / FLAG_BWD_HOME)
     lists    : the plan's tile lists, or the search     (list_cap > 0 / < 0)
 
-can be 5..45% faster (profiles/r05_policy_regret.txt).  `tune()` times the combinations on the tensors it is given --
+can be 5..45% faster (profiles/history/r05_policy_regret.txt).  `tune()` times the combinations on the tensors it is given --
 plan + forward (+ backward), a few repetitions each in three rounds after a 30 ms warm-up -- and registers the winner
 for the shape in the C library (`gsasr_set_kernel_choice`, include/gsasr_splat.h), so that every later call of that shape
 through any entry point (the GSCUDA drop-in, the C++ autograd node, the C ABI itself) follows it.  All combinations compute

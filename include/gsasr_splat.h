@@ -327,7 +327,7 @@ GSASR_API int gsasr_forward_subtile_width(const gsasr_dims *dims);
  * The library picks its kernels -- 8 x 16 or 16 x 16 forward sub-tiles, Gaussian- or tile-stationary backward, tile lists or the
  * search -- from the SHAPE of the problem (pixels per Gaussian, image size): the window sizes that really decide live on the device,
  * and no entry point synchronises to read them.  On Gaussians much smaller or larger than "about one LR pixel" another
- * combination can be 5..45% faster (profiles/r05_policy_regret.txt).  A caller who knows better -- it timed the combinations on
+ * combination can be 5..45% faster (profiles/history/r05_policy_regret.txt).  A caller who knows better -- it timed the combinations on
  * its own data -- registers the choice once; every later plan / forward / backward whose dims match `shape` in {s, h, w, row0,
  * row1, batch, slot, dmax, cutoff, GSASR_FLAG_FORWARD_ONLY} and carry NO explicit choice of their own (flags below, list_cap != 0)
  * behaves as if it had been given
