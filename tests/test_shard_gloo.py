@@ -131,7 +131,8 @@ def _packed_worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "all_reduce"), (3, "all_reduce"), (2, "reduce_scatter"), (3, "reduce_scatter")])
+@pytest.mark.parametrize("world,mode", [(2, "all_reduce"), (3, "all_reduce"), (2, "reduce_scatter"), (3, "reduce_scatter"),
+                                        (8, "reduce_scatter")])
 def test_packed_row_band_shard_matches_single_process(world, mode):
     """the north star's pattern on one packed buffer: broadcast_packed + splat_band_packed, gradients
     reduced in place on the [N,8] buffer the backward wrote"""
@@ -249,13 +250,20 @@ class OraclePackedBackend(OracleBackend):
 H_LR, W_LR, SCALE, DMAX_X = 12, 10, 3.0, 0.2
 
 
+def _h_lr(world):
+    """LR rows of the exchange tests: 12, or 32 for the eight-rank case (the node the driver scales to) -- bands of 12 HR rows,
+    taller than the 9.6-px dmax box, so that footprints reach the ADJACENT band only (what BandExchange requires)"""
+    return 32 if world >= 8 else H_LR
+
+
 def _exchange_worker(rank, world, port, cap, out, transport="alltoall", overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
-        lr0, lr1 = shard.row_band(H_LR, rank, world)           # this rank "decodes" its own LR rows
+        h_lr = _h_lr(world)
+        sig, xy, col, H, W = synthetic.kernel_inputs(h_lr, W_LR, SCALE, seed=5)
+        lr0, lr1 = shard.row_band(h_lr, rank, world)           # this rank "decodes" its own LR rows
         mine = shard.pack(sig, xy, col)[lr0 * W_LR: lr1 * W_LR]
         ex = shard.BandExchange(mine.shape[0], cap, H, W, DMAX_X, backend=OraclePackedBackend, transport=transport, overlap=overlap)
         p = mine.clone().requires_grad_(True)
@@ -274,6 +282,7 @@ def _exchange_worker(rank, world, port, cap, out, transport="alltoall", overlap=
 
 
 @pytest.mark.parametrize("world,transport,overlap", [(2, "alltoall", False), (3, "alltoall", False), (4, "alltoall", False),
+                                                     (8, "alltoall", False), (8, "p2p", False),
                                                      (2, "p2p", False), (3, "p2p", False),
                                                      (2, "alltoall", True), (3, "alltoall", True), (3, "p2p", True)])
 def test_band_exchange_matches_single_process(world, transport, overlap):
@@ -284,7 +293,7 @@ def test_band_exchange_matches_single_process(world, transport, overlap):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_exchange_worker, args=(world, _free_port(), 64, out, transport, overlap), nprocs=world, join=True)
-    sig, xy, col, H, W = synthetic.kernel_inputs(H_LR, W_LR, SCALE, seed=5)
+    sig, xy, col, H, W = synthetic.kernel_inputs(_h_lr(world), W_LR, SCALE, seed=5)
     wgt = synthetic.grad_image(H, W, 6)
     ref = gs_oracle.forward_f64(sig.numpy(), xy.numpy(), col.numpy(), H, W, DMAX_X)
     gref = shard.pack(*(torch.from_numpy(a) for a in
