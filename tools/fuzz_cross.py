@@ -5,7 +5,7 @@ reach (GPU, development aid):   python tools/fuzz_cross.py [cases] [seed]
 Per case: a random image (up to ~5000 px a side, sometimes very thin), a random row band, Gaussians from hairlines to
 several image widths, dmax or none, default / exact / no cutoff.  Checked:
   forward    band render  ==  oracle (f64) on a few rows of the band
-  backward   Gaussian-stationary, tile-stationary (slots), tile-stationary (atomics): each against the oracle's
+  backward   Gaussian-stationary, tile-stationary (slots), tile-stationary (atomics), home-tile: each against the oracle's
              gradient of the same band (upstream gradient dense or sparse)
 The sampled-pixel fuzzer found the one bug of round 3 this way (a window wider than 2048 px in the tile backward)."""
 import ctypes
@@ -23,8 +23,9 @@ from oracle import gs_oracle  # noqa: E402
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
-FLAGS = {"gaussian": _cabi.FLAG_BWD_GAUSSIAN, "tile": _cabi.FLAG_BWD_TILE, "atomic": _cabi.FLAG_BWD_TILE | _cabi.FLAG_BWD_ATOMIC}
-worst = {"img": 0.0, "gaussian": 0.0, "tile": 0.0, "atomic": 0.0}
+FLAGS = {"gaussian": _cabi.FLAG_BWD_GAUSSIAN, "tile": _cabi.FLAG_BWD_TILE, "atomic": _cabi.FLAG_BWD_TILE | _cabi.FLAG_BWD_ATOMIC,
+         "home": _cabi.FLAG_BWD_HOME}
+worst = {"img": 0.0, "gaussian": 0.0, "tile": 0.0, "atomic": 0.0, "home": 0.0}
 t0 = time.time()
 for case in range(cases):
     shape = rng.integers(0, 5)
@@ -92,7 +93,7 @@ for case in range(cases):
         # backward variants: stored / accumulated into the caller's gradients; the tile kernels also on a planar gradient
         acc = rng.random() < 0.3
         g = [torch.full_like(t, 0.25 if acc else float("nan")) for t in (a, b, c)]
-        if name != "gaussian" and rng.random() < 0.4:
+        if name in ("tile", "atomic") and rng.random() < 0.4:
             gchw = gw.permute(2, 0, 1).contiguous()
             d = type(plan.dims).from_buffer_copy(plan.dims)
             d.flags |= _cabi.FLAG_CHW_GRAD | (0 if acc else _cabi.FLAG_OVERWRITE_GRADS)
