@@ -219,7 +219,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int i = tid; i < RH; i += THREADS) s_py[i] = V.py[min(max(Y0 + i, 0), P.h - 1)];
             if (tid == 0) s_head = 0u;
         }
-        const float kw = __uint_as_float(V.hdr[3]);      // sqrt(2 tau'): the cutoff the windows were built with (0: none)
+        // sqrt(2 tau) of the ellipse the items cover: the windows' tau' (0: no cutoff), or the backward's own smaller one
+        // (GSASR_SPLAT_GRAD_TAU: a gradient sums over its own pixels only)
+        float kw = __uint_as_float(V.hdr[3]);
+        if (P.kb_max > 0.f && kw > P.kb_max) kw = P.kb_max;
         const float hx = 0.5f * (float)(g.w - 1), hy = 0.5f * (float)(g.h - 1);
         __syncthreads();
 

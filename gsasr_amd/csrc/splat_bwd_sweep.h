@@ -287,7 +287,7 @@ typedef unsigned u8v __attribute__((ext_vector_type(8)));
 // it will not use the non-coherent scalar cache) issued as three dependent round trips, which was most of a
 // wave's life.  The plan was written by an earlier kernel, so the scalar cache is coherent for it.
 struct BwdRec {
-    u8v bb;    // both bbox words: {c0|test|c1, r0|r1, spans.. | spans.., padded rows r0|r1 of the sweep, -}
+    u8v bb;    // both bbox words: {c0|test|c1, r0|r1, spans.. | spans.., padded rows r0|r1 of the sweep, its columns c0|test|c1}
     u8v rec;   // {x, y, IX, NR | IY, r, g, b}
     u8v fin;   // {c, kappa, rho, 1/sx | 1/sy, px-table offset, sample, index}
 };
@@ -326,9 +326,14 @@ __device__ __forceinline__ void bwd_item(unsigned j, const BwdRec &G, int chunk,
                                          float *__restrict__ g_sigmas, float *__restrict__ g_coords,
                                          float *__restrict__ g_colors)
 {
-    const unsigned bbx = G.bb[0];
-    const int c0 = (int)(bbx & 0x7fffu), c1 = (int)(bbx >> 16);
+    unsigned bbx = G.bb[0];
+    int c0 = (int)(bbx & 0x7fffu), c1 = (int)(bbx >> 16);
     if (c0 > c1) return;  // dead class (handled by the caller)
+    if (chunk < 0) {      // the backward's own window (k_bin: min(tau', GSASR_SPLAT_GRAD_TAU)); row chunks of the large class keep the forward's
+        bbx = G.bb[7];
+        c0 = (int)(bbx & 0x7fffu);
+        c1 = (int)(bbx >> 16);
+    }
     int r0, r1;
     bool empty = false;
     if (chunk >= 0) {  // (row chunks of a large Gaussian must not overlap: they split the window's own rows)

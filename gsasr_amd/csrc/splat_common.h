@@ -90,6 +90,7 @@ struct Params {
     int bounded;     // 1: gs_cuda_dmax box test, 0: gs_cuda (no test)
     float dmax;      // box half-size (normalised units); +inf when !bounded
     float kcut;      // sqrt(2 tau) or 0 when the support cutoff is disabled (the CONSERVATIVE tau: classes, dead set)
+    float kb_max;    // > 0 (adaptive default only): sqrt(2 GSASR_SPLAT_GRAD_TAU) -- the backward sweeps the window of min(tau', that)
     float adapt_cells;  // > 0: the windows are built with the data-derived cutoff tau' = ln(K / eps) <= tau, K = the most Gaussians
                      // whose dmax box can cover one pixel <= (largest cell count) * adapt_cells + (large class); 0: kcut everywhere
     int count_words; // words of one parity's counter array (cell counters + extent groups): what k_classify zeroes for the next plan
@@ -552,6 +553,13 @@ inline Params make_params(const gsasr_dims *d, const Layout &L)
     }
     const bool adapt = ((d->cutoff == 0.f && default_cutoff() == 0.f) || (d->flags & GSASR_FLAG_CUTOFF_CAP)) && P.kcut > 0.f && adapt_env();
     P.adapt_ring = adapt && tau >= 16.f;       // (the tail constant of adapt_kcut is derived for tau >= 16)
+    // the backward's own cutoff (include/gsasr_splat.h: GSASR_SPLAT_GRAD_TAU); development: GSASR_SPLAT_GRADTAU=0 switches it off
+    static const bool gradtau_on = !(dev_switch("GSASR_SPLAT_GRADTAU") && atoi(dev_switch("GSASR_SPLAT_GRADTAU")) == 0);
+    // (whole images only: "complete to 1e-5 of the Gaussian's own mass" is a statement about all of its pixels -- on a row band
+    // that holds nothing but a Gaussian's tail the same truncation is a large part of THAT band's share, and a band's gradient
+    // is compared and reduced on its own)
+    const bool whole = d->row0 == 0 && d->row1 == d->h;
+    P.kb_max = (adapt && gradtau_on && whole) ? (float)(std::sqrt(2.0 * (double)GSASR_SPLAT_GRAD_TAU) * (1.0 + 1e-6)) : 0.f;
     if (P.bounded && adapt) {
         const int B = batch_of(d);
         const double dpx = (double)d->dmax * 0.5 * (double)(d->w - 1), dpy = (double)d->dmax * 0.5 * (double)((B > 1 ? d->slot : d->h) - 1);

@@ -648,19 +648,32 @@ __global__ __launch_bounds__(256) void k_bin(Params P, const float *__restrict__
                 bc.x = lo4[1]; bc.y = hi4[1];
                 bb.y |= 0x8000u;
             }
-            {   // Rows the Gaussian-stationary backward sweeps: the window's rows rounded up to a whole number of trips
+            {   // The window the Gaussian-stationary backward sweeps (round 6): that of min(tau', GSASR_SPLAT_GRAD_TAU) -- a
+                // Gaussian's gradient sums over its own pixels only, so its window does not grow with the K of the forward's
+                // bound (include/gsasr_splat.h).  A Gaussian whose smaller window holds no pixel keeps the forward's.
+                Box w = b;
+                bool test_b = needs_test;
+                if (P.kb_max > 0.f && kw > P.kb_max) {
+                    const Box t = gaussian_box(sx, sy, x, y, P, g, P.kb_max);
+                    if (t.cls != 2) {
+                        w = t;
+                        test_b = P.bounded && !(P.kb_max * fabsf(sx) * hx + 1.f <= P.dmax * hx && P.kb_max * fabsf(sy) * hy + 1.f <= P.dmax * hy);
+                    }
+                }
+                // Its rows rounded up to a whole number of trips
                 // (8/4/2 rows for 16/32/64-lane columns) when the band has room -- the extra rows lie outside the window
                 // (their terms are < exp(-tau), or fail the dmax test), and the ragged, masked last trip disappears.
                 // Batched canvas: inside the sample's own rows (whatever gradient the caller left in the padding of the
                 // slot must not be read).  Worked out here, once, instead of by every backward wave on its scalar unit.
-                const int bwid = b.c1 - b.c0 + 1, nr = b.r1 - b.r0 + 1;
+                const int bwid = w.c1 - w.c0 + 1, nr = w.r1 - w.r0 + 1;
                 const int rpt = bwid <= 16 ? 8 : (bwid <= BWD_LX21_MAX ? 6 : (bwid <= 32 ? 4 : 2));      // (bwd_sweep's rows per trip)
                 const int pad = (rpt - nr % rpt) % rpt;
                 const int lo = max(P.row0, g.base), hi = min(P.row1, g.base + g.h) - 1;
-                int r0p = b.r0, r1p = b.r1;
+                int r0p = w.r0, r1p = w.r1;
                 if (r1p + pad <= hi) r1p += pad;
                 else if (r0p - pad >= lo) r0p -= pad;
                 bc.z = (unsigned)r0p | ((unsigned)r1p << 16);
+                bc.w = (unsigned)w.c0 | (test_b ? 0x8000u : 0u) | ((unsigned)w.c1 << 16);      // its columns | "a pixel may need the dmax test"
             }
         }
     }

@@ -170,6 +170,19 @@ typedef struct gsasr_dims {
  * reference; tau < 0 never skips. */
 #define GSASR_SPLAT_DEFAULT_EPS 1e-5f
 #define GSASR_SPLAT_EXACT_CUTOFF 104.0f
+/* The BACKWARD's own cutoff under the adaptive default (round 6).  The forward's tau' grows with K because the skipped terms of
+ * up to K Gaussians add up on ONE pixel (GSASR's 16 Gaussians per LR pixel: K ~ 7 000, tau' = 20.4).  A Gaussian's gradient is a
+ * sum over ITS OWN pixels only -- nothing accumulates across Gaussians -- so its window needs no more than the tau at which the
+ * integrals themselves are complete: outside the ellipse {exponent >= -tau} lies exp(-tau) of a Gaussian's mass,
+ * (2 / sqrt(pi)) sqrt(tau) exp(-tau) of its first and (1 + tau) exp(-tau) of its second moments (the d/dmu, d/dsigma, d/drho
+ * integrands): 1.1e-7, 5e-7 and 1.9e-6 at tau = 16 -- the LOWEST value the data-derived tau' of the forward ever takes (sparse
+ * plans), i.e. the per-Gaussian gradient accuracy every plan with few Gaussians per pixel has always had.  The
+ * Gaussian-stationary and home-tile backward sweep the window of min(tau', GSASR_SPLAT_GRAD_TAU), whatever K is.  (14.3 --
+ * "complete to 1e-5" -- was measured first: another 6% on the backward, and on stacked Gaussians 1.3e-5 of the tensor's
+ * max-abs on d/dmu, whose odd integrand leaves a signed value far below the unsigned mass the truncation is relative to: no
+ * margin under the per-Gaussian parity bar.)  Whole images and batched canvases only (a row band's share of a gradient may be
+ * all tail); an explicit cutoff (dims.cutoff, GSASR_SPLAT_CUTOFF) is used as given by both directions. */
+#define GSASR_SPLAT_GRAD_TAU 16.0f
 
 GSASR_API int gsasr_abi_version(void);
 GSASR_API const char *gsasr_last_error(void);

@@ -250,3 +250,40 @@ def test_near_dead_gaussians_are_charged_to_the_budget(dmax, dev):
     assert -3e-4 * want <= tau - want <= 0.35, (tau, want, tau0)
     err = _within_eps_of_exact(sig2, xy2, col2, H, W, dmax, dev, plan)
     assert err > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["gaussian", "home"])
+@pytest.mark.parametrize("case", ["dense", "stacked"])
+def test_backward_window_of_its_own_cutoff_is_complete(case, kernel):
+    """Round 6: under the adaptive default the Gaussian-stationary and home-tile backward sweep the window of
+    min(tau', GSASR_SPLAT_GRAD_TAU = 16) -- a gradient sums over its own pixels, so its window does not grow with the K of the
+    forward's bound (include/gsasr_splat.h).  Against the same backward with the FORWARD's tau' given explicitly (an explicit
+    cutoff is used as given by both directions): every Gaussian's row within a fifth of the per-Gaussian parity bar (the tail
+    between the two ellipses holds < 2e-6 of a Gaussian's moments), whatever K is -- 16 Gaussians per LR pixel (tau' ~ 20), and every Gaussian
+    stacked on one spot (K = N: tau' = the conservative tau)."""
+    from gsasr_amd import _cabi, synthetic
+    dev = torch.device("cuda:0")
+    sig, xy, col, H, W = synthetic.kernel_inputs(48, 48, 4.0, seed=21, gpp=16)
+    if case == "stacked":
+        xy = xy.clone()
+        xy[:] = torch.tensor([0.1, -0.2]) + 0.01 * torch.randn(xy.shape, generator=torch.Generator().manual_seed(3))
+    a, b, c = (t.contiguous().to(dev) for t in (sig, xy, col))
+    wgt = synthetic.grad_image(H, W, 22).to(dev)
+    flag = _cabi.FLAG_BWD_HOME if kernel == "home" else _cabi.FLAG_BWD_GAUSSIAN
+    plan = _cabi.plan(a, b, c, H, W, 0.5, flags=flag)
+    tau_w, _ = _cabi.plan_cutoff(plan)
+    assert tau_w > 18.0                                   # the forward's cutoff is well above the backward's own
+    got = _cabi.backward_new(plan, a, b, c, wgt)
+    ref = _cabi.backward_new(_cabi.plan(a, b, c, H, W, 0.5, cutoff=tau_w, flags=flag), a, b, c, wgt)
+    differs = False
+    for g, r, name in zip(got, ref, ("sigmas", "coords", "colors")):
+        g, r = g.cpu().numpy(), r.cpu().numpy()
+        differs = differs or not np.array_equal(g, r)
+        # a fifth of the per-Gaussian parity bar (5e-4 of the row + 1e-5 of the tensor's max-abs, tests/test_bwd_tile.py).  The
+        # floor matters: d/dx, d/dy integrate an ODD weight, so a row's signed value can be far below the Gaussian's unsigned
+        # mass, which is what the truncation is 1e-5 of
+        tol = 1e-4 * np.abs(r).max(axis=1, keepdims=True) + 2e-6 * np.abs(r).max()
+        ratio = float((np.abs(g - r) / tol).max())
+        assert ratio <= 1.0, (name, ratio, float(np.abs(g - r).max()), float(np.abs(r).max()))
+    assert differs                                        # (the smaller window IS in force)
