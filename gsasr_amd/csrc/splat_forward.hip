@@ -932,17 +932,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // chunk k+1 are in flight while chunk k is evaluated.  No barriers, no shared lists: the four waves of a workgroup only share
 // the tile.  A tile whose list overflowed its capacity is rendered by the one-level search (fwd_tile); the "large" class is
 // scanned by every tile as before.
-template <bool BOUNDED, int PARTS, bool PAIR>
-__global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanView V, float *__restrict__ img, int tiles_x)
+// PER_SUB (round 6): one workgroup per SUB-TILE (64 x PARTS threads) instead of per tile.  The waves of a tile never shared more
+// than its list, and a wave's work is the unit the chip's 1024 SIMDs are dealt: 1152 tile workgroups of four (eight) waves put
+// five on some CUs and four on the others (config 5's canvas: the forward took as long as the fives), 4608 (x PARTS) sub-tile
+// workgroups even out (profiles/r06_fwd_persub.txt).  The four sub-tiles of a tile stay on one XCD (consecutive units of its band).
+template <bool BOUNDED, int PARTS, bool PAIR, bool PER_SUB = false>
+__global__ __launch_bounds__(PER_SUB ? 64 * PARTS : 256 * PARTS) void k_render_fwd_list(Params P, PlanView V, float *__restrict__ img, int tiles_x)
 {
-    const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const unsigned unit = xcd_swizzle(blockIdx.x, gridDim.x);
+    const unsigned t = PER_SUB ? unit >> 2 : unit;
     const int bx = (int)(t % (unsigned)tiles_x), by = (int)(t / (unsigned)tiles_x);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sub = wv & 3;
-    const unsigned part = (unsigned)(wv >> 2);
-    __shared__ float4 s_stage[4 * PARTS][STAGE_F4];
-    __shared__ float s_part[PARTS > 1 ? 4 : 1][6][64];
+    const int sub = PER_SUB ? (int)(unit & 3u) : wv & 3;
+    const unsigned part = (unsigned)(PER_SUB ? wv : wv >> 2);
+    constexpr int NSUB = PER_SUB ? 1 : 4;      // sub-tiles of this workgroup
+    __shared__ float4 s_stage[NSUB * PARTS][STAGE_F4];
+    __shared__ float s_part[PARTS > 1 ? NSUB : 1][6][64];
     float4 *stage = s_stage[wv];
     v2f ar = {0.f, 0.f}, ag = {0.f, 0.f}, ab = {0.f, 0.f};
     const int bx0 = bx * 4 * SUBX, by0 = P.row0 + by * SUBY;
@@ -1001,13 +1007,12 @@ __global__ __launch_bounds__(256 * PARTS) void k_render_fwd_list(Params P, PlanV
         }
     }
     if (PARTS > 1) {
-        if (wv >= 4) {
-            float (*o)[64] = s_part[sub];
+        float (*o)[64] = s_part[PER_SUB ? 0 : sub];
+        if (part != 0u) {
             o[0][lane] = ar.x; o[1][lane] = ar.y; o[2][lane] = ag.x; o[3][lane] = ag.y; o[4][lane] = ab.x; o[5][lane] = ab.y;
         }
         __syncthreads();
-        if (wv >= 4) return;
-        float (*o)[64] = s_part[sub];
+        if (part != 0u) return;
         ar.x += o[0][lane]; ar.y += o[1][lane]; ag.x += o[2][lane]; ag.y += o[3][lane]; ab.x += o[4][lane]; ab.y += o[5][lane];
     }
     if (sx0 < P.w) fwd_store(P, V, img, sx0, by0, lane, ar, ag, ab);
@@ -1267,7 +1272,23 @@ int gsasr_splat_forward(const gsasr_dims *dims, const void *workspace, size_t wo
                                else hipLaunchKernelGGL((K<B, T, false>), grid, block, 0, st, P, V, img, tx4); } while (0)
 #define GSASR_F2(K) do { if (P.bounded) { if (two) GSASR_F3(K, true, 2); else GSASR_F3(K, true, 1); } \
                          else { if (two) GSASR_F3(K, false, 2); else GSASR_F3(K, false, 1); } } while (0)
-        if (lists) GSASR_F2(k_render_fwd_list);
+        // from lists: one workgroup per sub-tile with its list dealt to two waves (k_render_fwd_list, PER_SUB) where that evens
+        // out the load: tile workgroups put ceil(tiles / 256 CUs) waves on the fullest SIMD, half-list waves
+        // ceil(2 sub-tiles / 1024 SIMDs) halves.  736^2 at 16 per LR pixel 158.6 -> 146.8 us, 832^2 197 -> 182, 896^2 222 -> 204,
+        // 640^2 128 -> 117; where the tiles deal out evenly (704^2, 1024^2) the tile form is 2-3% ahead and stays
+        // (profiles/r06_fwd_persub.txt).  development: GSASR_SPLAT_FWD_PERSUB=0|1
+        static const int persub_env = dev_switch("GSASR_SPLAT_FWD_PERSUB") ? atoi(dev_switch("GSASR_SPLAT_FWD_PERSUB")) : -1;
+        const long on_simd_tile = 2 * (((long)grid.x + 255) / 256), on_simd_half = (8 * (long)grid.x + 1023) / 1024;   // in half-lists
+        const bool persub = lists && (persub_env >= 0 ? persub_env == 1 : (!parts_env && on_simd_half < on_simd_tile));
+        if (persub) {
+            const bool two = parts_env != 1;
+            const dim3 gs(grid.x * 4u), bs(two ? 128 : 64);
+#define GSASR_F4(B, T) do { if (pair) hipLaunchKernelGGL((k_render_fwd_list<B, T, true, true>), gs, bs, 0, st, P, V, img, tx4); \
+                            else hipLaunchKernelGGL((k_render_fwd_list<B, T, false, true>), gs, bs, 0, st, P, V, img, tx4); } while (0)
+            if (P.bounded) { if (two) GSASR_F4(true, 2); else GSASR_F4(true, 1); }
+            else { if (two) GSASR_F4(false, 2); else GSASR_F4(false, 1); }
+#undef GSASR_F4
+        } else if (lists) GSASR_F2(k_render_fwd_list);
         else GSASR_F2(k_render_fwd2);
 #undef GSASR_F2
 #undef GSASR_F3
