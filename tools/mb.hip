@@ -91,6 +91,17 @@ int main(int argc, char **argv)
         xy[2 * k + 1] = (my + 1 - 1.f / H) * H / (H - 1) - 1.f;
     }
     for (auto &g : grad) g = ud(rng);
+    if (getenv("MB_SHUFFLE") && atoi(getenv("MB_SHUFFLE"))) {   // the Gaussians in random order instead of the decoder's raster order
+        std::vector<int> perm(n);
+        for (int k = 0; k < n; ++k) perm[k] = k;
+        std::shuffle(perm.begin(), perm.end(), rng2);
+        std::vector<float> s2(sig.size()), x2(xy.size()), c2(col.size());
+        for (int k = 0; k < n; ++k) {
+            for (int c = 0; c < 3; ++c) { s2[3 * k + c] = sig[3 * (size_t)perm[k] + c]; c2[3 * k + c] = col[3 * (size_t)perm[k] + c]; }
+            x2[2 * k] = xy[2 * (size_t)perm[k]]; x2[2 * k + 1] = xy[2 * (size_t)perm[k] + 1];
+        }
+        sig.swap(s2); xy.swap(x2); col.swap(c2);
+    }
 
     const unsigned flags = argc > 8 ? (unsigned)atoi(argv[8]) : 0u;   // 6 = overwrite image + grads
     gsasr_dims d{n, H, W, 3, dmax, 0, H, tau, flags};
