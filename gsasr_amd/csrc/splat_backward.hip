@@ -618,6 +618,7 @@ int bwd_mode(const gsasr_dims *dims, const Layout &L)
     else if (const unsigned rf = registered_choice(dims).flags & (GSASR_FLAG_BWD_GAUSSIAN | GSASR_FLAG_BWD_TILE | GSASR_FLAG_BWD_HOME))
         mode = (rf & GSASR_FLAG_BWD_TILE) ? 1 : (rf & GSASR_FLAG_BWD_HOME) ? 3 : 0;
     else if (bwd_env()) mode = bwd_env() - 1;
+    else if (mode == 0 && bwd_wants_home(dims)) mode = 3;
     if (L.part_k == 0 && mode == 1) mode = (f & GSASR_FLAG_CHW_GRAD) ? 2 : 0;   // a forward-only plan has no slots
     return mode;
 }

@@ -274,3 +274,33 @@ def test_batched_canvas_home_backward(gpp, dev):
     tot.backward()
     for b in range(3):
         per_gaussian_ok(res["home"][b], pa.grad[b].cpu().numpy(), f"sample {b} vs loop")
+
+
+def test_dense_whole_images_take_the_home_tile_backward_by_default(dev):
+    """The library's own rule (splat_common.h:bwd_wants_home): denser than one Gaussian per two pixels on at least 1536 tiles of
+    32 x 16 px.  Both kernels are deterministic, so "the default ran the home-tile kernel" is bit-equality with the flagged run
+    (and a last-bits difference from the Gaussian-stationary one, which sums in another order); one tile row fewer, a row band
+    or a sparser image keep the Gaussian-stationary kernel."""
+    from gsasr_amd import _cabi
+    sig, xy, col, H, W, wgt = _synth(192, 256, 4.0, seed=31, gpp=2)       # 768 x 1024: 48 x 32 = 1536 tiles; 98 304 Gaussians
+    rep = 5                                                              # the rule reads the density: five jittered copies, 491 520 > 768 * 1024 / 2
+    sig, xy, col = (np.tile(a, (rep, 1)) for a in (sig, xy, col))
+    xy = xy + np.random.default_rng(5).normal(0.0, 2.0 / W, xy.shape).astype(np.float32)
+    dflt = _backward(sig, xy, col, wgt, H, W, 0.1, dev, 0)
+    home = _backward(sig, xy, col, wgt, H, W, 0.1, dev, _home())
+    gaus = _backward(sig, xy, col, wgt, H, W, 0.1, dev, _cabi.FLAG_BWD_GAUSSIAN)
+    for d, h_, g in zip(dflt, home, gaus):
+        assert np.array_equal(d, h_)
+        assert not np.array_equal(d, g)
+        assert np.abs(d - g).max() <= 2e-5 * np.abs(g).max()
+    # one tile row fewer (1504 tiles): the Gaussian-stationary kernel, bit for bit
+    Hs = H - 16
+    dflt = _backward(sig, xy, col, wgt[:Hs], Hs, W, 0.1, dev, 0)
+    gaus = _backward(sig, xy, col, wgt[:Hs], Hs, W, 0.1, dev, _cabi.FLAG_BWD_GAUSSIAN)
+    for d, g in zip(dflt, gaus):
+        assert np.array_equal(d, g)
+    # a row band of the dense image: the Gaussian-stationary kernel as well
+    dflt = _backward(sig, xy, col, wgt, H, W, 0.1, dev, 0, rows=(64, 256))
+    gaus = _backward(sig, xy, col, wgt, H, W, 0.1, dev, _cabi.FLAG_BWD_GAUSSIAN, rows=(64, 256))
+    for d, g in zip(dflt, gaus):
+        assert np.array_equal(d, g)

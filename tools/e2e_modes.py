@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Host API forward + backward per shape with the two backward kernels (which one `BACKWARD_KERNEL = "auto"` should pick).
+"""Host API forward + backward per shape with the three backward kernels (which one `BACKWARD_KERNEL = "auto"` should pick).
 Development aid."""
 import os
 import sys
@@ -29,10 +29,11 @@ def bench(fn, n=20, repeats=4):
 
 for h_lr, w_lr, scale, gpp, dmax, B in ((256, 256, 4.0, 1, 0.1, 1), (128, 128, 4.0, 1, 0.5, 1), (48, 48, 4.0, 16, 0.5, 1), (48, 48, 4.0, 16, 0.5, 16),
                                         (256, 256, 2.0, 1, 0.5, 1), (128, 128, 8.0, 1, 0.1, 1), (512, 512, 8.0, 1, 0.1, 1), (64, 64, 3.0, 16, 0.5, 8),
-                                        (96, 96, 2.0, 16, 0.5, 4), (64, 64, 12.0, 1, 0.1, 1)):
+                                        (96, 96, 2.0, 16, 0.5, 4), (64, 64, 12.0, 1, 0.1, 1), (256, 256, 4.0, 16, 0.1, 1), (320, 320, 4.0, 16, 0.1, 1),
+                                        (192, 192, 4.0, 16, 0.5, 1), (384, 384, 3.0, 16, 0.1, 1), (64, 64, 4.0, 16, 0.5, 16)):
     H, W = int(h_lr * scale), int(w_lr * scale)
     res = {}
-    for kernel in ("gaussian", "tile"):
+    for kernel in ("gaussian", "tile", "home"):
         gsp.BACKWARD_KERNEL = kernel
         if B == 1:
             p = synthetic.gs_parameters(h_lr, w_lr, seed=0, gpp=gpp).to(dev)
@@ -51,4 +52,4 @@ for h_lr, w_lr, scale, gpp, dmax, B in ((256, 256, 4.0, 1, 0.1, 1), (128, 128, 4
         res[kernel] = bench(fn)
     n = h_lr * w_lr * gpp
     print(f"B={B:2d} {H}x{W} N={n:7d} px/G={H * W / n:6.1f} dmax={dmax}: gaussian {res['gaussian'] * 1e6:8.1f} us  tile {res['tile'] * 1e6:8.1f} us  "
-          f"-> {'tile' if res['tile'] < res['gaussian'] else 'gaussian'}")
+          f"home {res['home'] * 1e6:8.1f} us  -> {min(res, key=res.get)}")
