@@ -662,10 +662,20 @@ int splat_backward(const float *sigmas, const float *coords, const float *colors
         if (mode == 3) {
             // home-tile kernel (splat_backward_home.hip).  Tile shape by density: 32 x 16-px tiles with eight waves where a tile
             // holds hundreds of Gaussians (GSASR's 16 per LR pixel), larger tiles with four waves for sparse plans -- a round
-            // should find a wave's worth of Gaussians per wave.  development: GSASR_SPLAT_HOME_VARIANT=0|1|2
+            // should find a wave's worth of Gaussians per wave.  development: GSASR_SPLAT_HOME_VARIANT=0|1|2|3
             static const int var_env = dev_switch("GSASR_SPLAT_HOME_VARIANT") ? atoi(dev_switch("GSASR_SPLAT_HOME_VARIANT")) : -1;
             const double per_cell = (double)dims->s / (double)(L.ncells > 0 ? L.ncells : 1);
-            const int variant = var_env >= 0 ? var_env : per_cell >= 64.0 ? 0 : per_cell >= 24.0 ? 1 : 2;
+            int variant = var_env >= 0 ? var_env : per_cell >= 64.0 ? 0 : per_cell >= 24.0 ? 1 : 2;
+            if (var_env < 0 && variant == 0) {
+                // 32 x 16-px tiles run two workgroups of eight waves per CU: 512 at a time.  Where their number leaves the last set
+                // mostly empty (768^2: 1152 = 2.25 sets; 896^2: 3.06) one-cell tiles with four waves even the tail out: 768^2
+                // 240 -> 233 us, 896^2 325 -> 309, 640^2 191 -> 173; at whole sets (512^2, 1024^2) the larger tile is 2-3% ahead
+                // (profiles/r06_home_default.txt)
+                const int cps = P.batch > 1 ? P.slot / CELL : P.ncy;
+                const long n0 = (long)((P.ncx + 1) / 2) * (long)cps * (long)P.batch;
+                const long over = n0 % 512;
+                if (n0 > 512 && over != 0 && over <= 384) variant = 3;      // (up to one set: nothing to even out)
+            }
             return launch_bwd_home(P, V, grad_img, g_sigmas, g_coords, g_colors, variant, st);
         }
         // Eight Gaussians per wave (k_render_bwd8): built in round 5, parity-green, and SLOWER than one wave per Gaussian --

@@ -489,6 +489,7 @@ int launch_bwd_home(const Params &P, const PlanView &V, const float *grad_img, f
         else hipLaunchKernelGGL((k_render_bwd_home<false, TCX, TCY, W>), grid, block, 0, st, P, V, grad_img, g_sigmas, g_coords, g_colors, tiles_x, tps, cps); } while (0)
     if (variant == 0) GSASR_HOME(2, 1, 8);
     else if (variant == 1) GSASR_HOME(2, 2, 4);
+    else if (variant == 3) GSASR_HOME(1, 1, 4);
     else GSASR_HOME(4, 2, 4);
 #undef GSASR_HOME
     HIP_TRY(hipGetLastError());

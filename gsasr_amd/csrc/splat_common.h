@@ -335,16 +335,17 @@ inline bool bt_tall(const gsasr_dims *d)
     return (double)d->h * (double)d->w >= 64.0 * (double)(d->s > 0 ? d->s : 1);
 }
 
-// The home-tile backward by default (round 6, after the backward's own cutoff): whole single images denser than one Gaussian per
-// two pixels (GSASR's 16 per LR pixel up to x5) with at least 1536 tiles of 32 x 16 px.  Measured against the Gaussian-stationary
+// The home-tile backward by default (round 6, after the backward's own cutoff): whole images and batched canvases denser than one Gaussian per
+// two pixels (GSASR's 16 per LR pixel up to x5) with at least 1024 tiles of 32 x 16 px.  Measured against the Gaussian-stationary
 // kernel on three boxes (profiles/r06_home_default.txt): 1024^2 at 16 per LR pixel -8..-9% (bench c2x16 backward 362 -> 331 us),
-// 1280^2 -8%, 1408^2 -12%, 1536^2 -16%, x3 -15%; 896^2 level, 768^2 level to +2% (their tiles deal out unevenly over the CUs); eight per LR
+// 1280^2 -8%, 1408^2 -12%, 1536^2 -16%, x3 -15%; 896^2 and 768^2 -7% with one-cell tiles (launch_bwd_home's variant 3), 640^2 level; eight per LR
 // pixel -4% but the tile-stationary kernel's range; four per LR pixel +21%, 512^2 +7%: those keep what they had.
 inline bool bwd_wants_home(const gsasr_dims *d)
 {
-    if (d->batch > 1 || d->row0 != 0 || d->row1 != d->h) return false;
+    if (d->row0 != 0 || d->row1 != d->h) return false;
+    // (a batched canvas counts as the image it is: h = batch x slot rows)
     const long tiles = (long)((d->w + 31) / 32) * (long)((d->h + 15) / 16);
-    return (double)d->h * (double)d->w < 2.0 * (double)d->s && tiles >= 1536;
+    return (double)d->h * (double)d->w < 2.0 * (double)d->s && tiles >= 1024;
 }
 
 inline int bwd_part_k(const gsasr_dims *d)

@@ -141,10 +141,10 @@ def _backward_kernel(n_pixels: int, n_gaussians: int, shape=None) -> int:
                     return f
     if _tile_backward(n_pixels, n_gaussians):
         return _cabi.FLAG_BWD_TILE
-    # round 6 (the library's own rule, splat_common.h:bwd_wants_home): denser than one Gaussian per two pixels on at least 1536 tiles
-    # of 32 x 16 px -- through this API 1024^2 at 16 per LR pixel -5%, 1280^2 -7%, 1152^2 x3 -17%, a batch of 16 x 256^2 -4%;
-    # 768^2 and the 16 x 192^2 training batch +2% and keep the Gaussian-stationary kernel (profiles/r06_home_default.txt)
-    if n_pixels < 2 * n_gaussians and n_pixels >= 1536 * 512:
+    # round 6 (the library's own rule, splat_common.h:bwd_wants_home): denser than one Gaussian per two pixels on at least 1024 tiles
+    # of 32 x 16 px -- through this API 1024^2 at 16 per LR pixel -5%, 1280^2 -7%, 1152^2 x3 -17%, a batch of 16 x 256^2 -4%
+    # (profiles/r06_home_default.txt)
+    if n_pixels < 2 * n_gaussians and n_pixels >= 1024 * 512:
         return _cabi.FLAG_BWD_HOME
     return _cabi.FLAG_BWD_GAUSSIAN
 

@@ -89,8 +89,8 @@ enum gsasr_status {
                                          atomics, deterministic.  Needs nothing from the plan beyond what the Gaussian-stationary
                                          kernel reads; a Gaussian whose window does not fit the region is swept by a whole wave
                                          (that kernel's code), so any input stays correct.  Interleaved [rows, w, 3] gradients.
-                                         The default of whole single images denser than one Gaussian per two pixels on at least
-                                         1536 tiles of 32 x 16 px (1024^2 at GSASR's 16 per LR pixel: -8..-9% against the
+                                         The default of whole images and batched canvases denser than one Gaussian per two pixels on
+                                         at least 1024 tiles of 32 x 16 px (1024^2 at GSASR's 16 per LR pixel: -8..-9% against the
                                          Gaussian-stationary kernel) */
 #define GSASR_FLAG_COUNTERS_CLEAN 1024u /* plan: the caller keeps this workspace between plans and promises that the
                                          per-cell counters of the parity given by GSASR_FLAG_PARITY are zero: the plan

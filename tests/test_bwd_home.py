@@ -277,10 +277,10 @@ def test_batched_canvas_home_backward(gpp, dev):
 
 
 def test_dense_whole_images_take_the_home_tile_backward_by_default(dev):
-    """The library's own rule (splat_common.h:bwd_wants_home): denser than one Gaussian per two pixels on at least 1536 tiles of
+    """The library's own rule (splat_common.h:bwd_wants_home): denser than one Gaussian per two pixels on at least 1024 tiles of
     32 x 16 px.  Both kernels are deterministic, so "the default ran the home-tile kernel" is bit-equality with the flagged run
     (and a last-bits difference from the Gaussian-stationary one, which sums in another order); one tile row fewer, a row band
-    or a sparser image keep the Gaussian-stationary kernel."""
+    or too few tiles keep the Gaussian-stationary kernel."""
     from gsasr_amd import _cabi
     sig, xy, col, H, W, wgt = _synth(192, 256, 4.0, seed=31, gpp=2)       # 768 x 1024: 48 x 32 = 1536 tiles; 98 304 Gaussians
     rep = 5                                                              # the rule reads the density: five jittered copies, 491 520 > 768 * 1024 / 2
@@ -293,8 +293,20 @@ def test_dense_whole_images_take_the_home_tile_backward_by_default(dev):
         assert np.array_equal(d, h_)
         assert not np.array_equal(d, g)
         assert np.abs(d - g).max() <= 2e-5 * np.abs(g).max()
-    # one tile row fewer (1504 tiles): the Gaussian-stationary kernel, bit for bit
-    Hs = H - 16
+    # 768 x 768: 1152 tiles = 2.25 sets of the 512 workgroups the chip runs at a time -- the one-cell tile shape (launch_bwd_home's
+    # variant 3; the image above runs whole sets of 32 x 16-px tiles)
+    s2, x2, c2, H2, W2, w2 = _synth(192, 192, 4.0, seed=33, gpp=2)
+    s2, x2, c2 = (np.tile(a, (rep, 1)) for a in (s2, x2, c2))
+    x2 = x2 + np.random.default_rng(6).normal(0.0, 2.0 / W2, x2.shape).astype(np.float32)
+    dflt = _backward(s2, x2, c2, w2, H2, W2, 0.25, dev, 0)
+    home = _backward(s2, x2, c2, w2, H2, W2, 0.25, dev, _home())
+    gaus = _backward(s2, x2, c2, w2, H2, W2, 0.25, dev, _cabi.FLAG_BWD_GAUSSIAN)
+    for d, h_, g in zip(dflt, home, gaus):
+        assert np.array_equal(d, h_)
+        assert not np.array_equal(d, g)
+        assert np.abs(d - g).max() <= 2e-5 * np.abs(g).max()
+    # 31 tile rows of 32 (992 tiles): the Gaussian-stationary kernel, bit for bit
+    Hs = 496
     dflt = _backward(sig, xy, col, wgt[:Hs], Hs, W, 0.1, dev, 0)
     gaus = _backward(sig, xy, col, wgt[:Hs], Hs, W, 0.1, dev, _cabi.FLAG_BWD_GAUSSIAN)
     for d, g in zip(dflt, gaus):
